@@ -1,0 +1,162 @@
+/*
+ * mgr.h - C ABI of libmgr.so: the MI355X (gfx950) BiLSTM + CTC training / decode hot path.
+ *
+ * The reference (AlexGidiotis/Multimodal-Gesture-Recognition-with-LSTMs-and-CTC) has NO native or FFI
+ * interface: its hot path is whatever Keras 2.1.4 / TensorFlow 1.12.1 execute for the Python call sites
+ * cited on each entry point below (paths relative to the reference root).  This header is therefore the
+ * boundary the build defines: plain pointers and sizes, no framework types.  The Python host
+ * (mgr_amd/_capi.py) binds it with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; mgr_last_error() (thread-local) explains.
+ *   - all tensors are row-major fp32 unless stated; integer inputs are int32.
+ *   - device pointers come from mgr_alloc(); the caller owns every buffer; the library keeps no caller
+ *     pointer past the call.  Scratch is passed explicitly (ws, ws_bytes) - see the *_ws_bytes queries.
+ *   - one mgr_ctx per device; calls on a ctx are serialised by the caller.  Kernels are enqueued on the
+ *     ctx's CURRENT stream (mgr_stream_set, 8 streams); mgr_sync() waits for all of them.
+ *   - LSTM weights use the "packed" gate-interleaved layout: column u*4+g of a packed matrix is column
+ *     g*H+u of the Keras matrix (g in i,f,c,o).  mgr_lstm_pack converts both ways.  Z / dZ (gate
+ *     pre-activations and their gradients) use the same interleaved column order.
+ */
+#ifndef MGR_H_
+#define MGR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mgr_ctx mgr_ctx;
+typedef struct mgr_comm mgr_comm;
+
+#define MGR_NUM_STREAMS 8
+#define MGR_NUM_EVENTS 64
+#define MGR_UNIQUE_ID_BYTES 128
+
+/* ---- library / context ------------------------------------------------------------------------------ */
+int mgr_version(void);
+const char* mgr_last_error(void);
+int mgr_device_count(int* n);
+int mgr_ctx_create(int device, mgr_ctx** out);
+int mgr_ctx_destroy(mgr_ctx* ctx);
+/* name may be NULL */
+int mgr_device_info(mgr_ctx* ctx, int* cu_count, size_t* hbm_bytes, char* name, int name_len);
+
+/* ---- memory / streams / events ---------------------------------------------------------------------- */
+int mgr_alloc(mgr_ctx* ctx, size_t bytes, void** dptr);
+int mgr_free(mgr_ctx* ctx, void* dptr);
+int mgr_memset(mgr_ctx* ctx, void* d, int byte, size_t n);
+/* Keras feeds numpy arrays through feed_dict (multimodal_fusion/multimodal.py:264); these are that copy. */
+int mgr_h2d(mgr_ctx* ctx, void* d, const void* h, size_t n);
+int mgr_d2h(mgr_ctx* ctx, void* h, const void* d, size_t n);
+int mgr_d2d(mgr_ctx* ctx, void* dst, const void* src, size_t n);
+int mgr_sync(mgr_ctx* ctx);
+int mgr_stream_set(mgr_ctx* ctx, int idx);
+int mgr_stream_wait(mgr_ctx* ctx, int waiter, int waited); /* waiter waits for everything queued on waited */
+int mgr_event_record(mgr_ctx* ctx, int ev);               /* on the current stream */
+int mgr_event_elapsed_ms(mgr_ctx* ctx, int ev0, int ev1, float* ms);
+/* Per-kernel-family device timing (HIP events around each launch, on the launch stream).
+ * family ids: MGR_K_*.  mgr_prof_get syncs the device and returns accumulated launches / milliseconds. */
+enum {
+  MGR_K_GEMM_NN = 0, MGR_K_GEMM_TN = 1, MGR_K_GEMM_NT = 2, MGR_K_SCAN_FWD = 3, MGR_K_SCAN_BWD = 4,
+  MGR_K_DENSE_FWD = 5, MGR_K_DENSE_BWD = 6, MGR_K_CTC = 7, MGR_K_ADAM = 8, MGR_K_MISC = 9, MGR_K_COUNT = 10
+};
+int mgr_prof_enable(mgr_ctx* ctx, int family_mask);
+int mgr_prof_get(mgr_ctx* ctx, int family, int* launches, float* ms);
+int mgr_prof_reset(mgr_ctx* ctx);
+
+/* ---- K1: GaussianNoise (multimodal_fusion/multimodal.py:103-106) ------------------------------------ */
+/* Y = X + stddev * N(0,1), counter-based RNG keyed by (seed, element index).  X may equal Y. */
+int mgr_add_gaussian_noise(mgr_ctx* ctx, const float* X, float* Y, size_t n, float stddev, uint64_t seed);
+/* mask[i] = (uniform(seed,i) >= p) ? 1/(1-p) : 0  - Keras dropout mask (inverted dropout) */
+int mgr_dropout_mask(mgr_ctx* ctx, float* mask, size_t n, float p, uint64_t seed);
+
+/* ---- K2/K3/K7: Bidirectional(LSTM) (multimodal_fusion/multimodal.py:109-118,159-168;
+ *      audio_network/speech_lstm_ctc_words.py:56-77; skeletal_network/skeletal_lstm_ctc.py:309-335) ---- */
+/* Keras layout <-> packed layout for a [rows, 4H] matrix (W: rows=F, U: rows=H, b: rows=1). */
+int mgr_lstm_pack(mgr_ctx* ctx, const float* src, float* dst, int rows, int H, int to_keras);
+/* dst[c][r] = src[r][c] */
+int mgr_transpose(mgr_ctx* ctx, const float* src, float* dst, int rows, int cols);
+/* Gate pre-activations for all T:  Z[b,t,:] = (X[b,t,:F] (.) mask4[g,b,:]) . Wp + bp   (f32 MFMA GEMM).
+ * X has row stride ldx floats (>= F).  mask4 [4,B,F] may be NULL (no input dropout).  Z is [B,T,4H] packed order. */
+int mgr_lstm_input_proj(mgr_ctx* ctx, const float* X, int ldx, const float* mask4, const float* Wp,
+                        const float* bp, float* Z, int B, int T, int F, int H);
+/* Recurrence. reverse=1 walks t = T-1..0 and writes outputs at their original t (Bidirectional backward
+ * sub-layer).  Y[b,t,0:H] with row stride ldy gets h_t (+ R[b,t,0:H] with stride ldr when R != NULL: the
+ * residual add / concat fusion of multimodal.py:111,117,155).  gates [B,T,H,4] (i,f,g,o after activation) and
+ * cs [B,T,H] are saved for BPTT when non-NULL.  ws from mgr_lstm_scan_ws_bytes (may be 0/NULL). */
+size_t mgr_lstm_scan_ws_bytes(int B, int T, int H);
+int mgr_lstm_scan_fwd(mgr_ctx* ctx, const float* Z, const float* Up, float* Y, int ldy, const float* R,
+                      int ldr, float* gates, float* cs, int B, int T, int H, int reverse, void* ws,
+                      size_t ws_bytes);
+/* BPTT: dY[b,t,0:H] (row stride lddy) is dLoss/dh_t from above; Y (stride ldy) is the layer's own output as
+ * written by scan_fwd WITHOUT residual (needed only through gates/cs here).  Produces dZ [B,T,4H] packed. */
+int mgr_lstm_scan_bwd(mgr_ctx* ctx, const float* dY, int lddy, const float* gates, const float* cs,
+                      const float* Up, float* dZ, int B, int T, int H, int reverse, void* ws, size_t ws_bytes);
+/* Parameter gradients from dZ (all packed layouts, f32 MFMA split-K GEMMs, deterministic slab reduce):
+ *   dWp[F,4H] = sum_rows (X (.) mask4)^T dZ ;  dUp[H,4H] = sum_rows hprev^T dZ ;  dbp[4H] = sum_rows dZ
+ * Hs is the layer's own un-residualed output h (row stride ldh); hprev is its time-shifted view. */
+size_t mgr_lstm_param_grads_ws_bytes(int B, int T, int F, int H);
+int mgr_lstm_param_grads(mgr_ctx* ctx, const float* X, int ldx, const float* mask4, const float* Hs, int ldh,
+                         const float* dZ, float* dWp, float* dUp, float* dbp, int B, int T, int F, int H,
+                         int reverse, void* ws, size_t ws_bytes);
+/* dX[b,t,0:F] (stride lddx) (+)= sum_g mask4[g] (.) (dZ_g . W_g^T); accumulate=1 adds into dX. */
+int mgr_lstm_input_grad(mgr_ctx* ctx, const float* dZ, const float* Wp, const float* mask4, float* dX,
+                        int lddx, int accumulate, int B, int T, int F, int H);
+
+/* ---- K5: Dropout -> Dense -> softmax (multimodal_fusion/multimodal.py:171-179) ---------------------- */
+/* P[B,T,C] = softmax((A (.) dm) . Wd + bd).  A has row stride lda.  The dropout mask dm is either the
+ * explicit array dmask[B,T,D] (parity runs) or, when dmask==NULL and p>0, generated in-kernel from
+ * (seed, element index) exactly as mgr_dropout_mask would; p==0 & dmask==NULL means no dropout. */
+int mgr_dense_softmax_fwd(mgr_ctx* ctx, const float* A, int lda, const float* dmask, float p, uint64_t seed,
+                          const float* Wd, const float* bd, float* P, int B, int T, int D, int C);
+size_t mgr_dense_bwd_ws_bytes(int B, int T, int D, int C);
+/* dWd[D,C], dbd[C], dA[B,T,D] (stride ldda) from dLogits[B,T,C]. */
+int mgr_dense_bwd(mgr_ctx* ctx, const float* A, int lda, const float* dmask, float p, uint64_t seed,
+                  const float* dLogits, const float* Wd, float* dWd, float* dbd, float* dA, int ldda, int B,
+                  int T, int D, int C, void* ws, size_t ws_bytes);
+
+/* ---- K6: ctc_lambda_func (multimodal_fusion/losses.py:4-15 -> K.ctc_batch_cost -> tf.nn.ctc_loss) ---- */
+/* CTC on P[:, skip:, :] with y = softmax(log(P+eps)); labels int32 [B,Lmax] padded -1; blank = C-1 in the
+ * reference.  loss[B] = -log p(l|x).  dLogits[B,T,C] (may be NULL) = gscale * dloss_b/d(Dense logits),
+ * zero on dropped / out-of-length frames. */
+size_t mgr_ctc_ws_bytes(int B, int T, int C, int Lmax);
+int mgr_ctc_loss_grad(mgr_ctx* ctx, const float* P, const int32_t* labels, const int32_t* input_len,
+                      const int32_t* label_len, int B, int T, int C, int Lmax, int skip, int blank, float eps,
+                      float gscale, float* loss, float* dLogits, void* ws, size_t ws_bytes);
+
+/* ---- K7: Adam(clipvalue) + maxnorm (multimodal_fusion/multimodal.py:159-168,206-213) ---------------- */
+/* g' = clip(g*gscale, +-clipvalue) (clipvalue<=0: no clip); m,v,p Keras-Adam update with step size lr_t. */
+int mgr_adam_step(mgr_ctx* ctx, float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1,
+                  float b2, float eps, float clipvalue, float gscale);
+/* per column j of W[rows,cols]: W[:,j] *= clip(n_j,0,maxv)/(eps+n_j), n_j = ||W[:,j]||_2 */
+int mgr_maxnorm_cols(mgr_ctx* ctx, float* W, int rows, int cols, float maxv, float eps);
+/* Out[r, 0:cols] = A[r, 0:cols] + Bm[r, 0:cols] with independent row strides (layers.add, multimodal.py:111) */
+int mgr_add2d(mgr_ctx* ctx, const float* A, int lda, const float* Bm, int ldb, float* Out, int ldo, size_t rows,
+              int cols);
+/* out[0] = mean(x[0:n]) */
+int mgr_mean(mgr_ctx* ctx, const float* x, int n, float* out);
+
+/* ---- K8: data parallel gradient all-reduce (not in the reference; BASELINE.json config 4) ----------- */
+int mgr_comm_unique_id(uint8_t id[MGR_UNIQUE_ID_BYTES]);
+int mgr_comm_init_rank(mgr_ctx* ctx, int nranks, int rank, const uint8_t id[MGR_UNIQUE_ID_BYTES], mgr_comm** out);
+int mgr_allreduce_sum(mgr_comm* comm, float* dbuf, size_t n); /* in place, on the ctx's current stream */
+int mgr_allreduce_max(mgr_comm* comm, float* dbuf, size_t n);
+int mgr_comm_destroy(mgr_comm* comm);
+
+/* ---- K9: decode (multimodal_fusion/sequence_decoding.py:38-53; audio_network/sequence_decoding.py:38-53) */
+/* best[b,t-skip] = argmax_c P[b,t,c] (first index on ties, numpy semantics), prob = that max. */
+int mgr_frame_argmax(mgr_ctx* ctx, const float* P, int B, int T, int C, int skip, int32_t* best, float* prob);
+/* CTC prefix beam search (K.ctc_decode(greedy=False, beam_width) semantics; BASELINE.json config 5).
+ * out[B,T-skip] padded -1 holds the best path (after merge_repeated collapse when merge_repeated!=0). */
+size_t mgr_ctc_beam_ws_bytes(int B, int T, int C, int beam);
+int mgr_ctc_beam_search(mgr_ctx* ctx, const float* P, const int32_t* input_len, int B, int T, int C, int skip,
+                        int blank, int beam, float eps, int merge_repeated, int32_t* out, int32_t* out_len,
+                        double* logp, void* ws, size_t ws_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGR_H_ */

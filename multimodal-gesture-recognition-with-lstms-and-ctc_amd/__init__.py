@@ -1,0 +1,10 @@
+"""mgr_amd - MI355X-native BiLSTM + CTC training / decode path behind the reference's Python surface.
+
+Layout: csrc/ (HIP kernels + C ABI, built to libmgr.so), _capi.py (ctypes), engine.py (device sequencing),
+keras_like.py (Keras-shaped façade), and the reference's three script packages
+(audio_network, skeletal_network, multimodal_fusion) with the same module and symbol names.
+"""
+from .spec import NetworkSpec  # noqa: F401
+
+__all__ = ["NetworkSpec"]
+__version__ = "0.1.0"

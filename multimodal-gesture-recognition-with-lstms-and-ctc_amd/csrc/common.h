@@ -1,0 +1,71 @@
+// Internal helpers shared by the libmgr.so translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mgr.h"
+
+struct mgr_ctx {
+  int device;
+  int cu_count;
+  size_t hbm_bytes;
+  char name[64];
+  hipStream_t streams[MGR_NUM_STREAMS];
+  int cur;
+  hipEvent_t events[MGR_NUM_EVENTS];
+  hipEvent_t xev[64];  // round-robin events for stream_wait
+  int xev_next;
+  // profiling: ring of (start, stop) event pairs per family
+  int prof_mask;
+  struct ProfPair {
+    hipEvent_t a, b;
+  };
+  ProfPair* prof_pairs[MGR_K_COUNT];
+  int prof_n[MGR_K_COUNT];
+  int prof_cap[MGR_K_COUNT];
+  float prof_ms[MGR_K_COUNT];
+  int prof_launches[MGR_K_COUNT];
+};
+
+int mgr_fail(int code, const char* fmt, ...);
+
+#define MGR_HIP(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) return mgr_fail(-2, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+#define MGR_REQUIRE(cond, ...)                  \
+  do {                                          \
+    if (!(cond)) return mgr_fail(-1, __VA_ARGS__); \
+  } while (0)
+
+#define MGR_LAUNCH_CHECK() MGR_HIP(hipGetLastError())
+
+static inline hipStream_t mgr_stream(mgr_ctx* c) { return c->streams[c->cur]; }
+
+// RAII-less profiling bracket: call mgr_prof_begin before and mgr_prof_end after the launches of a family.
+int mgr_prof_begin(mgr_ctx* c, int family);
+int mgr_prof_end(mgr_ctx* c, int family);
+
+static inline size_t mgr_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- device-side RNG: one 64-bit mix per element index (splitmix64 finaliser); stateless ---------------
+__host__ __device__ static inline uint64_t mgr_mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__host__ __device__ static inline uint32_t mgr_rand_u32(uint64_t seed, uint64_t idx) {
+  return (uint32_t)(mgr_mix64(seed * 0xD1342543DE82EF95ull + idx) >> 32);
+}
+// dropout keep decision shared by mgr_dropout_mask and the fused dense kernels
+__host__ __device__ static inline float mgr_drop_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
+  // uniform in [0,1): top 24 bits
+  float u = (float)(mgr_rand_u32(seed, idx) >> 8) * (1.0f / 16777216.0f);
+  return (u >= p) ? inv_keep : 0.0f;
+}

@@ -1,0 +1,318 @@
+// K6: CTC loss + gradient w.r.t. the Dense logits, one workgroup per sample.
+//
+// Restates K.ctc_batch_cost -> tf.nn.ctc_loss as called by ctc_lambda_func
+// (reference multimodal_fusion/losses.py:4-15): y = softmax(log(P[:,skip:]+eps)), blank = C-1,
+// log-space alpha/beta DP over l' = [blank,l1,blank,...,lL,blank].
+//
+// Mapping: wave 0 runs alpha forward in time, wave 1 runs beta backward in time, concurrently.  The
+// extended label sequence lives across the lanes of the wave as (blank,label) PAIRS: lane*PPL+j holds
+// states 2p (blank) and 2p+1 (label p), so the only cross-lane traffic per time step is one
+// shuffle-by-one of the neighbouring pair's label state; the three-way log-sum-exp is max-shifted fp32.
+// Emissions log y(t,.) are precomputed (phase 0, all 4 waves) and software-prefetched a chunk of time
+// steps ahead of the recursion, so the serial chain per step is shuffle -> lse -> add.
+// Phase 2 (all 4 waves) combines alpha+beta into per-class occupancies through an LDS row per thread and
+// chains through softmax(log(P+eps)) and the network's own softmax to dLogits.
+#include "common.h"
+
+namespace {
+
+constexpr float kNegInf = -__builtin_huge_valf();
+
+__device__ __forceinline__ float lse2(float a, float b) {
+  float m = fmaxf(a, b);
+  if (m == kNegInf) return kNegInf;
+  return m + __logf(__expf(a - m) + __expf(b - m));
+}
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+  float m = fmaxf(fmaxf(a, b), c);
+  if (m == kNegInf) return kNegInf;
+  return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+}
+
+template <int PPL>
+struct Chunk {
+  static constexpr int CH = (8 / PPL) >= 2 ? (8 / PPL) : 2;
+  float eb[CH];
+  float el[CH][PPL];
+};
+
+template <int PPL>
+__global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const int32_t* __restrict__ labels,
+                                             const int32_t* __restrict__ input_len,
+                                             const int32_t* __restrict__ label_len, int B, int T, int C, int Lmax,
+                                             int skip, int blank, float eps, float gscale, float* __restrict__ loss,
+                                             float* __restrict__ dLogits, float* __restrict__ LY,
+                                             float* __restrict__ AL, float* __restrict__ BE) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [256][C+1] occupancy rows, then labels
+  constexpr int CH = Chunk<PPL>::CH;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int To = T - skip;
+  int Tp = input_len[b];
+  Tp = Tp < 0 ? 0 : (Tp > To ? To : Tp);
+  int L = label_len[b];
+  L = L < 0 ? 0 : (L > Lmax ? Lmax : L);
+  const int S2 = 2 * (Lmax + 1);
+  float* LYb = LY + (size_t)b * To * C;
+  float* ALb = AL + (size_t)b * To * S2;
+  float* BEb = BE + (size_t)b * To * S2;
+  int* s_lab = reinterpret_cast<int*>(smem + 256 * (C + 1));
+  float* s_logp = reinterpret_cast<float*>(s_lab + Lmax + 1);
+
+  for (int i = tid; i < Lmax; i += 256) {
+    int v = (i < L) ? labels[(size_t)b * Lmax + i] : -1;
+    v = v < 0 ? 0 : (v >= C ? C - 1 : v);
+    s_lab[i] = v;
+  }
+  // ---- phase 0: emissions log y(t,c) = log(P+eps) - log(sum_c (P+eps)) --------------------------------
+  for (int t = tid; t < Tp; t += 256) {
+    const float* row = P + ((size_t)b * T + skip + t) * C;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += row[c] + eps;
+    float ls = logf(s);
+    float* o = LYb + (size_t)t * C;
+    for (int c = 0; c < C; ++c) o[c] = logf(row[c] + eps) - ls;
+  }
+  __syncthreads();
+
+  // ---- phase 1: alpha (wave 0) / beta (wave 1) --------------------------------------------------------
+  if (wave < 2 && Tp > 0) {
+    int lab[PPL];
+    bool vl[PPL], vb[PPL], cs[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      int p = lane * PPL + j;
+      vl[j] = p < L;
+      vb[j] = p <= L;
+      lab[j] = vl[j] ? s_lab[p] : blank;
+    }
+    {
+      int prev_last = __shfl_up(lab[PPL - 1], 1);
+      bool prev_vl = __shfl_up((int)vl[PPL - 1], 1) != 0;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        int p = lane * PPL + j;
+        int pl = (j > 0) ? lab[j - 1] : prev_last;
+        bool pv = (j > 0) ? vl[j - 1] : (lane > 0 && prev_vl);
+        cs[j] = vl[j] && p >= 1 && pv && lab[j] != blank && lab[j] != pl;
+      }
+    }
+    if (wave == 0) {
+      float ab[PPL], al[PPL];
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        int p = lane * PPL + j;
+        ab[j] = (p == 0) ? LYb[blank] : kNegInf;
+        al[j] = (p == 0 && vl[j]) ? LYb[lab[j]] : kNegInf;
+        if (p <= Lmax) *reinterpret_cast<float2*>(ALb + 2 * p) = make_float2(ab[j], al[j]);
+      }
+      Chunk<PPL> cur, nxt;
+      auto load = [&](Chunk<PPL>& ch, int t0) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          int t = t0 + k;
+          t = t < Tp ? t : Tp - 1;
+          const float* r = LYb + (size_t)t * C;
+          ch.eb[k] = r[blank];
+#pragma unroll
+          for (int j = 0; j < PPL; ++j) ch.el[k][j] = r[lab[j]];
+        }
+      };
+      load(cur, 1);
+      for (int t0 = 1; t0 < Tp; t0 += CH) {
+        load(nxt, t0 + CH);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          int t = t0 + k;
+          if (t < Tp) {
+            float carry = __shfl_up(al[PPL - 1], 1);
+            if (lane == 0) carry = kNegInf;
+            float nb[PPL], nl[PPL];
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+              float up = (j > 0) ? al[j - 1] : carry;
+              nb[j] = vb[j] ? cur.eb[k] + lse2(ab[j], up) : kNegInf;
+              nl[j] = vl[j] ? cur.el[k][j] + lse3(al[j], ab[j], cs[j] ? up : kNegInf) : kNegInf;
+            }
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+              ab[j] = nb[j];
+              al[j] = nl[j];
+              int p = lane * PPL + j;
+              if (p <= Lmax) *reinterpret_cast<float2*>(ALb + (size_t)t * S2 + 2 * p) = make_float2(ab[j], al[j]);
+            }
+          }
+        }
+        cur = nxt;
+      }
+      // log p(l|x) = lse(alpha(2L, Tp-1), alpha(2L-1, Tp-1))
+      float fb = kNegInf, fl = kNegInf;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        int p = lane * PPL + j;
+        if (p == L) fb = ab[j];
+        if (p == L - 1) fl = al[j];
+      }
+      // reduce across lanes (exactly one lane holds each)
+      for (int o = 32; o > 0; o >>= 1) {
+        fb = fmaxf(fb, __shfl_xor(fb, o));
+        fl = fmaxf(fl, __shfl_xor(fl, o));
+      }
+      float logp = lse2(fb, fl);
+      if (lane == 0) {
+        loss[b] = -logp;
+        *s_logp = logp;
+      }
+    } else {
+      float bb[PPL], bl[PPL];
+      bool csn[PPL];  // can_skip of pair p+1
+      {
+        int nfirst = __shfl_down((int)cs[0], 1);
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) csn[j] = (j < PPL - 1) ? cs[j + 1] : (lane < 63 && nfirst != 0);
+      }
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        int p = lane * PPL + j;
+        bb[j] = (p == L) ? 0.f : kNegInf;
+        bl[j] = (p == L - 1) ? 0.f : kNegInf;
+        if (p <= Lmax) *reinterpret_cast<float2*>(BEb + (size_t)(Tp - 1) * S2 + 2 * p) = make_float2(bb[j], bl[j]);
+      }
+      Chunk<PPL> cur, nxt;
+      // step index n = 0.. walks t = Tp-2-n; uses emissions at t+1 = Tp-1-n
+      auto load = [&](Chunk<PPL>& ch, int n0) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          int te = Tp - 1 - (n0 + k);
+          te = te > 0 ? te : 0;
+          const float* r = LYb + (size_t)te * C;
+          ch.eb[k] = r[blank];
+#pragma unroll
+          for (int j = 0; j < PPL; ++j) ch.el[k][j] = r[lab[j]];
+        }
+      };
+      load(cur, 0);
+      const int nsteps = Tp - 1;
+      for (int n0 = 0; n0 < nsteps; n0 += CH) {
+        load(nxt, n0 + CH);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          int n = n0 + k;
+          if (n < nsteps) {
+            int t = Tp - 2 - n;
+            float xb[PPL], xl[PPL];  // beta(.,t+1) + emission(.,t+1)
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+              xb[j] = vb[j] ? bb[j] + cur.eb[k] : kNegInf;
+              xl[j] = vl[j] ? bl[j] + cur.el[k][j] : kNegInf;
+            }
+            float nxb = __shfl_down(xb[0], 1);
+            float nxl = __shfl_down(xl[0], 1);
+            if (lane == 63) {
+              nxb = kNegInf;
+              nxl = kNegInf;
+            }
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+              float b1 = (j < PPL - 1) ? xb[j + 1] : nxb;  // blank of pair p+1 (state u+1 for the label state)
+              float l1 = (j < PPL - 1) ? xl[j + 1] : nxl;  // label of pair p+1 (state u+2)
+              bb[j] = vb[j] ? lse2(xb[j], xl[j]) : kNegInf;
+              bl[j] = vl[j] ? lse3(xl[j], b1, csn[j] ? l1 : kNegInf) : kNegInf;
+              int p = lane * PPL + j;
+              if (p <= Lmax) *reinterpret_cast<float2*>(BEb + (size_t)t * S2 + 2 * p) = make_float2(bb[j], bl[j]);
+            }
+          }
+        }
+        cur = nxt;
+      }
+    }
+  }
+  if (Tp == 0 && tid == 0) {
+    loss[b] = __builtin_huge_valf();
+    *s_logp = kNegInf;
+  }
+  __syncthreads();
+  if (dLogits == nullptr) return;
+
+  // ---- phase 2: gradient ------------------------------------------------------------------------------
+  const float logp = *s_logp;
+  float* occ = smem + (size_t)tid * (C + 1);
+  for (int f = tid; f < T; f += 256) {
+    float* out = dLogits + ((size_t)b * T + f) * C;
+    int tt = f - skip;
+    if (tt < 0 || tt >= Tp || logp == kNegInf) {
+      for (int c = 0; c < C; ++c) out[c] = 0.f;
+      continue;
+    }
+    for (int c = 0; c < C; ++c) occ[c] = 0.f;
+    const float* ar = ALb + (size_t)tt * S2;
+    const float* br = BEb + (size_t)tt * S2;
+    for (int p = 0; p <= L; ++p) {
+      float2 a = *reinterpret_cast<const float2*>(ar + 2 * p);
+      float2 be = *reinterpret_cast<const float2*>(br + 2 * p);
+      occ[blank] += __expf(a.x + be.x - logp);
+      if (p < L) occ[s_lab[p]] += __expf(a.y + be.y - logp);
+    }
+    const float* row = P + ((size_t)b * T + f) * C;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += row[c] + eps;
+    float inv = 1.f / s;
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float u = row[c] + eps;
+      float gp = (u * inv - occ[c]) / u;
+      occ[c] = gp;
+      dot += row[c] * gp;
+    }
+    for (int c = 0; c < C; ++c) out[c] = row[c] * (occ[c] - dot) * gscale;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mgr_ctc_ws_bytes(int B, int T, int C, int Lmax) {
+  size_t To = (size_t)(T > 0 ? T : 1);
+  size_t ly = mgr_align_up((size_t)B * To * C * sizeof(float), 256);
+  size_t ab = mgr_align_up((size_t)B * To * 2 * (Lmax + 1) * sizeof(float), 256);
+  return ly + 2 * ab;
+}
+
+int mgr_ctc_loss_grad(mgr_ctx* c, const float* P, const int32_t* labels, const int32_t* input_len,
+                      const int32_t* label_len, int B, int T, int C, int Lmax, int skip, int blank, float eps,
+                      float gscale, float* loss, float* dLogits, void* ws, size_t ws_bytes) {
+  MGR_REQUIRE(c && P && labels && input_len && label_len && loss, "null argument");
+  MGR_REQUIRE(B > 0 && T > skip && skip >= 0 && C > 1 && Lmax > 0, "bad shape B=%d T=%d C=%d Lmax=%d skip=%d", B, T, C, Lmax, skip);
+  MGR_REQUIRE(blank >= 0 && blank < C, "blank %d out of range", blank);
+  MGR_REQUIRE(Lmax + 1 <= 256, "Lmax %d too large (max 255)", Lmax);
+  MGR_REQUIRE(ws && ws_bytes >= mgr_ctc_ws_bytes(B, T, C, Lmax), "workspace too small");
+  size_t To = (size_t)T;  // sized with T (>= T-skip) to keep the query simple
+  size_t ly = mgr_align_up((size_t)B * To * C * sizeof(float), 256);
+  size_t ab = mgr_align_up((size_t)B * To * 2 * (Lmax + 1) * sizeof(float), 256);
+  float* LY = reinterpret_cast<float*>(ws);
+  float* AL = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ly);
+  float* BE = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ly + ab);
+  size_t lds = (size_t)256 * (C + 1) * sizeof(float) + (size_t)(Lmax + 1) * sizeof(int) + 16;
+  MGR_REQUIRE(lds <= 160 * 1024, "C=%d too large for the LDS occupancy tile", C);
+  int npairs = Lmax + 1;
+  int ppl = (npairs + 63) / 64;
+  mgr_prof_begin(c, MGR_K_CTC);
+#define MGR_CTC_LAUNCH(N)                                                                                          \
+  hipLaunchKernelGGL(k_ctc<N>, dim3(B), dim3(256), lds, mgr_stream(c), P, labels, input_len, label_len, B, T, C, \
+                     Lmax, skip, blank, eps, gscale, loss, dLogits, LY, AL, BE)
+  switch (ppl) {
+    case 1: MGR_CTC_LAUNCH(1); break;
+    case 2: MGR_CTC_LAUNCH(2); break;
+    case 3: MGR_CTC_LAUNCH(3); break;
+    default: MGR_CTC_LAUNCH(4); break;
+  }
+#undef MGR_CTC_LAUNCH
+  MGR_LAUNCH_CHECK();
+  mgr_prof_end(c, MGR_K_CTC);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,232 @@
+// Context, memory, streams, events, profiling brackets.
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+int mgr_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" {
+
+int mgr_version(void) { return 100; }
+const char* mgr_last_error(void) { return g_err; }
+
+int mgr_device_count(int* n) {
+  MGR_REQUIRE(n, "null out pointer");
+  hipError_t e = hipGetDeviceCount(n);
+  if (e != hipSuccess) {
+    *n = 0;
+    return mgr_fail(-2, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  return 0;
+}
+
+int mgr_ctx_create(int device, mgr_ctx** out) {
+  MGR_REQUIRE(out, "null out pointer");
+  int n = 0;
+  MGR_HIP(hipGetDeviceCount(&n));
+  MGR_REQUIRE(device >= 0 && device < n, "device %d out of range (%d visible)", device, n);
+  MGR_HIP(hipSetDevice(device));
+  mgr_ctx* c = new mgr_ctx();
+  memset(c, 0, sizeof(*c));
+  c->device = device;
+  hipDeviceProp_t prop;
+  MGR_HIP(hipGetDeviceProperties(&prop, device));
+  c->cu_count = prop.multiProcessorCount;
+  c->hbm_bytes = prop.totalGlobalMem;
+  snprintf(c->name, sizeof(c->name), "%s/%s", prop.name, prop.gcnArchName);
+  for (int i = 0; i < MGR_NUM_STREAMS; ++i) MGR_HIP(hipStreamCreateWithFlags(&c->streams[i], hipStreamNonBlocking));
+  for (int i = 0; i < MGR_NUM_EVENTS; ++i) MGR_HIP(hipEventCreate(&c->events[i]));
+  for (int i = 0; i < 64; ++i) MGR_HIP(hipEventCreateWithFlags(&c->xev[i], hipEventDisableTiming));
+  *out = c;
+  return 0;
+}
+
+int mgr_ctx_destroy(mgr_ctx* c) {
+  if (!c) return 0;
+  hipSetDevice(c->device);
+  hipDeviceSynchronize();
+  for (int i = 0; i < MGR_NUM_STREAMS; ++i) hipStreamDestroy(c->streams[i]);
+  for (int i = 0; i < MGR_NUM_EVENTS; ++i) hipEventDestroy(c->events[i]);
+  for (int i = 0; i < 64; ++i) hipEventDestroy(c->xev[i]);
+  for (int f = 0; f < MGR_K_COUNT; ++f) {
+    for (int i = 0; i < c->prof_cap[f]; ++i) {
+      hipEventDestroy(c->prof_pairs[f][i].a);
+      hipEventDestroy(c->prof_pairs[f][i].b);
+    }
+    delete[] c->prof_pairs[f];
+  }
+  delete c;
+  return 0;
+}
+
+int mgr_device_info(mgr_ctx* c, int* cu_count, size_t* hbm_bytes, char* name, int name_len) {
+  MGR_REQUIRE(c, "null ctx");
+  if (cu_count) *cu_count = c->cu_count;
+  if (hbm_bytes) *hbm_bytes = c->hbm_bytes;
+  if (name && name_len > 0) snprintf(name, name_len, "%s", c->name);
+  return 0;
+}
+
+int mgr_alloc(mgr_ctx* c, size_t bytes, void** dptr) {
+  MGR_REQUIRE(c && dptr, "null argument");
+  MGR_HIP(hipSetDevice(c->device));
+  if (bytes == 0) bytes = 16;
+  MGR_HIP(hipMalloc(dptr, bytes));
+  return 0;
+}
+
+int mgr_free(mgr_ctx* c, void* dptr) {
+  MGR_REQUIRE(c, "null ctx");
+  if (!dptr) return 0;
+  MGR_HIP(hipSetDevice(c->device));
+  MGR_HIP(hipFree(dptr));
+  return 0;
+}
+
+int mgr_memset(mgr_ctx* c, void* d, int byte, size_t n) {
+  MGR_REQUIRE(c && d, "null argument");
+  MGR_HIP(hipMemsetAsync(d, byte, n, mgr_stream(c)));
+  return 0;
+}
+
+int mgr_h2d(mgr_ctx* c, void* d, const void* h, size_t n) {
+  MGR_REQUIRE(c && d && h, "null argument");
+  MGR_HIP(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, mgr_stream(c)));
+  // pageable host memory: make the call synchronous w.r.t. the host buffer (caller may free it)
+  MGR_HIP(hipStreamSynchronize(mgr_stream(c)));
+  return 0;
+}
+
+int mgr_d2h(mgr_ctx* c, void* h, const void* d, size_t n) {
+  MGR_REQUIRE(c && d && h, "null argument");
+  MGR_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, mgr_stream(c)));
+  MGR_HIP(hipStreamSynchronize(mgr_stream(c)));
+  return 0;
+}
+
+int mgr_d2d(mgr_ctx* c, void* dst, const void* src, size_t n) {
+  MGR_REQUIRE(c && dst && src, "null argument");
+  MGR_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, mgr_stream(c)));
+  return 0;
+}
+
+int mgr_sync(mgr_ctx* c) {
+  MGR_REQUIRE(c, "null ctx");
+  for (int i = 0; i < MGR_NUM_STREAMS; ++i) MGR_HIP(hipStreamSynchronize(c->streams[i]));
+  return 0;
+}
+
+int mgr_stream_set(mgr_ctx* c, int idx) {
+  MGR_REQUIRE(c, "null ctx");
+  MGR_REQUIRE(idx >= 0 && idx < MGR_NUM_STREAMS, "stream index %d out of range", idx);
+  c->cur = idx;
+  return 0;
+}
+
+int mgr_stream_wait(mgr_ctx* c, int waiter, int waited) {
+  MGR_REQUIRE(c, "null ctx");
+  MGR_REQUIRE(waiter >= 0 && waiter < MGR_NUM_STREAMS && waited >= 0 && waited < MGR_NUM_STREAMS, "bad stream index");
+  if (waiter == waited) return 0;
+  hipEvent_t ev = c->xev[c->xev_next];
+  c->xev_next = (c->xev_next + 1) & 63;
+  MGR_HIP(hipEventRecord(ev, c->streams[waited]));
+  MGR_HIP(hipStreamWaitEvent(c->streams[waiter], ev, 0));
+  return 0;
+}
+
+int mgr_event_record(mgr_ctx* c, int ev) {
+  MGR_REQUIRE(c && ev >= 0 && ev < MGR_NUM_EVENTS, "bad event index");
+  MGR_HIP(hipEventRecord(c->events[ev], mgr_stream(c)));
+  return 0;
+}
+
+int mgr_event_elapsed_ms(mgr_ctx* c, int ev0, int ev1, float* ms) {
+  MGR_REQUIRE(c && ms && ev0 >= 0 && ev0 < MGR_NUM_EVENTS && ev1 >= 0 && ev1 < MGR_NUM_EVENTS, "bad argument");
+  MGR_HIP(hipEventSynchronize(c->events[ev1]));
+  MGR_HIP(hipEventElapsedTime(ms, c->events[ev0], c->events[ev1]));
+  return 0;
+}
+
+int mgr_prof_enable(mgr_ctx* c, int family_mask) {
+  MGR_REQUIRE(c, "null ctx");
+  c->prof_mask = family_mask;
+  return 0;
+}
+
+static int prof_collect(mgr_ctx* c) {
+  for (int f = 0; f < MGR_K_COUNT; ++f) {
+    for (int i = 0; i < c->prof_n[f]; ++i) {
+      float ms = 0;
+      MGR_HIP(hipEventSynchronize(c->prof_pairs[f][i].b));
+      MGR_HIP(hipEventElapsedTime(&ms, c->prof_pairs[f][i].a, c->prof_pairs[f][i].b));
+      c->prof_ms[f] += ms;
+      c->prof_launches[f] += 1;
+    }
+    c->prof_n[f] = 0;
+  }
+  return 0;
+}
+
+int mgr_prof_get(mgr_ctx* c, int family, int* launches, float* ms) {
+  MGR_REQUIRE(c && family >= 0 && family < MGR_K_COUNT, "bad family");
+  int r = mgr_sync(c);
+  if (r) return r;
+  r = prof_collect(c);
+  if (r) return r;
+  if (launches) *launches = c->prof_launches[family];
+  if (ms) *ms = c->prof_ms[family];
+  return 0;
+}
+
+int mgr_prof_reset(mgr_ctx* c) {
+  MGR_REQUIRE(c, "null ctx");
+  int r = mgr_sync(c);
+  if (r) return r;
+  r = prof_collect(c);
+  if (r) return r;
+  for (int f = 0; f < MGR_K_COUNT; ++f) {
+    c->prof_ms[f] = 0;
+    c->prof_launches[f] = 0;
+  }
+  return 0;
+}
+
+}  // extern "C"
+
+int mgr_prof_begin(mgr_ctx* c, int f) {
+  if (!(c->prof_mask & (1 << f))) return 0;
+  if (c->prof_n[f] == c->prof_cap[f]) {
+    if (c->prof_cap[f] >= 4096) {  // drain instead of growing without bound
+      int r = mgr_sync(c);
+      if (r) return r;
+      r = prof_collect(c);
+      if (r) return r;
+    } else {
+      int ncap = c->prof_cap[f] ? c->prof_cap[f] * 2 : 64;
+      mgr_ctx::ProfPair* np = new mgr_ctx::ProfPair[ncap];
+      for (int i = 0; i < c->prof_cap[f]; ++i) np[i] = c->prof_pairs[f][i];
+      for (int i = c->prof_cap[f]; i < ncap; ++i) {
+        MGR_HIP(hipEventCreate(&np[i].a));
+        MGR_HIP(hipEventCreate(&np[i].b));
+      }
+      delete[] c->prof_pairs[f];
+      c->prof_pairs[f] = np;
+      c->prof_cap[f] = ncap;
+    }
+  }
+  MGR_HIP(hipEventRecord(c->prof_pairs[f][c->prof_n[f]].a, mgr_stream(c)));
+  return 0;
+}
+
+int mgr_prof_end(mgr_ctx* c, int f) {
+  if (!(c->prof_mask & (1 << f))) return 0;
+  MGR_HIP(hipEventRecord(c->prof_pairs[f][c->prof_n[f]].b, mgr_stream(c)));
+  c->prof_n[f] += 1;
+  return 0;
+}

@@ -1,0 +1,423 @@
+// K2 / K7: the dense contractions of the LSTM layers on the f32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   nn : Z[b,t,:]   = (X[b,t,:] (.) mask4[g,b,:]) . Wp + bp            (input projection, all T at once)
+//   tn : dWp / dUp  = sum_{b,t} A[b,t,:]^T dZ[b,t,:]                   (parameter gradients, split over samples)
+//   nt : dX[b,t,:]  = sum_g mask4[g,b,:] (.) (dZ_g[b,t,:] . Wp_g^T)    (gradient to the layer below)
+//
+// One 256-thread workgroup (4 waves, 2x2) computes a 128x128 output tile, each wave a 64x64 sub-tile as 2x2
+// MFMA 32x32 tiles (64 accumulator VGPRs); K advances 16 per LDS stage (8 MFMA k-steps).  Both operands are
+// staged k-major in LDS (As[k][m], Bs[k][n]) so an MFMA fragment read is 32 consecutive floats per half-wave
+// (conflict-free ds_read_b32).  Global->register prefetch of the next stage overlaps the MFMAs of the current.
+// The Keras per-gate input-dropout masks are folded into the B-operand staging (nn, nt: one sample per row
+// tile) or the epilogue (tn), so no masked copy of X is ever materialised.  The gate of a packed column is col&3.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16, LDS_LD = BM + 4;
+
+// element (m,k) at base[m*ld + k]  ("k-contiguous"); thread handles 2 float4 along k
+struct RegTile {
+  float v[8];
+};
+
+__device__ __forceinline__ void load_kc(RegTile& r, const float* __restrict__ base, size_t ld, int m0, int k0, int Mlim,
+                                        int Klim, bool vec, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int idx4 = tid + i * 256;
+    int m = idx4 >> 2, k4 = (idx4 & 3) * 4;
+    int gm = m0 + m, gk = k0 + k4;
+    const float* p = base + (size_t)gm * ld + gk;
+    if (vec && gm < Mlim && gk + 3 < Klim) {
+      float4 t = *reinterpret_cast<const float4*>(p);
+      r.v[i * 4 + 0] = t.x;
+      r.v[i * 4 + 1] = t.y;
+      r.v[i * 4 + 2] = t.z;
+      r.v[i * 4 + 3] = t.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r.v[i * 4 + e] = (gm < Mlim && gk + e < Klim) ? p[e] : 0.f;
+    }
+  }
+}
+__device__ __forceinline__ void store_kc(float (*S)[LDS_LD], const RegTile& r, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int idx4 = tid + i * 256;
+    int m = idx4 >> 2, k4 = (idx4 & 3) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) S[k4 + e][m] = r.v[i * 4 + e];
+  }
+}
+// element (m,k) at base[k*ld + m]  ("m-contiguous"); thread handles 2 float4 along m.
+// kshift/Klo: row index = k0+k+kshift must lie in [Klo,Klim) else zero (time-shifted h_prev view)
+__device__ __forceinline__ void load_mc(RegTile& r, const float* __restrict__ base, size_t ld, int m0, int k0, int Mlim,
+                                        int Klim, bool vec, int tid, int kshift = 0) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int idx4 = tid + i * 256;
+    int k = idx4 >> 5, m4 = (idx4 & 31) * 4;
+    int gm = m0 + m4, gk = k0 + k + kshift;
+    bool kv = (k0 + k) < Klim && gk >= 0 && gk < Klim;
+    const float* p = base + (ptrdiff_t)gk * (ptrdiff_t)ld + gm;
+    if (vec && kv && gm + 3 < Mlim) {
+      float4 t = *reinterpret_cast<const float4*>(p);
+      r.v[i * 4 + 0] = t.x;
+      r.v[i * 4 + 1] = t.y;
+      r.v[i * 4 + 2] = t.z;
+      r.v[i * 4 + 3] = t.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r.v[i * 4 + e] = (kv && gm + e < Mlim) ? p[e] : 0.f;
+    }
+  }
+}
+__device__ __forceinline__ void store_mc(float (*S)[LDS_LD], const RegTile& r, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int idx4 = tid + i * 256;
+    int k = idx4 >> 5, m4 = (idx4 & 31) * 4;
+    *reinterpret_cast<float4*>(&S[k][m4]) = make_float4(r.v[i * 4 + 0], r.v[i * 4 + 1], r.v[i * 4 + 2], r.v[i * 4 + 3]);
+  }
+}
+
+__device__ __forceinline__ void mma_stage(const float (*As)[LDS_LD], const float (*Bs)[LDS_LD], f32x16 (&acc)[2][2], int wr,
+                                          int wc, int lane) {
+  const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int ks = 0; ks < BK / 2; ++ks) {
+    float a0 = As[ks * 2 + lh][wr * 64 + l31];
+    float a1 = As[ks * 2 + lh][wr * 64 + 32 + l31];
+    float b0 = Bs[ks * 2 + lh][wc * 64 + l31];
+    float b1 = Bs[ks * 2 + lh][wc * 64 + 32 + l31];
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+
+// accumulator element -> (row, col) inside the 128x128 tile
+#define ACC_ROW(wr, mt, reg, lane) ((wr) * 64 + (mt) * 32 + ((reg) & 3) + 8 * ((reg) >> 2) + 4 * ((lane) >> 5))
+#define ACC_COL(wc, nt, lane) ((wc) * 64 + (nt) * 32 + ((lane) & 31))
+
+// ------------------------------------------------------------------------------------------------ nn
+// grid: (ceil(N/128), ceil(T/128), B)
+__global__ __launch_bounds__(256) void k_gemm_nn(const float* __restrict__ X, int ldx, const float* __restrict__ mask4,
+                                                 const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                 float* __restrict__ Z, int B, int T, int F, int N, int vecA) {
+  __shared__ __attribute__((aligned(16))) float As[BK][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BK][LDS_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int n0 = blockIdx.x * BN, r0 = blockIdx.y * BM, b = blockIdx.z;
+  const float* Xb = X + (size_t)b * T * ldx;
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  RegTile ra, rb;
+  auto fetch = [&](int k0) {
+    load_kc(ra, Xb, (size_t)ldx, r0, k0, T, F, vecA != 0, tid);
+    load_mc(rb, Wp, (size_t)N, n0, k0, N, F, true, tid);
+    if (mask4) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int idx4 = tid + i * 256;
+        int k = k0 + (idx4 >> 5);
+        if (k < F) {
+          // n is a multiple of 4: the 4 lanes of the float4 are gates 0..3 of one unit
+#pragma unroll
+          for (int g = 0; g < 4; ++g) rb.v[i * 4 + g] *= mask4[((size_t)g * B + b) * F + k];
+        }
+      }
+    }
+  };
+  fetch(0);
+  store_kc(As, ra, tid);
+  store_mc(Bs, rb, tid);
+  __syncthreads();
+  for (int k0 = 0; k0 < F; k0 += BK) {
+    bool more = k0 + BK < F;
+    if (more) fetch(k0 + BK);
+    mma_stage(As, Bs, acc, wr, wc, lane);
+    __syncthreads();
+    if (more) {
+      store_kc(As, ra, tid);
+      store_mc(Bs, rb, tid);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      int col = n0 + ACC_COL(wc, nt, lane);
+      float bias = (col < N) ? bp[col] : 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        int r = r0 + ACC_ROW(wr, mt, reg, lane);
+        if (r < T && col < N) Z[((size_t)b * T + r) * N + col] = acc[mt][nt][reg] + bias;
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ tn
+// slab[z][f][n] = sum over samples b = z, z+SG, ...  of  mask(b,f,n) * sum_t A[b,t+shift,f] * dZ[b,t,n]
+// grid: (ceil(N/128), ceil(F/128), SG)
+__global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, int lda, int shift,
+                                                 const float* __restrict__ mask4, const float* __restrict__ dZ,
+                                                 float* __restrict__ slab, int B, int T, int F, int N, int SG, int vecA) {
+  __shared__ __attribute__((aligned(16))) float As[BK][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BK][LDS_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int n0 = blockIdx.x * BN, f0 = blockIdx.y * BM, z = blockIdx.z;
+  f32x16 tot[2][2];
+  zero_acc(tot);
+  RegTile ra, rb;
+  for (int b = z; b < B; b += SG) {
+    const float* Ab = A + (size_t)b * T * lda;
+    const float* Zb = dZ + (size_t)b * T * N;
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    auto fetch = [&](int k0) {
+      load_mc(ra, Ab, (size_t)lda, f0, k0, F, T, vecA != 0, tid, shift);
+      load_mc(rb, Zb, (size_t)N, n0, k0, N, T, true, tid);
+    };
+    fetch(0);
+    __syncthreads();
+    store_mc(As, ra, tid);
+    store_mc(Bs, rb, tid);
+    __syncthreads();
+    for (int k0 = 0; k0 < T; k0 += BK) {
+      bool more = k0 + BK < T;
+      if (more) fetch(k0 + BK);
+      mma_stage(As, Bs, acc, wr, wc, lane);
+      __syncthreads();
+      if (more) {
+        store_mc(As, ra, tid);
+        store_mc(Bs, rb, tid);
+        __syncthreads();
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        int col = n0 + ACC_COL(wc, nt, lane);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          int f = f0 + ACC_ROW(wr, mt, reg, lane);
+          float m = 1.f;
+          if (mask4 && f < F && col < N) m = mask4[((size_t)(col & 3) * B + b) * F + f];
+          tot[mt][nt][reg] += acc[mt][nt][reg] * m;
+        }
+      }
+  }
+  float* out = slab + (size_t)z * F * N;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      int col = n0 + ACC_COL(wc, nt, lane);
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        int f = f0 + ACC_ROW(wr, mt, reg, lane);
+        if (f < F && col < N) out[(size_t)f * N + col] = tot[mt][nt][reg];
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ nt
+// dX[b,r,f] (+)= sum_j dZ[b,r,j] * Wp[f,j] * mask4[j&3,b,f];  grid: (ceil(F/128), ceil(T/128), B)
+__global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ dZ, const float* __restrict__ Wp,
+                                                 const float* __restrict__ mask4, float* __restrict__ dX, int lddx,
+                                                 int accumulate, int B, int T, int F, int N) {
+  __shared__ __attribute__((aligned(16))) float As[BK][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BK][LDS_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int f0 = blockIdx.x * BN, r0 = blockIdx.y * BM, b = blockIdx.z;
+  const float* Zb = dZ + (size_t)b * T * N;
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  RegTile ra, rb;
+  auto fetch = [&](int k0) {
+    load_kc(ra, Zb, (size_t)N, r0, k0, T, N, true, tid);
+    load_kc(rb, Wp, (size_t)N, f0, k0, F, N, true, tid);
+    if (mask4) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int idx4 = tid + i * 256;
+        int f = f0 + (idx4 >> 2);
+        if (f < F) {
+          // k0 and k4 are multiples of 4: the float4 covers gates 0..3 of one unit
+#pragma unroll
+          for (int g = 0; g < 4; ++g) rb.v[i * 4 + g] *= mask4[((size_t)g * B + b) * F + f];
+        }
+      }
+    }
+  };
+  fetch(0);
+  store_kc(As, ra, tid);
+  store_kc(Bs, rb, tid);
+  __syncthreads();
+  for (int k0 = 0; k0 < N; k0 += BK) {
+    bool more = k0 + BK < N;
+    if (more) fetch(k0 + BK);
+    mma_stage(As, Bs, acc, wr, wc, lane);
+    __syncthreads();
+    if (more) {
+      store_kc(As, ra, tid);
+      store_kc(Bs, rb, tid);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      int f = f0 + ACC_COL(wc, nt, lane);
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        int r = r0 + ACC_ROW(wr, mt, reg, lane);
+        if (r < T && f < F) {
+          float* o = dX + ((size_t)b * T + r) * lddx + f;
+          *o = accumulate ? (*o + acc[mt][nt][reg]) : acc[mt][nt][reg];
+        }
+      }
+    }
+}
+
+// slab reduce: out[i] = sum_k slab[k][i]
+__global__ void k_reduce(const float* __restrict__ slab, float* __restrict__ out, size_t n, int nslab) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += slab[(size_t)k * n + i];
+    out[i] = s;
+  }
+}
+
+// column sums of dZ [rows, N] -> slab[wg][N]; each WG takes a contiguous row range, thread per column (coalesced)
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dZ, float* __restrict__ slab, size_t rows, int N,
+                                                int rows_per_wg) {
+  size_t rbeg = (size_t)blockIdx.x * rows_per_wg;
+  size_t rend = rbeg + rows_per_wg < rows ? rbeg + rows_per_wg : rows;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float s = 0.f;
+    for (size_t r = rbeg; r < rend; ++r) s += dZ[r * N + n];
+    slab[(size_t)blockIdx.x * N + n] = s;
+  }
+}
+
+static int tn_groups(int B, int F, int N) {
+  int tiles = ((F + BM - 1) / BM) * ((N + BN - 1) / BN);
+  int sg = (1024 + tiles - 1) / tiles;
+  if (sg > B) sg = B;
+  if (sg < 1) sg = 1;
+  return sg;
+}
+static int colsum_wgs(size_t rows) {
+  size_t w = (rows + 255) / 256;
+  if (w > 512) w = 512;
+  if (w < 1) w = 1;
+  return (int)w;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int mgr_lstm_input_proj(mgr_ctx* c, const float* X, int ldx, const float* mask4, const float* Wp, const float* bp,
+                        float* Z, int B, int T, int F, int H) {
+  MGR_REQUIRE(c && X && Wp && bp && Z, "null argument");
+  MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0 && ldx >= F, "bad shape");
+  MGR_REQUIRE(aligned16(Wp) && aligned16(Z), "Wp/Z must be 16-byte aligned");
+  int N = 4 * H;
+  int vecA = (ldx % 4 == 0) && aligned16(X);
+  dim3 grid((N + BN - 1) / BN, (T + BM - 1) / BM, B);
+  mgr_prof_begin(c, MGR_K_GEMM_NN);
+  hipLaunchKernelGGL(k_gemm_nn, grid, dim3(256), 0, mgr_stream(c), X, ldx, mask4, Wp, bp, Z, B, T, F, N, vecA);
+  MGR_LAUNCH_CHECK();
+  mgr_prof_end(c, MGR_K_GEMM_NN);
+  return 0;
+}
+
+size_t mgr_lstm_param_grads_ws_bytes(int B, int T, int F, int H) {
+  int N = 4 * H;
+  size_t a = mgr_align_up((size_t)tn_groups(B, F, N) * F * N * sizeof(float), 256);
+  size_t b = mgr_align_up((size_t)tn_groups(B, H, N) * H * N * sizeof(float), 256);
+  size_t d = mgr_align_up((size_t)colsum_wgs((size_t)B * T) * N * sizeof(float), 256);
+  return a + b + d;
+}
+
+int mgr_lstm_param_grads(mgr_ctx* c, const float* X, int ldx, const float* mask4, const float* Hs, int ldh,
+                         const float* dZ, float* dWp, float* dUp, float* dbp, int B, int T, int F, int H, int reverse,
+                         void* ws, size_t ws_bytes) {
+  MGR_REQUIRE(c && X && Hs && dZ && dWp && dUp && dbp, "null argument");
+  MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0 && ldx >= F && ldh >= H, "bad shape");
+  MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_param_grads_ws_bytes(B, T, F, H), "workspace too small");
+  MGR_REQUIRE(aligned16(dZ), "dZ must be 16-byte aligned");
+  int N = 4 * H;
+  int sgW = tn_groups(B, F, N), sgU = tn_groups(B, H, N);
+  char* w = reinterpret_cast<char*>(ws);
+  float* slabW = reinterpret_cast<float*>(w);
+  w += mgr_align_up((size_t)sgW * F * N * sizeof(float), 256);
+  float* slabU = reinterpret_cast<float*>(w);
+  w += mgr_align_up((size_t)sgU * H * N * sizeof(float), 256);
+  float* slabB = reinterpret_cast<float*>(w);
+  hipStream_t s = mgr_stream(c);
+  mgr_prof_begin(c, MGR_K_GEMM_TN);
+  {
+    int vecA = (ldx % 4 == 0) && aligned16(X);
+    dim3 grid((N + BN - 1) / BN, (F + BM - 1) / BM, sgW);
+    hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, s, X, ldx, 0, mask4, dZ, slabW, B, T, F, N, sgW, vecA);
+    size_t n = (size_t)F * N;
+    hipLaunchKernelGGL(k_reduce, dim3((int)((n + 255) / 256)), dim3(256), 0, s, slabW, dWp, n, sgW);
+  }
+  {
+    // h_prev: forward direction uses h[t-1], reverse direction uses h[t+1]
+    int vecA = (ldh % 4 == 0) && aligned16(Hs);
+    dim3 grid((N + BN - 1) / BN, (H + BM - 1) / BM, sgU);
+    hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, s, Hs, ldh, reverse ? 1 : -1, (const float*)nullptr, dZ, slabU, B, T, H, N, sgU, vecA);
+    size_t n = (size_t)H * N;
+    hipLaunchKernelGGL(k_reduce, dim3((int)((n + 255) / 256)), dim3(256), 0, s, slabU, dUp, n, sgU);
+  }
+  {
+    size_t rows = (size_t)B * T;
+    int nwg = colsum_wgs(rows);
+    int rpw = (int)((rows + nwg - 1) / nwg);
+    nwg = (int)((rows + rpw - 1) / rpw);
+    hipLaunchKernelGGL(k_colsum, dim3(nwg), dim3(256), 0, s, dZ, slabB, rows, N, rpw);
+    hipLaunchKernelGGL(k_reduce, dim3((N + 255) / 256), dim3(256), 0, s, slabB, dbp, (size_t)N, nwg);
+  }
+  MGR_LAUNCH_CHECK();
+  mgr_prof_end(c, MGR_K_GEMM_TN);
+  return 0;
+}
+
+int mgr_lstm_input_grad(mgr_ctx* c, const float* dZ, const float* Wp, const float* mask4, float* dX, int lddx,
+                        int accumulate, int B, int T, int F, int H) {
+  MGR_REQUIRE(c && dZ && Wp && dX, "null argument");
+  MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0 && lddx >= F, "bad shape");
+  MGR_REQUIRE(aligned16(dZ) && aligned16(Wp), "dZ/Wp must be 16-byte aligned");
+  int N = 4 * H;
+  dim3 grid((F + BN - 1) / BN, (T + BM - 1) / BM, B);
+  mgr_prof_begin(c, MGR_K_GEMM_NT);
+  hipLaunchKernelGGL(k_gemm_nt, grid, dim3(256), 0, mgr_stream(c), dZ, Wp, mask4, dX, lddx, accumulate, B, T, F, N);
+  MGR_LAUNCH_CHECK();
+  mgr_prof_end(c, MGR_K_GEMM_NT);
+  return 0;
+}
+
+}  // extern "C"

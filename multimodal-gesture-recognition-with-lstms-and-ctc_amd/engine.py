@@ -1,0 +1,496 @@
+"""Device engine: runs one network of the reference's family on one MI355X through the libmgr C ABI.
+
+It owns the device-resident weights (packed layouts), the activation workspaces sized for a fixed
+(B, T, Lmax), and sequences the HIP kernels for predict / train steps over the ctx's streams (the two
+directions of every Bidirectional layer and the modality encoders run concurrently).  This is what
+Keras' ``train_on_batch`` / ``predict_on_batch`` do for the reference (multimodal_fusion/multimodal.py:264,
+multimodal_fusion/sequence_decoding.py:121); there is no CPU fallback.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _capi
+from ._capi import Device, DeviceArray
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class _LstmDir:
+    """Device state of one direction of one Bidirectional(LSTM) layer."""
+
+    def __init__(self, prefix, d, fin, H, trainable):
+        self.prefix = prefix
+        self.d = d  # "fwd" | "bwd"
+        self.reverse = 1 if d == "bwd" else 0
+        self.fin = fin
+        self.H = H
+        self.trainable = trainable
+        self.Wp = self.Up = self.bp = None
+        self.gWp = self.gUp = self.gbp = None
+        self.mask = None       # device [4,B,fin] when input dropout is active
+        self.Z = None
+        self.gates = self.cs = self.dZ = None
+        self.ws_scan = self.ws_pg = None
+
+
+class Engine:
+    def __init__(self, spec, B, T, Lmax, device=0, seed=1234, comm=None, world=1, inference_only=False):
+        self.spec = spec
+        self.B, self.T, self.Lmax = int(B), int(T), int(Lmax)
+        self.dev = device if isinstance(device, Device) else Device(device)
+        self.lib = self.dev.lib
+        self.seed = int(seed)
+        self.comm = comm
+        self.world = int(world)
+        self.inference_only = inference_only
+        self.iterations = 0   # optimizer step count (Keras `iterations`)
+        self.rng_step = 0     # advances per forward pass that draws randomness
+        self._build()
+
+    # ------------------------------------------------------------------------------------------ build
+    def _build(self):
+        sp, dev, B, T = self.spec, self.dev, self.B, self.T
+        table = sp.weight_table()
+        # flat trainable buffer layout (every segment padded to 4 floats)
+        self.seg = {}
+        off = 0
+        for name, shape, tr, kind in table:
+            n = int(np.prod(shape))
+            if tr:
+                self.seg[name] = (off, n, shape, kind)
+                off += _pad4(n)
+        self.n_train = off
+        self.params = dev.zeros((max(off, 4),))
+        if not self.inference_only:
+            self.grads = dev.zeros((max(off, 4),))
+            self.m = dev.zeros((max(off, 4),))
+            self.v = dev.zeros((max(off, 4),))
+        self.frozen = {}
+        for name, shape, tr, kind in table:
+            if not tr:
+                self.frozen[name] = dev.zeros((_pad4(int(np.prod(shape))),))
+        self.kinds = {name: kind for name, _, _, kind in table}
+        self.shapes = {name: shape for name, shape, _, _ in table}
+
+        # LSTM layer-direction objects
+        self.dirs = {}
+        train = not self.inference_only
+        for prefix, fin, H, p, tr in sp.lstm_layers():
+            for d in ("fwd", "bwd"):
+                L = _LstmDir(prefix, d, fin, H, tr)
+                base = "%s/%s" % (prefix, d)
+                L.Wp, L.Up, L.bp = (self._wview(base + "/W"), self._wview(base + "/U"), self._wview(base + "/b"))
+                if tr and train:
+                    L.gWp, L.gUp, L.gbp = (self._gview(base + "/W"), self._gview(base + "/U"), self._gview(base + "/b"))
+                    L.gates = dev.empty((B, T, H, 4))
+                    L.cs = dev.empty((B, T, H))
+                    L.dZ = dev.empty((B, T, 4 * H))
+                    L.ws_scan = dev.bytes(self.lib.mgr_lstm_scan_ws_bytes(B, T, H))
+                    L.ws_pg = dev.bytes(self.lib.mgr_lstm_param_grads_ws_bytes(B, T, fin, H))
+                if p > 0:
+                    L.mask = dev.empty((4, B, fin))
+                L.p = p
+                self.dirs[base] = L
+
+        # activations
+        W = sp.concat_width
+        self.X = {}
+        self.Y1 = {}
+        self.Y2 = {}
+        self.dY1 = {}
+        self.Zbuf = {}
+        self.Xin = {}
+        self._xcur = {}
+        for s in sp.streams:
+            self.Xin[s["name"]] = dev.empty((B, T, s["F"]))
+            if s["noise"] > 0:
+                self.X[s["name"]] = dev.empty((B, T, s["F"]))
+            Hs = [lay["H"] for lay in s["layers"]]
+            zf = dev.empty((B, T, 4 * max(Hs)))
+            zb = dev.empty((B, T, 4 * max(Hs)))
+            self.Zbuf[s["name"]] = (zf, zb)
+            if len(Hs) == 2:
+                self.Y1[s["name"]] = dev.empty((B, T, 2 * Hs[0]))
+                if s["trainable"] and train:
+                    if s["residual"]:
+                        self.Y2[s["name"]] = dev.empty((B, T, 2 * Hs[1]))
+                    self.dY1[s["name"]] = dev.empty((B, T, 2 * Hs[0]))
+        self.FEAT = dev.empty((B, T, W))
+        any_tr_stream = any(s["trainable"] for s in sp.streams)
+        if sp.fusion:
+            Hf = sp.fusion["H"]
+            self.ZF = (dev.empty((B, T, 4 * Hf)), dev.empty((B, T, 4 * Hf)))
+            self.YF = dev.empty((B, T, 2 * Hf))
+            if train:
+                self.dYF = dev.empty((B, T, 2 * Hf))
+        if train and any_tr_stream:
+            self.dFEAT = dev.empty((B, T, W))
+        D, Cn = sp.head_width, sp.num_classes
+        self.P = dev.empty((B, T, Cn))
+        self.head_mask = None
+        if train:
+            self.dLogits = dev.empty((B, T, Cn))
+            self.loss_b = dev.empty((B,))
+            self.loss_mean = dev.empty((4,))
+            self.labels_d = dev.empty((B, self.Lmax), np.int32)
+            self.ilen_d = dev.empty((B,), np.int32)
+            self.llen_d = dev.empty((B,), np.int32)
+            self.ws_ctc = dev.bytes(self.lib.mgr_ctc_ws_bytes(B, T, Cn, self.Lmax))
+            self.ws_dense = dev.bytes(self.lib.mgr_dense_bwd_ws_bytes(B, T, D, Cn))
+        dev.sync()
+
+    def _wview(self, name):
+        if name in self.seg:
+            off, n, shape, _ = self.seg[name]
+            return self.params.view(off, (n,))
+        return self.frozen[name]
+
+    def _gview(self, name):
+        off, n, shape, _ = self.seg[name]
+        return self.grads.view(off, (n,))
+
+    # ------------------------------------------------------------------------------------------ weights
+    def set_weights(self, weights):
+        """weights: dict name -> numpy array in Keras layout (see NetworkSpec.weight_table)."""
+        dev = self.dev
+        dev.stream(0)
+        for name, shape, tr, kind in self.spec.weight_table():
+            if name not in weights:
+                continue
+            w = np.ascontiguousarray(np.asarray(weights[name], dtype=np.float32))
+            if tuple(w.shape) != tuple(shape):
+                raise ValueError("weight %s: expected shape %s, got %s" % (name, shape, w.shape))
+            dst = self._wview(name)
+            if kind in ("kernel", "recurrent", "bias"):
+                H = shape[-1] // 4
+                rows = 1 if kind == "bias" else shape[0]
+                tmp = dev.array(w.reshape(-1))
+                dev.call("mgr_lstm_pack", tmp, dst, rows, H, 0)
+                dev.sync()
+                tmp.free()
+            else:
+                dst.view(0, (w.size,)).upload(w.reshape(-1))
+        dev.sync()
+
+    def get_weights(self):
+        dev = self.dev
+        dev.stream(0)
+        out = {}
+        for name, shape, tr, kind in self.spec.weight_table():
+            n = int(np.prod(shape))
+            src = self._wview(name)
+            if kind in ("kernel", "recurrent", "bias"):
+                H = shape[-1] // 4
+                rows = 1 if kind == "bias" else shape[0]
+                tmp = dev.empty((n,))
+                dev.call("mgr_lstm_pack", src, tmp, rows, H, 1)
+                out[name] = tmp.download().reshape(shape)
+                tmp.free()
+            else:
+                out[name] = src.view(0, (n,)).download().reshape(shape)
+        return out
+
+    def get_grads(self):
+        """Trainable gradients of the last train step's backward pass, Keras layouts (tests / debugging)."""
+        dev = self.dev
+        dev.stream(0)
+        out = {}
+        for name, (off, n, shape, kind) in self.seg.items():
+            src = self.grads.view(off, (n,))
+            if kind in ("kernel", "recurrent", "bias"):
+                H = shape[-1] // 4
+                rows = 1 if kind == "bias" else shape[0]
+                tmp = dev.empty((n,))
+                dev.call("mgr_lstm_pack", src, tmp, rows, H, 1)
+                out[name] = tmp.download().reshape(shape)
+                tmp.free()
+            else:
+                out[name] = src.download().reshape(shape)
+        return out
+
+    def reset_optimizer(self):
+        self.m.zero()
+        self.v.zero()
+        self.iterations = 0
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def _seed(self, slot):
+        return (self.seed * 1000003 + self.rng_step * 131 + slot) & 0xFFFFFFFFFFFFFFFF
+
+    def _upload_inputs(self, inputs, rand, train):
+        dev = self.dev
+        dev.stream(0)
+        for s in self.spec.streams:
+            x = np.asarray(inputs[s["name"]], dtype=np.float32)
+            if x.shape != (self.B, self.T, s["F"]):
+                raise ValueError("input %s: expected %s got %s" % (s["name"], (self.B, self.T, s["F"]), x.shape))
+            nz = rand.get(s["name"] + "/noise") if rand else None
+            if train and nz is not None:
+                x = x + np.asarray(nz, dtype=np.float32)
+            self.Xin[s["name"]].upload(x)
+
+    def _prep_mask(self, L, train, rand, slot):
+        """Returns the device pointer (or 0) of the [4,B,fin] input-dropout mask for this pass."""
+        if not train or L.p <= 0:
+            return 0
+        key = "%s/%s/mask" % (L.prefix, L.d)
+        if rand is not None:
+            if key in rand and rand[key] is not None:
+                L.mask.upload(np.asarray(rand[key], dtype=np.float32))
+                return L.mask.ptr
+            return 0  # explicit randomness given but no mask for this layer: no dropout
+        self.dev.call("mgr_dropout_mask", L.mask, L.mask.size, float(L.p), C.c_uint64(self._seed(slot)))
+        return L.mask.ptr
+
+    # ------------------------------------------------------------------------------------------ forward
+    def _forward(self, train, rand):
+        sp, dev, B, T = self.spec, self.dev, self.B, self.T
+        W = sp.concat_width
+        save = train and not self.inference_only
+        slot = 0
+        col = 0
+        used_streams = []
+        self._masks = {}
+        for si, s in enumerate(sp.streams):
+            sa, sb = 1 + 2 * si, 2 + 2 * si
+            used_streams += [sa, sb]
+            name = s["name"]
+            X = self.Xin[name]
+            dev.stream(sa)
+            dev.wait(sa, 0)
+            if train and rand is None and s["noise"] > 0:
+                # GaussianNoise on device; the resident input stays pristine for the next step
+                dev.call("mgr_add_gaussian_noise", X, self.X[name], X.size, float(s["noise"]),
+                         C.c_uint64(self._seed(900 + si)))
+                X = self.X[name]
+            self._xcur[name] = X
+            dev.wait(sb, sa)
+            nl = len(s["layers"])
+            cur, ldcur, fin = X, s["F"], s["F"]
+            for k, lay in enumerate(s["layers"]):
+                H = lay["H"]
+                last = k == nl - 1
+                for di, (dname, st) in enumerate((("fwd", sa), ("bwd", sb))):
+                    L = self.dirs["%s/l%d/%s" % (name, k, dname)]
+                    dev.stream(st)
+                    slot += 1
+                    mptr = self._prep_mask(L, train, rand, slot)
+                    self._masks[(L.prefix, L.d)] = mptr
+                    Z = self.Zbuf[name][di]
+                    dev.call("mgr_lstm_input_proj", cur, ldcur, mptr, L.Wp, L.bp, Z, B, T, fin, H)
+                    R, ldr = 0, 0
+                    if not last:
+                        Y, ldy = self.Y1[name].view(di * H, (1,)), 2 * H
+                    elif nl == 2 and s["residual"] and name in self.Y2 and save:
+                        Y, ldy = self.Y2[name].view(di * H, (1,)), 2 * H
+                    else:
+                        Y, ldy = self.FEAT.view(col + di * H, (1,)), W
+                        if nl == 2 and s["residual"]:
+                            R, ldr = self.Y1[name].view(di * H, (1,)), 2 * H
+                    g = L.gates if (save and L.trainable) else 0
+                    cs = L.cs if (save and L.trainable) else 0
+                    dev.call("mgr_lstm_scan_fwd", Z, L.Up, Y, ldy, R, ldr, g, cs, B, T, H, L.reverse, 0, 0)
+                dev.wait(sa, sb)
+                dev.wait(sb, sa)
+                if not last:
+                    cur, ldcur, fin = self.Y1[name], 2 * H, 2 * H
+            if nl == 2 and s["residual"] and name in self.Y2 and save:
+                H = s["layers"][-1]["H"]
+                dev.stream(sa)
+                dev.call("mgr_add2d", self.Y1[name], 2 * H, self.Y2[name], 2 * H, self.FEAT.view(col, (1,)), W,
+                         B * T, 2 * H)
+            col += sp.stream_width(s)
+        dev.stream(0)
+        for st in used_streams:
+            dev.wait(0, st)
+        feat, ldf = self.FEAT, W
+        if sp.fusion:
+            Hf = sp.fusion["H"]
+            dev.wait(1, 0)
+            for di, (dname, st) in enumerate((("fwd", 0), ("bwd", 1))):
+                L = self.dirs["fusion/%s" % dname]
+                dev.stream(st)
+                slot += 1
+                mptr = self._prep_mask(L, train, rand, slot)
+                self._masks[(L.prefix, L.d)] = mptr
+                dev.call("mgr_lstm_input_proj", self.FEAT, W, mptr, L.Wp, L.bp, self.ZF[di], B, T, W, Hf)
+                g = L.gates if save else 0
+                cs = L.cs if save else 0
+                dev.call("mgr_lstm_scan_fwd", self.ZF[di], L.Up, self.YF.view(di * Hf, (1,)), 2 * Hf, 0, 0, g, cs,
+                         B, T, Hf, L.reverse, 0, 0)
+            dev.stream(0)
+            dev.wait(0, 1)
+            feat, ldf = self.YF, 2 * Hf
+        # head
+        D, Cn = sp.head_width, sp.num_classes
+        p_head = float(sp.head["dropout"]) if train else 0.0
+        hm = 0
+        self._head_seed = 0
+        if train and rand is not None:
+            p_head = 0.0
+            if rand.get("head/mask") is not None:
+                if self.head_mask is None:
+                    self.head_mask = dev.empty((B, T, D))
+                self.head_mask.upload(np.asarray(rand["head/mask"], dtype=np.float32))
+                hm = self.head_mask.ptr
+        elif train and p_head > 0:
+            self._head_seed = self._seed(999)
+        self._head_args = (hm, p_head, self._head_seed)
+        dev.call("mgr_dense_softmax_fwd", feat, ldf, hm, p_head, C.c_uint64(self._head_seed),
+                 self._wview("dense/W"), self._wview("dense/b"), self.P, B, T, D, Cn)
+        self._feat = (feat, ldf)
+        if train:
+            self.rng_step += 1
+
+    # ------------------------------------------------------------------------------------------ public
+    def predict(self, inputs):
+        """Softmax output (B,T,C) with learning phase 0 (sequence_decoding.py:81)."""
+        self._upload_inputs(inputs, None, False)
+        self._forward(False, None)
+        return self.P.download()
+
+    def forward_train_phase(self, inputs, rand=None):
+        """Softmax output with learning phase 1 (dropout / noise active) - no gradient."""
+        self._upload_inputs(inputs, rand, True)
+        self._forward(True, rand)
+        return self.P.download()
+
+    def _upload_labels(self, labels, input_length, label_length):
+        lab = np.asarray(labels)
+        lab = np.where(np.isfinite(lab), lab, -1).astype(np.int32).reshape(self.B, -1)
+        if lab.shape[1] != self.Lmax:
+            if lab.shape[1] > self.Lmax:
+                raise ValueError("label rows longer (%d) than Lmax=%d" % (lab.shape[1], self.Lmax))
+            lab = np.concatenate([lab, -np.ones((self.B, self.Lmax - lab.shape[1]), np.int32)], axis=1)
+        self.labels_d.upload(lab)
+        self.ilen_d.upload(np.asarray(input_length).reshape(self.B).astype(np.int32))
+        self.llen_d.upload(np.asarray(label_length).reshape(self.B).astype(np.int32))
+
+    def loss_on_batch(self, inputs, labels, input_length, label_length, rand=None, train_phase=True):
+        """Per-sample CTC loss (validation inside fit_generator: learning phase stays 1, multimodal.py:66)."""
+        self._upload_inputs(inputs, rand, train_phase)
+        self._upload_labels(labels, input_length, label_length)
+        self._forward(train_phase, rand)
+        sp = self.spec
+        self.dev.call("mgr_ctc_loss_grad", self.P, self.labels_d, self.ilen_d, self.llen_d, self.B, self.T,
+                      sp.num_classes, self.Lmax, int(sp.ctc["skip"]), sp.num_classes - 1, float(sp.ctc["eps"]),
+                      1.0, self.loss_b, 0, self.ws_ctc, self.ws_ctc.nbytes)
+        return self.loss_b.download()
+
+    def train_step(self, inputs, labels, input_length, label_length, rand=None, apply_update=True):
+        """One optimizer step (Keras train_on_batch).  Returns the mean CTC loss of the local batch."""
+        self.enqueue_train_step(inputs, labels, input_length, label_length, rand, apply_update)
+        return float(self.loss_mean.download()[0])
+
+    def enqueue_train_step(self, inputs, labels, input_length, label_length, rand=None, apply_update=True,
+                           upload=True):
+        sp, dev, B, T = self.spec, self.dev, self.B, self.T
+        if upload:
+            self._upload_inputs(inputs, rand, True)
+            self._upload_labels(labels, input_length, label_length)
+        self._forward(True, rand)
+        Cn, D = sp.num_classes, sp.head_width
+        dev.stream(0)
+        dev.call("mgr_ctc_loss_grad", self.P, self.labels_d, self.ilen_d, self.llen_d, B, T, Cn, self.Lmax,
+                 int(sp.ctc["skip"]), Cn - 1, float(sp.ctc["eps"]), 1.0 / B, self.loss_b, self.dLogits,
+                 self.ws_ctc, self.ws_ctc.nbytes)
+        dev.call("mgr_mean", self.loss_b, B, self.loss_mean)
+        feat, ldf = self._feat
+        hm, p_head, hseed = self._head_args
+        any_tr_stream = any(s["trainable"] for s in sp.streams)
+        W = sp.concat_width
+        if sp.fusion:
+            dA, ldda = self.dYF, 2 * sp.fusion["H"]
+        elif any_tr_stream:
+            dA, ldda = self.dFEAT, W
+        else:
+            dA, ldda = 0, D
+        dev.call("mgr_dense_bwd", feat, ldf, hm, p_head, C.c_uint64(hseed), self.dLogits, self._wview("dense/W"),
+                 self._gview("dense/W"), self._gview("dense/b"), dA, ldda, B, T, D, Cn, self.ws_dense,
+                 self.ws_dense.nbytes)
+        if sp.fusion:
+            Hf = sp.fusion["H"]
+            self._bilstm_backward("fusion", self.dYF, 2 * Hf, self.FEAT, W, W, self.YF, 2 * Hf,
+                                  self.dFEAT if any_tr_stream else None, W)
+        if any_tr_stream:
+            col = 0
+            for si, s in enumerate(sp.streams):
+                wout = sp.stream_width(s)
+                if s["trainable"]:
+                    self._stream_backward(s, col)
+                col += wout
+        dev.stream(0)
+        if apply_update:
+            self.apply_gradients()
+
+    def _bilstm_backward(self, prefix, dY, lddy, Xin, ldx, fin, Hbuf, ldh, dX, lddx):
+        """BPTT + parameter grads of one Bidirectional layer; the two directions run on streams 0 and 1."""
+        dev, B, T = self.dev, self.B, self.T
+        dev.wait(1, 0)
+        for di, (dname, st) in enumerate((("fwd", 0), ("bwd", 1))):
+            L = self.dirs["%s/%s" % (prefix, dname)]
+            H = L.H
+            dev.stream(st)
+            dYv = dY.view(di * H, (1,)) if isinstance(dY, DeviceArray) else dY
+            dev.call("mgr_lstm_scan_bwd", dYv, lddy, L.gates, L.cs, L.Up, L.dZ, B, T, H, L.reverse, L.ws_scan,
+                     L.ws_scan.nbytes)
+            mptr = self._masks.get((L.prefix, L.d), 0)
+            dev.call("mgr_lstm_param_grads", Xin, ldx, mptr, Hbuf.view(di * H, (1,)), ldh, L.dZ, L.gWp, L.gUp, L.gbp,
+                     B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes)
+        dev.stream(0)
+        dev.wait(0, 1)
+        if dX is not None:
+            for di, dname in enumerate(("fwd", "bwd")):
+                L = self.dirs["%s/%s" % (prefix, dname)]
+                mptr = self._masks.get((L.prefix, L.d), 0)
+                dev.call("mgr_lstm_input_grad", L.dZ, L.Wp, mptr, dX, lddx, 1 if di == 1 else 0, B, T, fin, L.H)
+
+    def _stream_backward(self, s, col):
+        sp, dev, B, T = self.spec, self.dev, self.B, self.T
+        W = sp.concat_width
+        name = s["name"]
+        nl = len(s["layers"])
+        dout = self.dFEAT.view(col, (1,))
+        if nl == 2:
+            H1, H2 = s["layers"][0]["H"], s["layers"][1]["H"]
+            if s["residual"]:
+                Hbuf, ldh = self.Y2[name], 2 * H2
+            else:
+                Hbuf, ldh = self.FEAT.view(col, (1,)), W
+            self._bilstm_backward("%s/l1" % name, dout, W, self.Y1[name], 2 * H1, 2 * H1, Hbuf, ldh,
+                                  self.dY1[name], 2 * H1)
+            if s["residual"]:
+                dev.call("mgr_add2d", self.dY1[name], 2 * H1, dout, W, self.dY1[name], 2 * H1, B * T, 2 * H1)
+            self._bilstm_backward("%s/l0" % name, self.dY1[name], 2 * H1, self._xcur[name], s["F"], s["F"],
+                                  self.Y1[name], 2 * H1, None, 0)
+        else:
+            H1 = s["layers"][0]["H"]
+            self._bilstm_backward("%s/l0" % name, dout, W, self._xcur[name], s["F"], s["F"],
+                                  self.FEAT.view(col, (1,)), W, None, 0)
+
+    def apply_gradients(self):
+        """all-reduce (if data parallel) -> clip -> Adam -> max-norm; identical on every replica."""
+        dev, o = self.dev, self.spec.optimizer
+        dev.stream(0)
+        gscale = 1.0
+        if self.comm is not None and self.world > 1:
+            self.comm.allreduce_sum(self.grads, self.n_train)
+            gscale = 1.0 / self.world
+        k = self.iterations
+        lr_k = o["lr"] * (1.0 / (1.0 + o["decay"] * k))
+        t = k + 1
+        lr_t = lr_k * math.sqrt(1.0 - o["beta_2"] ** t) / (1.0 - o["beta_1"] ** t)
+        dev.call("mgr_adam_step", self.params, self.grads, self.m, self.v, self.n_train, lr_t, o["beta_1"],
+                 o["beta_2"], o["epsilon"], o["clipvalue"] or 0.0, gscale)
+        if o.get("maxnorm"):
+            for name, (off, n, shape, kind) in self.seg.items():
+                if kind == "kernel":
+                    dev.call("mgr_maxnorm_cols", self.params.view(off, (n,)), shape[0], shape[1], float(o["maxnorm"]), 1e-7)
+        self.iterations += 1
+
+    def close(self):
+        self.dev.close()

@@ -1,0 +1,240 @@
+"""-m gpu parity tests: every C-ABI kernel against the fp64 oracle on seeded inputs.
+Tolerances: fp32 kernels vs fp64 oracle.  CTC loss 1e-4 relative (BASELINE.json north_star)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import keras_ref as kr
+from tests.helpers import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_probs(rng, B, T, Cn, scale=2.0):
+    z = rng.standard_normal((B, T, Cn)) * scale
+    P = np.exp(z - z.max(-1, keepdims=True))
+    return (P / P.sum(-1, keepdims=True)).astype(np.float32)
+
+
+def _run_ctc(dev, P, labels, il, ll, skip=2, gscale=1.0, need_grad=True):
+    B, T, Cn = P.shape
+    Lmax = labels.shape[1]
+    dP = dev.array(P)
+    dl = dev.array(labels.astype(np.int32))
+    dil = dev.array(np.asarray(il).reshape(B).astype(np.int32))
+    dll = dev.array(np.asarray(ll).reshape(B).astype(np.int32))
+    loss = dev.empty((B,))
+    dz = dev.empty((B, T, Cn))
+    wsb = dev.lib.mgr_ctc_ws_bytes(B, T, Cn, Lmax)
+    ws = dev.bytes(wsb)
+    dev.call("mgr_ctc_loss_grad", dP, dl, dil, dll, B, T, Cn, Lmax, skip, Cn - 1, 1e-8, gscale, loss,
+             dz if need_grad else 0, ws, ws.nbytes)
+    out = loss.download(), dz.download()
+    for a in (dP, dl, dil, dll, loss, dz, ws):
+        a.free()
+    return out
+
+
+def test_ctc_golden(device):
+    z = np.load(GOLDEN + "/ctc_small.npz")
+    loss, dz = _run_ctc(device, z["P"].astype(np.float32), z["labels"], z["input_length"], z["label_length"])
+    assert np.allclose(loss, z["loss"], rtol=1e-5), (loss, z["loss"])
+    assert rel_err(dz, z["dlogits"]) < 2e-4
+
+
+@pytest.mark.parametrize("B,T,Cn,Lmax,lo,hi", [(4, 50, 22, 35, 1, 12), (3, 400, 22, 35, 8, 20), (2, 330, 44, 150, 100, 150),
+                                               (2, 70, 22, 28, 1, 28), (1, 3, 5, 4, 1, 1)])
+def test_ctc_random(device, B, T, Cn, Lmax, lo, hi):
+    rng = np.random.default_rng(B * 1000 + T)
+    P = _rand_probs(rng, B, T, Cn)
+    labels = -np.ones((B, Lmax))
+    ll = np.zeros(B, np.int64)
+    for b in range(B):
+        L = int(rng.integers(lo, hi + 1))
+        L = min(L, (T - 2) // 2) if T > 4 else 1
+        labels[b, :L] = rng.integers(0, Cn - 1, size=L)
+        ll[b] = L
+    il = np.full(B, T - 2)
+    if B > 1:
+        il[1] = max(2 * int(ll[1]) + 1, (T - 2) // 2)
+    ref_loss, ref_dz = kr.ctc_loss_grad(P.astype(np.float64), labels, il, ll)
+    loss, dz = _run_ctc(device, P, labels, il, ll)
+    assert np.allclose(loss, ref_loss, rtol=1e-4), (loss, ref_loss)
+    assert rel_err(dz, ref_dz) < 5e-4
+    loss2, _ = _run_ctc(device, P, labels, il, ll, need_grad=False)
+    assert np.array_equal(loss, loss2)
+
+
+def test_ctc_long_T_relative(device):
+    """BASELINE shape T=1900 (B reduced): loss ~ thousands, must match 1e-4 relative."""
+    rng = np.random.default_rng(5)
+    B, T, Cn, Lmax = 2, 1900, 22, 35
+    P = _rand_probs(rng, B, T, Cn, scale=1.0)
+    labels = -np.ones((B, Lmax))
+    ll = np.array([20, 8])
+    for b in range(B):
+        labels[b, :ll[b]] = rng.integers(0, Cn - 1, size=ll[b])
+    il = np.full(B, T - 2)
+    ref_loss, ref_dz = kr.ctc_loss_grad(P.astype(np.float64), labels, il, ll)
+    loss, dz = _run_ctc(device, P, labels, il, ll)
+    assert np.allclose(loss, ref_loss, rtol=1e-4), (loss, ref_loss)
+    assert rel_err(dz, ref_dz) < 2e-3
+
+
+@pytest.mark.parametrize("B,T,D,Cn,p", [(3, 37, 200, 22, 0.5), (2, 65, 1000, 44, 0.0), (1, 5, 8, 6, 0.5)])
+def test_dense_softmax_fwd_bwd(device, B, T, D, Cn, p):
+    dev = device
+    rng = np.random.default_rng(D)
+    A = rng.standard_normal((B, T, D)).astype(np.float32)
+    Wd = (rng.standard_normal((D, Cn)) * 0.1).astype(np.float32)
+    bd = rng.standard_normal(Cn).astype(np.float32)
+    dm = ((rng.random((B, T, D)) >= p) / (1 - p)).astype(np.float32) if p > 0 else None
+    dL = rng.standard_normal((B, T, Cn)).astype(np.float32)
+    Pref, cache = kr.dense_softmax_forward(A.astype(np.float64), None if dm is None else dm.astype(np.float64),
+                                           Wd.astype(np.float64), bd.astype(np.float64))
+    dAref, dWref, dbref = kr.dense_backward(dL.astype(np.float64), cache)
+    dA_, dW_, db_, dP_ = dev.array(A), dev.array(Wd), dev.array(bd), dev.empty((B, T, Cn))
+    dmask = dev.array(dm) if dm is not None else 0
+    dev.call("mgr_dense_softmax_fwd", dA_, D, dmask, 0.0, C.c_uint64(0), dW_, db_, dP_, B, T, D, Cn)
+    assert rel_err(dP_.download(), Pref) < 1e-5
+    gW, gb, gA, ddL = dev.empty((D, Cn)), dev.empty((Cn,)), dev.empty((B, T, D)), dev.array(dL)
+    ws = dev.bytes(dev.lib.mgr_dense_bwd_ws_bytes(B, T, D, Cn))
+    dev.call("mgr_dense_bwd", dA_, D, dmask, 0.0, C.c_uint64(0), ddL, dW_, gW, gb, gA, D, B, T, D, Cn, ws, ws.nbytes)
+    assert rel_err(gW.download(), dWref) < 1e-5
+    assert rel_err(gb.download(), dbref) < 1e-5
+    assert rel_err(gA.download(), dAref) < 1e-5
+
+
+def test_dense_device_rng_mask_consistent(device):
+    """In-kernel dropout (seed) must equal mgr_dropout_mask's mask, in forward and backward."""
+    dev = device
+    B, T, D, Cn, p, seed = 2, 33, 200, 22, 0.5, 77
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((B, T, D)).astype(np.float32)
+    Wd = (rng.standard_normal((D, Cn)) * 0.1).astype(np.float32)
+    bd = np.zeros(Cn, np.float32)
+    m = dev.empty((B, T, D))
+    dev.call("mgr_dropout_mask", m, m.size, p, C.c_uint64(seed))
+    mh = m.download()
+    assert set(np.unique(mh)) <= {0.0, 2.0} and 0.4 < (mh > 0).mean() < 0.6
+    dA_, dW_, db_ = dev.array(A), dev.array(Wd), dev.array(bd)
+    P1, P2 = dev.empty((B, T, Cn)), dev.empty((B, T, Cn))
+    dev.call("mgr_dense_softmax_fwd", dA_, D, m, 0.0, C.c_uint64(0), dW_, db_, P1, B, T, D, Cn)
+    dev.call("mgr_dense_softmax_fwd", dA_, D, 0, p, C.c_uint64(seed), dW_, db_, P2, B, T, D, Cn)
+    assert np.array_equal(P1.download(), P2.download())
+
+
+def _lstm_case(rng, B, T, F, H, p):
+    x = rng.standard_normal((B, T, F))
+    W = rng.uniform(-0.3, 0.3, (F, 4 * H))
+    U = rng.uniform(-0.4, 0.4, (H, 4 * H))
+    b = rng.uniform(-0.2, 0.2, 4 * H)
+    mask = ((rng.random((4, B, F)) >= p) / (1 - p)) if p > 0 else None
+    return x, W, U, b, mask
+
+
+@pytest.mark.parametrize("B,T,F,H,p", [(3, 12, 5, 8, 0.4), (17, 9, 39, 32, 0.5), (5, 21, 20, 100, 0.0), (2, 7, 1600, 100, 0.5),
+                                       (3, 6, 30, 128, 0.5), (5, 8, 13, 12, 0.5), (2, 5, 600, 300, 0.6), (2, 4, 64, 500, 0.4)])
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_lstm_direction_fwd_bwd(device, B, T, F, H, p, reverse):
+    """input projection (MFMA GEMM) + scan fwd + scan bwd + parameter / input grads for one direction."""
+    dev = device
+    rng = np.random.default_rng(B * 100 + T * 10 + H + reverse)
+    x, W, U, b, mask = _lstm_case(rng, B, T, F, H, p)
+    y_ref, cache = kr.lstm_forward(x, W, U, b, mask, bool(reverse))
+    dy = rng.standard_normal((B, T, H))
+    dx_ref, dW_ref, dU_ref, db_ref = kr.lstm_backward(dy, cache, need_dx=True)
+
+    f32 = np.float32
+    dX = dev.array(x.astype(f32))
+    dmask = dev.array(mask.astype(f32)) if mask is not None else 0
+    Wk, Uk, bk = dev.array(W.astype(f32)), dev.array(U.astype(f32)), dev.array(b.astype(f32))
+    Wp, Up, bp = dev.empty((F, 4 * H)), dev.empty((H, 4 * H)), dev.empty((4 * H,))
+    dev.call("mgr_lstm_pack", Wk, Wp, F, H, 0)
+    dev.call("mgr_lstm_pack", Uk, Up, H, H, 0)
+    dev.call("mgr_lstm_pack", bk, bp, 1, H, 0)
+    Z = dev.empty((B, T, 4 * H))
+    dev.call("mgr_lstm_input_proj", dX, F, dmask, Wp, bp, Z, B, T, F, H)
+    Y, G, Cs = dev.empty((B, T, H)), dev.empty((B, T, H, 4)), dev.empty((B, T, H))
+    dev.call("mgr_lstm_scan_fwd", Z, Up, Y, H, 0, 0, G, Cs, B, T, H, reverse, 0, 0)
+    y = Y.download()
+    assert rel_err(y, y_ref) < 2e-5, rel_err(y, y_ref)
+    assert rel_err(Cs.download(), cache["c"]) < 2e-5
+    g = G.download()
+    assert rel_err(g[..., 0], cache["i"]) < 2e-5 and rel_err(g[..., 2], cache["g"]) < 2e-5
+
+    ddY, dZ = dev.array(dy.astype(f32)), dev.empty((B, T, 4 * H))
+    ws = dev.bytes(dev.lib.mgr_lstm_scan_ws_bytes(B, T, H))
+    dev.call("mgr_lstm_scan_bwd", ddY, H, G, Cs, Up, dZ, B, T, H, reverse, ws, ws.nbytes)
+    gW, gU, gb = dev.empty((F, 4 * H)), dev.empty((H, 4 * H)), dev.empty((4 * H,))
+    ws2 = dev.bytes(dev.lib.mgr_lstm_param_grads_ws_bytes(B, T, F, H))
+    dev.call("mgr_lstm_param_grads", dX, F, dmask, Y, H, dZ, gW, gU, gb, B, T, F, H, reverse, ws2, ws2.nbytes)
+    gWk, gUk, gbk = dev.empty((F, 4 * H)), dev.empty((H, 4 * H)), dev.empty((4 * H,))
+    dev.call("mgr_lstm_pack", gW, gWk, F, H, 1)
+    dev.call("mgr_lstm_pack", gU, gUk, H, H, 1)
+    dev.call("mgr_lstm_pack", gb, gbk, 1, H, 1)
+    assert rel_err(gWk.download(), dW_ref) < 1e-4
+    assert rel_err(gUk.download(), dU_ref) < 1e-4
+    assert rel_err(gbk.download(), db_ref) < 1e-4
+    gX = dev.empty((B, T, F))
+    dev.call("mgr_lstm_input_grad", dZ, Wp, dmask, gX, F, 0, B, T, F, H)
+    assert rel_err(gX.download(), dx_ref) < 1e-4
+    dev.call("mgr_lstm_input_grad", dZ, Wp, dmask, gX, F, 1, B, T, F, H)
+    assert rel_err(gX.download(), 2 * dx_ref) < 1e-4
+
+
+def test_scan_residual_and_strides(device):
+    """Y written with a row stride / column offset and a residual source (multimodal.py:111,155)."""
+    dev = device
+    rng = np.random.default_rng(3)
+    B, T, F, H = 3, 7, 6, 8
+    x, W, U, b, _ = _lstm_case(rng, B, T, F, H, 0.0)
+    y_ref, _ = kr.lstm_forward(x, W, U, b, None, False)
+    R = rng.standard_normal((B, T, 2 * H)).astype(np.float32)
+    f32 = np.float32
+    Wp, Up, bp = dev.empty((F, 4 * H)), dev.empty((H, 4 * H)), dev.empty((4 * H,))
+    dev.call("mgr_lstm_pack", dev.array(W.astype(f32)), Wp, F, H, 0)
+    dev.call("mgr_lstm_pack", dev.array(U.astype(f32)), Up, H, H, 0)
+    dev.call("mgr_lstm_pack", dev.array(b.astype(f32)), bp, 1, H, 0)
+    Z = dev.empty((B, T, 4 * H))
+    dev.call("mgr_lstm_input_proj", dev.array(x.astype(f32)), F, 0, Wp, bp, Z, B, T, F, H)
+    ld = 3 * H + 4
+    OUT = dev.zeros((B, T, ld))
+    dR = dev.array(R)
+    dev.call("mgr_lstm_scan_fwd", Z, Up, OUT.view(H, (1,)), ld, dR.view(H, (1,)), 2 * H, 0, 0, B, T, H, 0, 0, 0)
+    out = OUT.download()
+    assert rel_err(out[:, :, H:2 * H], y_ref + R[:, :, H:]) < 2e-5
+    assert np.all(out[:, :, :H] == 0) and np.all(out[:, :, 2 * H:] == 0)
+
+
+def test_adam_maxnorm_noise_argmax(device):
+    dev = device
+    rng = np.random.default_rng(9)
+    n = 1003
+    p = rng.standard_normal(n).astype(np.float32)
+    g = (rng.standard_normal(n) * 2).astype(np.float32)
+    m = rng.standard_normal(n).astype(np.float32) * 0.1
+    v = rng.random(n).astype(np.float32) * 0.1
+    pr, mr, vr = p.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    lr_t = kr.adam_lr_t(1e-4, 1e-5, 7)
+    kr.adam_step(pr, g.astype(np.float64), mr, vr, lr_t, clipvalue=0.5, gscale=0.5)
+    dp, dg, dm, dv = dev.array(p), dev.array(g), dev.array(m), dev.array(v)
+    dev.call("mgr_adam_step", dp, dg, dm, dv, n, lr_t, 0.9, 0.999, 1e-7, 0.5, 0.5)
+    assert rel_err(dp.download(), pr) < 1e-6 and rel_err(dm.download(), mr) < 1e-6 and rel_err(dv.download(), vr) < 1e-6
+    W = (rng.standard_normal((37, 45)) * 1.2).astype(np.float32)
+    Wr = W.astype(np.float64)
+    kr.maxnorm_cols(Wr, 3.0)
+    dW = dev.array(W)
+    dev.call("mgr_maxnorm_cols", dW, 37, 45, 3.0, 1e-7)
+    assert rel_err(dW.download(), Wr) < 1e-6
+    x = np.zeros(200001, np.float32)
+    dx, dyv = dev.array(x), dev.empty((200001,))
+    dev.call("mgr_add_gaussian_noise", dx, dyv, x.size, 0.5, C.c_uint64(5))
+    yv = dyv.download()
+    assert abs(yv.mean()) < 0.01 and abs(yv.std() - 0.5) < 0.01
+    P = _rand_probs(rng, 3, 17, 22)
+    P[0, 5, 3] = P[0, 5, 7] = 0.9  # tie: first index wins
+    best, prob = dev.empty((3, 15), np.int32), dev.empty((3, 15))
+    dev.call("mgr_frame_argmax", dev.array(P), 3, 17, 22, 2, best, prob)
+    assert np.array_equal(best.download(), P[:, 2:].argmax(-1)) and np.array_equal(prob.download(), P[:, 2:].max(-1))
