@@ -10,6 +10,11 @@
 // shuffle-by-one of the neighbouring pair's label state; the three-way log-sum-exp is max-shifted fp32.
 // Emissions log y(t,.) are precomputed (phase 0, all 4 waves) and software-prefetched a chunk of time
 // steps ahead of the recursion, so the serial chain per step is shuffle -> lse -> add.
+// Numerics: alpha and beta are RENORMALISED every 16 time steps (the wave-wide max is subtracted and summed
+// into an fp64 scalar), so the stored log-values stay O(10) instead of O(-5000) at T=1900, where an fp32 ulp is
+// 5e-4 and would put percent-level noise on the gradient.  The loss adds the fp64 offset back; the gradient
+// needs no offsets at all because sum_u alpha(t,u)beta(t,u) = p(l|x) at every t, so each frame's occupancies
+// are normalised by their own sum.
 // Phase 2 (all 4 waves) combines alpha+beta into per-class occupancies through an LDS row per thread and
 // chains through softmax(log(P+eps)) and the network's own softmax to dLogits.
 #include "common.h"
@@ -121,6 +126,8 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
         }
       };
       load(cur, 1);
+      double coff = 0.0;
+      int since = 0;
       for (int t0 = 1; t0 < Tp; t0 += CH) {
         load(nxt, t0 + CH);
 #pragma unroll
@@ -146,8 +153,24 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
           }
         }
         cur = nxt;
+        since += CH;
+        if (since >= 16) {  // renormalise: keep the running log-values O(10)
+          since = 0;
+          float m = kNegInf;
+#pragma unroll
+          for (int j = 0; j < PPL; ++j) m = fmaxf(m, fmaxf(ab[j], al[j]));
+          for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+          if (m != kNegInf) {
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+              ab[j] -= m;
+              al[j] -= m;
+            }
+            coff += (double)m;
+          }
+        }
       }
-      // log p(l|x) = lse(alpha(2L, Tp-1), alpha(2L-1, Tp-1))
+      // log p(l|x) = lse(alpha(2L, Tp-1), alpha(2L-1, Tp-1)) + accumulated offset
       float fb = kNegInf, fl = kNegInf;
 #pragma unroll
       for (int j = 0; j < PPL; ++j) {
@@ -160,10 +183,10 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
         fb = fmaxf(fb, __shfl_xor(fb, o));
         fl = fmaxf(fl, __shfl_xor(fl, o));
       }
-      float logp = lse2(fb, fl);
+      float lfin = lse2(fb, fl);
       if (lane == 0) {
-        loss[b] = -logp;
-        *s_logp = logp;
+        loss[b] = (lfin == kNegInf) ? __builtin_huge_valf() : (float)(-((double)lfin + coff));
+        *s_logp = lfin;  // only its finiteness is used below
       }
     } else {
       float bb[PPL], bl[PPL];
@@ -195,6 +218,7 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
       };
       load(cur, 0);
       const int nsteps = Tp - 1;
+      int since = 0;
       for (int n0 = 0; n0 < nsteps; n0 += CH) {
         load(nxt, n0 + CH);
 #pragma unroll
@@ -226,6 +250,21 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
           }
         }
         cur = nxt;
+        since += CH;
+        if (since >= 16) {
+          since = 0;
+          float m = kNegInf;
+#pragma unroll
+          for (int j = 0; j < PPL; ++j) m = fmaxf(m, fmaxf(bb[j], bl[j]));
+          for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+          if (m != kNegInf) {
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+              bb[j] -= m;
+              bl[j] -= m;
+            }
+          }
+        }
       }
     }
   }
@@ -249,12 +288,27 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
     for (int c = 0; c < C; ++c) occ[c] = 0.f;
     const float* ar = ALb + (size_t)tt * S2;
     const float* br = BEb + (size_t)tt * S2;
+    float vmax = kNegInf;
     for (int p = 0; p <= L; ++p) {
       float2 a = *reinterpret_cast<const float2*>(ar + 2 * p);
       float2 be = *reinterpret_cast<const float2*>(br + 2 * p);
-      occ[blank] += __expf(a.x + be.x - logp);
-      if (p < L) occ[s_lab[p]] += __expf(a.y + be.y - logp);
+      vmax = fmaxf(vmax, a.x + be.x);
+      if (p < L) vmax = fmaxf(vmax, a.y + be.y);
     }
+    float den = 0.f;
+    for (int p = 0; p <= L; ++p) {
+      float2 a = *reinterpret_cast<const float2*>(ar + 2 * p);
+      float2 be = *reinterpret_cast<const float2*>(br + 2 * p);
+      float wb = __expf(a.x + be.x - vmax);
+      occ[blank] += wb;
+      den += wb;
+      if (p < L) {
+        float wl = __expf(a.y + be.y - vmax);
+        occ[s_lab[p]] += wl;
+        den += wl;
+      }
+    }
+    const float iden = 1.f / den;  // sum_u alpha*beta = p(l|x) for every t: normalise by the frame's own sum
     const float* row = P + ((size_t)b * T + f) * C;
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += row[c] + eps;
@@ -262,7 +316,7 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
     float dot = 0.f;
     for (int c = 0; c < C; ++c) {
       float u = row[c] + eps;
-      float gp = (u * inv - occ[c]) / u;
+      float gp = (u * inv - occ[c] * iden) / u;
       occ[c] = gp;
       dot += row[c] * gp;
     }
