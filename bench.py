@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py - headline metric of BASELINE.json on MI355X:
+train frames/sec (+ CTC-loss delta vs the fp64 oracle), fusion BiLSTM+CTC, B=64 per GPU, T=1900.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One JSON line on rank 0.  Inputs are synthetic and resident in HBM before the timed region; a step is one
+full training step (frozen encoders fwd, fusion BiLSTM fwd/bwd, CTC, Adam) with device-side noise/dropout
+RNG and one loss read-back, exactly K of them between barrier+sync pairs; value = all ranks' frames / max time.
+torch is used only for the multi-process rendezvous (gloo store) - never for compute.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 MFMA
+
+
+def cpu_baseline(spec_dict, seed, T_cpu, B_cpu):
+    """Reference-CPU leg: the oracle's fp32 numpy restatement of the Keras op structure, bounded sample."""
+    from oracle import network_ref as nr
+    rng = np.random.default_rng(seed)
+    w = nr.init_weights(spec_dict, rng, np.float32)
+    inputs, labels, il, ll = nr.synthetic_batch(spec_dict, B_cpu, T_cpu, 35, rng, np.float32)
+    rand = nr.draw_rand(spec_dict, B_cpu, T_cpu, rng, np.float32)
+    tr = nr.Trainer(spec_dict, w)
+    t0 = time.time()
+    loss = tr.train_on_batch(inputs, labels, il, ll, rand)
+    dt = time.time() - t0
+    return B_cpu * T_cpu / dt, dt, float(loss)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="F")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
+    ap.add_argument("--maxlen", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--cpu-T", type=int, default=400)
+    ap.add_argument("--cpu-B", type=int, default=64)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import mgr_amd  # noqa: F401
+    from mgr_amd import _capi
+    from mgr_amd.configs import baseline_config
+    from mgr_amd.engine import Engine
+    from mgr_amd.parallel import RcclComm
+    from mgr_amd.synthetic import synthetic_arrays, synthetic_weights
+
+    spec, B, T, Lmax = baseline_config(args.config)
+    if args.batch:
+        B = args.batch
+    if args.maxlen:
+        T = args.maxlen
+    dev = _capi.Device(local_rank)
+
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+
+        def bootstrap(uid):
+            obj = [uid]
+            dist.broadcast_object_list(obj, src=0)
+            return obj[0]
+
+        comm = RcclComm(dev, rank, world, bootstrap)
+
+    eng = Engine(spec, B, T, Lmax, device=dev, seed=1000 + rank, comm=comm, world=world)
+    eng.set_weights(synthetic_weights(spec, 20131900 + 3))
+    xs, labels, il, ll = synthetic_arrays(spec, B, T, Lmax, 20131900 + 3 + 17 * rank)
+    eng._upload_inputs(xs, None, True)
+    eng._upload_labels(labels, il, ll)
+    dev.sync()
+
+    def step():
+        eng.enqueue_train_step(None, None, None, None, rand=None, apply_update=True, upload=False)
+        return float(eng.loss_mean.download()[0])
+
+    for _ in range(args.warmup):
+        loss = step()
+    dev.prof_enable((1 << 10) - 1)
+    dev.prof_reset()
+    if comm:
+        comm.barrier()
+    dev.sync()
+    t0 = time.perf_counter()
+    losses = []
+    for _ in range(args.steps):
+        losses.append(step())
+    dev.sync()
+    if comm:
+        comm.barrier()
+    dt = time.perf_counter() - t0
+    if comm:
+        dt = comm.allreduce_max_scalar(dt)
+    fam = {}
+    for i, name in enumerate(_capi.KERNEL_FAMILIES):
+        n, ms = dev.prof_get(i)
+        fam[name] = {"launches": n, "ms": round(ms, 3)}
+    dev.prof_enable(0)
+
+    frames = B * T * world * args.steps
+    value = frames / dt
+    ms_per_step = dt / args.steps * 1e3
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel family (device time from HIP events on the launch streams) ----
+        dom = max(fam, key=lambda k: fam[k]["ms"])
+        flops_family = {}
+        gemm_nn = scan_fwd = scan_bwd = gemm_tn = gemm_nt = 0
+        for prefix, fin, H, _, tr in spec.lstm_layers():
+            gemm_nn += 2 * 2 * fin * 4 * H
+            scan_fwd += 2 * 2 * H * 4 * H
+            if tr:
+                scan_bwd += 2 * 2 * H * 4 * H
+                gemm_tn += 2 * 2 * (fin * 4 * H + H * 4 * H)
+        flops_family = {"gemm_nn": gemm_nn, "scan_fwd": scan_fwd, "scan_bwd": scan_bwd, "gemm_tn": gemm_tn, "gemm_nt": gemm_nt}
+        roof = None
+        if dom in flops_family and fam[dom]["ms"] > 0:
+            fl = flops_family[dom] * B * T * args.steps
+            ach = fl / (fam[dom]["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 5), "traffic": None,
+                    "avg_launch_ms": round(fam[dom]["ms"] / max(1, fam[dom]["launches"]), 4)}
+        whole = spec.flops_per_frame() * value / 1e12
+        # ---- parity: same weights / batch / injected randomness on a short-T slice vs the fp64 oracle ----
+        parity = None
+        if not args.no_parity:
+            parity = loss_parity(spec, dev)
+        cpu = None
+        if not args.no_cpu:
+            v, sec, _ = cpu_baseline(spec.to_dict(), 7, args.cpu_T, args.cpu_B)
+            cpu = {"value": round(v, 2), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+                   "sample": "one full train step of the same network, B=%d T=%d, numpy/OpenBLAS fp32 oracle, %.1f s"
+                             % (args.cpu_B, args.cpu_T, sec)}
+        out = {"metric": "train frames/sec, fusion BiLSTM+CTC", "value": round(value, 1), "unit": "frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[2]: multimodal_fusion fusion BiLSTM+CTC train step "
+                                      "(frozen audio 2xBiLSTM(500)+skeletal 2xBiLSTM(300), fusion BiLSTM(100), Dense 22, CTC)"
+                          if args.config == "F" else args.config,
+                          "per_gpu_batch": B, "global_batch": B * world, "maxlen": T, "parallelism": "dp%d" % world},
+               "roofline": roof, "cpu_baseline": cpu, "whole_step_tflops": round(whole, 3),
+               "whole_step_frac_of_mfma_peak": round(whole / MFMA_F32_PEAK_TFLOPS, 5),
+               "loss": losses[-1], "ctc_loss_parity": parity, "kernel_ms": fam,
+               "speedup_vs_cpu": round(value / cpu["value"], 1) if cpu else None}
+        print(json.dumps(out))
+    if comm:
+        comm.close()
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def loss_parity(spec, dev):
+    """CTC-loss delta vs the fp64 oracle on identical inputs (short-T slice so the CPU side takes seconds)."""
+    from mgr_amd.engine import Engine
+    from mgr_amd.synthetic import synthetic_arrays, synthetic_weights
+    from oracle import network_ref as nr
+    B, T, Lmax = 4, 64, 35
+    eng = Engine(spec, B, T, Lmax, device=dev, seed=5)
+    w = synthetic_weights(spec, 99)
+    eng.set_weights(w)
+    xs, labels, il, ll = synthetic_arrays(spec, B, T, Lmax, 123, lmin=3, lmax=10)
+    sd = spec.to_dict()
+    rng = np.random.default_rng(4)
+    rand = nr.draw_rand(sd, B, T, rng)
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    ref, _, _, _ = nr.loss_and_grads(sd, w64, xs, labels, il, ll, rand)
+    eng.enqueue_train_step(xs, labels, il, ll, rand=rand, apply_update=False)
+    got = float(eng.loss_mean.download()[0])
+    return {"gpu": got, "oracle_fp64": ref, "rel_delta": abs(got - ref) / abs(ref), "shape": "B=4,T=64"}
+
+
+if __name__ == "__main__":
+    main()
