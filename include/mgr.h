@@ -91,6 +91,26 @@ size_t mgr_lstm_scan_ws_bytes(int B, int T, int H);
 int mgr_lstm_scan_fwd(mgr_ctx* ctx, const float* Z, const float* Up, float* Y, int ldy, const float* R,
                       int ldr, float* gates, float* cs, int B, int T, int H, int reverse, void* ws,
                       size_t ws_bytes);
+/* Several independent recurrences (e.g. audio fwd/rev + skeletal fwd/rev of one encoder depth) in ONE call.
+ * Layers whose recurrent matrix does not fit one CU (H = 300, 500) run as a single persistent multi-CU launch
+ * (clusters of CUs exchanging h_t each step, lstm_cluster.hip); sharing the launch keeps every spinning
+ * workgroup co-resident.  Fields as in mgr_lstm_scan_fwd.  ws from mgr_lstm_scan_multi_ws_bytes. */
+typedef struct mgr_scan_job {
+  const float* Z;
+  const float* Up;
+  float* Y;
+  const float* R;
+  float* gates;
+  float* cs;
+  int ldy, ldr, B, T, H, reverse;
+} mgr_scan_job;
+size_t mgr_lstm_scan_multi_ws_bytes(int njobs, const mgr_scan_job* jobs);
+int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, void* ws, size_t ws_bytes);
+/* Tuning / test hooks.  key 0 (MGR_TUNE_SCAN_PATH): 0 auto, 1 force the L2-streaming fallback kernels,
+ * 2 force single-CU MFMA kernels where instantiated, 3 force the cluster kernel with 4 tiles per workgroup,
+ * 4 same with 8 tiles per workgroup. */
+enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 4 };
+int mgr_tune(mgr_ctx* ctx, int key, int value);
 /* BPTT: dY[b,t,0:H] (row stride lddy) is dLoss/dh_t from above; Y (stride ldy) is the layer's own output as
  * written by scan_fwd WITHOUT residual (needed only through gates/cs here).  Produces dZ [B,T,4H] packed. */
 int mgr_lstm_scan_bwd(mgr_ctx* ctx, const float* dY, int lddy, const float* gates, const float* cs,

@@ -43,6 +43,9 @@ SIGNATURES = {
     "mgr_lstm_input_proj": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32]),
     "mgr_lstm_scan_ws_bytes": (sz, [i32, i32, i32]),
     "mgr_lstm_scan_fwd": (i32, [vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, sz]),
+    "mgr_lstm_scan_multi_ws_bytes": (sz, [i32, vp]),
+    "mgr_lstm_scan_fwd_multi": (i32, [vp, i32, vp, vp, sz]),
+    "mgr_tune": (i32, [vp, i32, i32]),
     "mgr_lstm_scan_bwd": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz]),
     "mgr_lstm_param_grads_ws_bytes": (sz, [i32, i32, i32, i32]),
     "mgr_lstm_param_grads": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz]),
@@ -68,6 +71,26 @@ SIGNATURES = {
 
 (K_GEMM_NN, K_GEMM_TN, K_GEMM_NT, K_SCAN_FWD, K_SCAN_BWD, K_DENSE_FWD, K_DENSE_BWD, K_CTC, K_ADAM, K_MISC) = range(10)
 KERNEL_FAMILIES = ["gemm_nn", "gemm_tn", "gemm_nt", "scan_fwd", "scan_bwd", "dense_fwd", "dense_bwd", "ctc", "adam", "misc"]
+
+
+
+class ScanJob(C.Structure):
+    """struct mgr_scan_job"""
+    _fields_ = [("Z", vp), ("Up", vp), ("Y", vp), ("R", vp), ("gates", vp), ("cs", vp),
+                ("ldy", i32), ("ldr", i32), ("B", i32), ("T", i32), ("H", i32), ("reverse", i32)]
+
+
+def make_scan_jobs(jobs):
+    """jobs: list of dicts with the mgr_scan_job fields (DeviceArray or int pointers)."""
+    arr = (ScanJob * len(jobs))()
+    for a, j in zip(arr, jobs):
+        for k in ("Z", "Up", "Y", "R", "gates", "cs"):
+            v = j.get(k, 0)
+            setattr(a, k, v.ptr if isinstance(v, DeviceArray) else (v or 0))
+        for k in ("ldy", "ldr", "B", "T", "H", "reverse"):
+            setattr(a, k, int(j.get(k, 0)))
+    return arr
+
 
 _lib = None
 

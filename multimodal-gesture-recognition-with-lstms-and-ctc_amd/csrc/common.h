@@ -28,6 +28,7 @@ struct mgr_ctx {
   int prof_cap[MGR_K_COUNT];
   float prof_ms[MGR_K_COUNT];
   int prof_launches[MGR_K_COUNT];
+  int tune[MGR_TUNE_COUNT];
 };
 
 int mgr_fail(int code, const char* fmt, ...);

@@ -1,36 +1,208 @@
-// C-ABI entry points of the LSTM recurrence (K3, K7-scan): pick the kernel family for the shape.
-//   H in the weight-stationary set  -> lstm_mfma.hip   (one CU per 16-sample group, U in VGPRs)
-//   anything else (H <= 1024)       -> lstm_simple.hip (U streamed from L2; correctness fallback)
+// C-ABI entry points of the LSTM recurrence (K3, K7-scan): pick the kernel family for each shape.
+//   H with a weight-stationary single-CU instantiation (<= 128)  -> lstm_mfma.hip
+//   H = 300 / 500 (and test sizes)                               -> lstm_cluster.hip (persistent multi-CU clusters)
+//   anything else (H <= 1024)                                    -> lstm_simple.hip (U streamed from L2; fallback)
+#include <algorithm>
+
 #include "common.h"
+#include "lstm_cluster.h"
 
 int mgr_scan_fwd_simple(mgr_ctx*, const float*, const float*, float*, int, const float*, int, float*, float*, int, int, int, int);
 int mgr_scan_bwd_simple(mgr_ctx*, const float*, int, const float*, const float*, const float*, float*, int, int, int, int);
 int mgr_scan_fwd_mfma(mgr_ctx*, const float*, const float*, float*, int, const float*, int, float*, float*, int, int, int, int);
 int mgr_scan_bwd_mfma(mgr_ctx*, const float*, int, const float*, const float*, const float*, float*, int, int, int, int);
 
-static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+namespace {
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+bool has_mfma_fwd(int H) { return H == 4 || H == 8 || H == 16 || H == 32 || H == 64 || H == 100 || H == 128; }
+
+struct Cfg {
+  int nw, tpw;
+};
+// candidate (active waves, tiles per wave) configurations, most parallel first
+const Cfg kCfgs[3] = {{4, 1}, {8, 1}, {8, 2}};
+
+struct Plan {
+  bool cluster[MGR_MAX_SCAN_JOBS];
+  Cfg cfg[MGR_MAX_SCAN_JOBS];
+  int G[MGR_MAX_SCAN_JOBS], nbg[MGR_MAX_SCAN_JOBS], wgs[MGR_MAX_SCAN_JOBS];
+  int total;
+  bool any;
+};
+
+size_t job_ws(const mgr_scan_job& j) {
+  int ks = j.H / 4;
+  size_t img = (size_t)((ks + 3) / 4) * 256;
+  int nbg = (j.B + 15) / 16;
+  return mgr_align_up((size_t)nbg * 2 * img * sizeof(float), 256) + mgr_align_up((size_t)nbg * 64 * sizeof(unsigned), 256);
+}
+
+// Choose per-job configurations: minimise the slowest job's per-step MFMA time subject to all workgroups
+// being co-resident (sum <= CUs).  Jobs that cannot run on the cluster kernel are left to the other families.
+void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
+  int path = c->tune[MGR_TUNE_SCAN_PATH];
+  P.any = false;
+  P.total = 0;
+  int idx[MGR_MAX_SCAN_JOBS], n = 0;
+  for (int i = 0; i < njobs; ++i) {
+    int H = jobs[i].H, ks = H / 4;
+    bool ok = (H % 4 == 0) && (mgr_cluster_supported(ks, 1));
+    if (path == 1 || path == 2) ok = false;
+    if (path == 0 && has_mfma_fwd(H)) ok = false;  // single-CU kernel needs no exchange
+    P.cluster[i] = ok;
+    if (ok) idx[n++] = i;
+  }
+  if (n == 0) return;
+  int best[MGR_MAX_SCAN_JOBS], cur[MGR_MAX_SCAN_JOBS];
+  long best_cost = -1;
+  int combos = 1;
+  for (int k = 0; k < n; ++k) combos *= 3;
+  for (int code = 0; code < combos; ++code) {
+    int x = code, total = 0;
+    long worst = 0, sum = 0;
+    bool feas = true;
+    for (int k = 0; k < n; ++k) {
+      cur[k] = x % 3;
+      x /= 3;
+      const mgr_scan_job& j = jobs[idx[k]];
+      Cfg f = kCfgs[cur[k]];
+      int ks = j.H / 4;
+      if (!mgr_cluster_supported(ks, f.tpw)) feas = false;
+      if (path == 3 && cur[k] != 0) feas = false;
+      if (path == 4 && cur[k] != 1) feas = false;
+      int tiles = f.nw * f.tpw;
+      int G = (ks + tiles - 1) / tiles;
+      if (G > 64) feas = false;
+      int nbg = (j.B + 15) / 16;
+      total += G * nbg;
+      long t = (long)(f.nw / 4) * f.tpw * ks * 32 + (G > 1 ? 6000 : 0);  // MFMA cycles per SIMD + exchange estimate
+      worst = std::max(worst, t);
+      sum += t;
+    }
+    if (!feas || total > c->cu_count) continue;
+    long cost = worst * 1000 + sum / n;
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      for (int k = 0; k < n; ++k) best[k] = cur[k];
+    }
+  }
+  if (best_cost < 0) {  // does not fit: leave these jobs to the fallback
+    for (int k = 0; k < n; ++k) P.cluster[idx[k]] = false;
+    return;
+  }
+  for (int k = 0; k < n; ++k) {
+    int i = idx[k];
+    P.cfg[i] = kCfgs[best[k]];
+    int tiles = P.cfg[i].nw * P.cfg[i].tpw;
+    P.G[i] = (jobs[i].H / 4 + tiles - 1) / tiles;
+    P.nbg[i] = (jobs[i].B + 15) / 16;
+    P.wgs[i] = P.G[i] * P.nbg[i];
+    P.total += P.wgs[i];
+  }
+  P.any = true;
+}
+
+}  // namespace
 
 extern "C" {
 
+int mgr_tune(mgr_ctx* c, int key, int value) {
+  MGR_REQUIRE(c && key >= 0 && key < MGR_TUNE_COUNT, "bad tune key");
+  c->tune[key] = value;
+  return 0;
+}
+
 size_t mgr_lstm_scan_ws_bytes(int B, int T, int H) {
-  (void)B;
   (void)T;
-  return mgr_align_up((size_t)4 * H * H * sizeof(float), 256);  // U^T for the fallback backward kernel
+  mgr_scan_job j;
+  memset(&j, 0, sizeof(j));
+  j.B = B;
+  j.H = H;
+  size_t fallback = mgr_align_up((size_t)4 * H * H * sizeof(float), 256);  // U^T for the fallback backward kernel
+  return std::max(fallback, job_ws(j) + 256);
+}
+
+size_t mgr_lstm_scan_multi_ws_bytes(int njobs, const mgr_scan_job* jobs) {
+  size_t s = 256;
+  for (int i = 0; i < njobs; ++i) s += job_ws(jobs[i]);
+  return s;
+}
+
+int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, void* ws, size_t ws_bytes) {
+  MGR_REQUIRE(c && jobs && njobs > 0 && njobs <= MGR_MAX_SCAN_JOBS, "bad job list");
+  for (int i = 0; i < njobs; ++i) {
+    const mgr_scan_job& j = jobs[i];
+    MGR_REQUIRE(j.Z && j.Up && j.Y, "job %d: null argument", i);
+    MGR_REQUIRE(j.B > 0 && j.T > 0 && j.H > 0 && j.ldy >= j.H && (!j.R || j.ldr >= j.H), "job %d: bad shape", i);
+    MGR_REQUIRE(aligned16(j.Z) && aligned16(j.Up) && (!j.gates || aligned16(j.gates)), "job %d: Z/Up/gates must be 16-byte aligned", i);
+  }
+  int r = mgr_prof_begin(c, MGR_K_SCAN_FWD);
+  if (r) return r;
+  Plan P;
+  make_plan(c, njobs, jobs, P);
+  if (P.any && (!ws || ws_bytes < mgr_lstm_scan_multi_ws_bytes(njobs, jobs))) {
+    // no workspace for the exchange: degrade to the non-cluster families
+    for (int i = 0; i < njobs; ++i) P.cluster[i] = false;
+    P.any = false;
+  }
+  unsigned* status = nullptr;
+  if (P.any) {
+    ClusterLaunch L;
+    memset(&L, 0, sizeof(L));
+    char* w = reinterpret_cast<char*>(ws);
+    status = reinterpret_cast<unsigned*>(w);
+    char* base = w;
+    w += 256;
+    int begin = 0;
+    for (int i = 0; i < njobs; ++i) {
+      if (!P.cluster[i]) continue;
+      const mgr_scan_job& j = jobs[i];
+      ClusterJob& cj = L.job[L.njobs++];
+      int ks = j.H / 4;
+      size_t img = (size_t)((ks + 3) / 4) * 256;
+      cj.Z = j.Z; cj.Up = j.Up; cj.Y = j.Y; cj.R = j.R; cj.G = j.gates; cj.Cs = j.cs;
+      cj.ldy = j.ldy; cj.ldr = j.ldr; cj.B = j.B; cj.T = j.T; cj.H = j.H; cj.reverse = j.reverse;
+      cj.ks = ks; cj.tpw = P.cfg[i].tpw; cj.nw = P.cfg[i].nw;
+      cj.wg_begin = begin; cj.G_ = P.G[i]; cj.nbg = P.nbg[i];
+      begin += P.wgs[i];
+      cj.flags = reinterpret_cast<unsigned*>(w);
+      w += mgr_align_up((size_t)P.nbg[i] * 64 * sizeof(unsigned), 256);
+      cj.xbuf = reinterpret_cast<float*>(w);
+      w += mgr_align_up((size_t)P.nbg[i] * 2 * img * sizeof(float), 256);
+    }
+    L.status = status;
+    // flags + status must be zero at every launch (epochs count from 1 within the call)
+    MGR_HIP(hipMemsetAsync(base, 0, (size_t)(w - base), mgr_stream(c)));
+    r = mgr_cluster_launch(c, L, P.total);
+    if (r) return r;
+  }
+  for (int i = 0; i < njobs; ++i) {
+    if (P.cluster[i]) continue;
+    const mgr_scan_job& j = jobs[i];
+    int path = c->tune[MGR_TUNE_SCAN_PATH];
+    r = 0;
+    if (path != 1) r = mgr_scan_fwd_mfma(c, j.Z, j.Up, j.Y, j.ldy, j.R, j.ldr, j.gates, j.cs, j.B, j.T, j.H, j.reverse);
+    if (r == 0) r = mgr_scan_fwd_simple(c, j.Z, j.Up, j.Y, j.ldy, j.R, j.ldr, j.gates, j.cs, j.B, j.T, j.H, j.reverse);
+    if (r < 0) return r;
+  }
+  r = mgr_prof_end(c, MGR_K_SCAN_FWD);
+  if (r) return r;
+  if (status && c->tune[1]) {  // tune key 1: synchronous status check (tests)
+    unsigned st = 0;
+    MGR_HIP(hipMemcpyAsync(&st, status, sizeof(st), hipMemcpyDeviceToHost, mgr_stream(c)));
+    MGR_HIP(hipStreamSynchronize(mgr_stream(c)));
+    MGR_REQUIRE(st == 0, "cluster scan: a bounded spin gave up (status %u)", st);
+  }
+  return 0;
 }
 
 int mgr_lstm_scan_fwd(mgr_ctx* c, const float* Z, const float* Up, float* Y, int ldy, const float* R, int ldr,
                       float* gates, float* cs, int B, int T, int H, int reverse, void* ws, size_t ws_bytes) {
-  (void)ws;
-  (void)ws_bytes;
-  MGR_REQUIRE(c && Z && Up && Y, "null argument");
-  MGR_REQUIRE(B > 0 && T > 0 && H > 0 && ldy >= H && (!R || ldr >= H), "bad shape");
-  MGR_REQUIRE(aligned16(Z) && aligned16(Up) && (!gates || aligned16(gates)), "Z/Up/gates must be 16-byte aligned");
-  int r = mgr_prof_begin(c, MGR_K_SCAN_FWD);
-  if (r) return r;
-  r = mgr_scan_fwd_mfma(c, Z, Up, Y, ldy, R, ldr, gates, cs, B, T, H, reverse);
-  if (r == 0) r = mgr_scan_fwd_simple(c, Z, Up, Y, ldy, R, ldr, gates, cs, B, T, H, reverse);
-  if (r < 0) return r;
-  return mgr_prof_end(c, MGR_K_SCAN_FWD);
+  mgr_scan_job j;
+  j.Z = Z; j.Up = Up; j.Y = Y; j.R = R; j.gates = gates; j.cs = cs;
+  j.ldy = ldy; j.ldr = ldr; j.B = B; j.T = T; j.H = H; j.reverse = reverse;
+  return mgr_lstm_scan_fwd_multi(c, 1, &j, ws, ws_bytes);
 }
 
 int mgr_lstm_scan_bwd(mgr_ctx* c, const float* dY, int lddy, const float* gates, const float* cs, const float* Up,
@@ -40,9 +212,10 @@ int mgr_lstm_scan_bwd(mgr_ctx* c, const float* dY, int lddy, const float* gates,
   MGR_REQUIRE(aligned16(gates) && aligned16(Up) && aligned16(dZ), "gates/Up/dZ must be 16-byte aligned");
   int r = mgr_prof_begin(c, MGR_K_SCAN_BWD);
   if (r) return r;
-  r = mgr_scan_bwd_mfma(c, dY, lddy, gates, cs, Up, dZ, B, T, H, reverse);
+  r = 0;
+  if (c->tune[MGR_TUNE_SCAN_PATH] != 1) r = mgr_scan_bwd_mfma(c, dY, lddy, gates, cs, Up, dZ, B, T, H, reverse);
   if (r == 0) {
-    MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_scan_ws_bytes(B, T, H), "workspace too small");
+    MGR_REQUIRE(ws && ws_bytes >= mgr_align_up((size_t)4 * H * H * sizeof(float), 256), "workspace too small");
     float* UpT = reinterpret_cast<float*>(ws);
     r = mgr_transpose(c, Up, UpT, H, 4 * H);
     if (r) return r;

@@ -252,9 +252,14 @@ class Engine:
         W = sp.concat_width
         save = train and not self.inference_only
         slot = 0
-        col = 0
         used_streams = []
         self._masks = {}
+        cols = {}
+        col = 0
+        for s in sp.streams:
+            cols[s["name"]] = col
+            col += sp.stream_width(s)
+        # GaussianNoise (K1) per stream
         for si, s in enumerate(sp.streams):
             sa, sb = 1 + 2 * si, 2 + 2 * si
             used_streams += [sa, sb]
@@ -263,17 +268,29 @@ class Engine:
             dev.stream(sa)
             dev.wait(sa, 0)
             if train and rand is None and s["noise"] > 0:
-                # GaussianNoise on device; the resident input stays pristine for the next step
+                # on device; the resident input stays pristine for the next step
                 dev.call("mgr_add_gaussian_noise", X, self.X[name], X.size, float(s["noise"]),
                          C.c_uint64(self._seed(900 + si)))
                 X = self.X[name]
             self._xcur[name] = X
             dev.wait(sb, sa)
-            nl = len(s["layers"])
-            cur, ldcur, fin = X, s["F"], s["F"]
-            for k, lay in enumerate(s["layers"]):
-                H = lay["H"]
+        depth = max(len(s["layers"]) for s in sp.streams)
+        for k in range(depth):
+            jobs = []
+            for si, s in enumerate(sp.streams):
+                nl = len(s["layers"])
+                if k >= nl:
+                    continue
+                sa, sb = 1 + 2 * si, 2 + 2 * si
+                name = s["name"]
+                H = s["layers"][k]["H"]
                 last = k == nl - 1
+                col = cols[name]
+                if k == 0:
+                    cur, ldcur, fin = self._xcur[name], s["F"], s["F"]
+                else:
+                    Hp = s["layers"][k - 1]["H"]
+                    cur, ldcur, fin = self.Y1[name], 2 * Hp, 2 * Hp
                 for di, (dname, st) in enumerate((("fwd", sa), ("bwd", sb))):
                     L = self.dirs["%s/l%d/%s" % (name, k, dname)]
                     dev.stream(st)
@@ -291,19 +308,23 @@ class Engine:
                         Y, ldy = self.FEAT.view(col + di * H, (1,)), W
                         if nl == 2 and s["residual"]:
                             R, ldr = self.Y1[name].view(di * H, (1,)), 2 * H
-                    g = L.gates if (save and L.trainable) else 0
-                    cs = L.cs if (save and L.trainable) else 0
-                    dev.call("mgr_lstm_scan_fwd", Z, L.Up, Y, ldy, R, ldr, g, cs, B, T, H, L.reverse, 0, 0)
-                dev.wait(sa, sb)
-                dev.wait(sb, sa)
-                if not last:
-                    cur, ldcur, fin = self.Y1[name], 2 * H, 2 * H
-            if nl == 2 and s["residual"] and name in self.Y2 and save:
+                    keep = save and L.trainable
+                    jobs.append(dict(Z=Z, Up=L.Up, Y=Y, ldy=ldy, R=R, ldr=ldr, gates=L.gates if keep else 0,
+                                     cs=L.cs if keep else 0, B=B, T=T, H=H, reverse=L.reverse))
+            # all recurrences of this depth in ONE call (one persistent multi-CU launch when H is large)
+            dev.stream(0)
+            for st in used_streams:
+                dev.wait(0, st)
+            self._scan_multi(jobs)
+            for st in used_streams:
+                dev.wait(st, 0)
+        for si, s in enumerate(sp.streams):
+            name = s["name"]
+            if len(s["layers"]) == 2 and s["residual"] and name in self.Y2 and save:
                 H = s["layers"][-1]["H"]
-                dev.stream(sa)
-                dev.call("mgr_add2d", self.Y1[name], 2 * H, self.Y2[name], 2 * H, self.FEAT.view(col, (1,)), W,
+                dev.stream(1 + 2 * si)
+                dev.call("mgr_add2d", self.Y1[name], 2 * H, self.Y2[name], 2 * H, self.FEAT.view(cols[name], (1,)), W,
                          B * T, 2 * H)
-            col += sp.stream_width(s)
         dev.stream(0)
         for st in used_streams:
             dev.wait(0, st)
@@ -345,6 +366,14 @@ class Engine:
         self._feat = (feat, ldf)
         if train:
             self.rng_step += 1
+
+    def _scan_multi(self, jobs):
+        arr = _capi.make_scan_jobs(jobs)
+        need = self.lib.mgr_lstm_scan_multi_ws_bytes(len(jobs), arr)
+        if getattr(self, "_ws_multi", None) is None or self._ws_multi.nbytes < need:
+            self._ws_multi = self.dev.bytes(need)
+        _capi.check(self.lib.mgr_lstm_scan_fwd_multi(self.dev.ctx, len(jobs), arr, self._ws_multi.ptr,
+                                                     self._ws_multi.nbytes))
 
     # ------------------------------------------------------------------------------------------ public
     def predict(self, inputs):

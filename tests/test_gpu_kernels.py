@@ -238,3 +238,44 @@ def test_adam_maxnorm_noise_argmax(device):
     best, prob = dev.empty((3, 15), np.int32), dev.empty((3, 15))
     dev.call("mgr_frame_argmax", dev.array(P), 3, 17, 22, 2, best, prob)
     assert np.array_equal(best.download(), P[:, 2:].argmax(-1)) and np.array_equal(prob.download(), P[:, 2:].max(-1))
+
+
+@pytest.mark.parametrize("B,T,H,path", [(5, 9, 32, 3), (33, 6, 32, 3), (17, 7, 100, 3), (17, 7, 100, 4), (20, 5, 300, 0),
+                                        (18, 5, 500, 0), (64, 4, 500, 3), (3, 6, 12, 3)])
+def test_cluster_scan_matches_oracle(device, B, T, H, path):
+    """Persistent multi-CU scan (per-step sc1 hand-off between workgroups) vs the oracle, both directions in ONE launch."""
+    from mgr_amd import _capi
+    dev = device
+    rng = np.random.default_rng(H + B)
+    F = 6
+    f32 = np.float32
+    jobs, refs, outs, keep = [], [], [], []
+    for reverse in (0, 1):
+        x, W, U, b, _ = _lstm_case(rng, B, T, F, H, 0.0)
+        U = U * (0.1 if H >= 300 else 1.0)
+        y_ref, cache = kr.lstm_forward(x, W, U, b, None, bool(reverse))
+        Wp, Up, bp = dev.empty((F, 4 * H)), dev.empty((H, 4 * H)), dev.empty((4 * H,))
+        dev.call("mgr_lstm_pack", dev.array(W.astype(f32)), Wp, F, H, 0)
+        dev.call("mgr_lstm_pack", dev.array(U.astype(f32)), Up, H, H, 0)
+        dev.call("mgr_lstm_pack", dev.array(b.astype(f32)), bp, 1, H, 0)
+        Z = dev.empty((B, T, 4 * H))
+        dev.call("mgr_lstm_input_proj", dev.array(x.astype(f32)), F, 0, Wp, bp, Z, B, T, F, H)
+        Y, G, Cs = dev.empty((B, T, H)), dev.empty((B, T, H, 4)), dev.empty((B, T, H))
+        jobs.append(dict(Z=Z, Up=Up, Y=Y, ldy=H, R=0, ldr=0, gates=G, cs=Cs, B=B, T=T, H=H, reverse=reverse))
+        refs.append((y_ref, cache))
+        outs.append((Y, G, Cs))
+        keep += [Wp, Up, bp, Z]
+    dev.call("mgr_tune", 0, path)
+    dev.call("mgr_tune", 1, 1)  # synchronous give-up check
+    try:
+        arr = _capi.make_scan_jobs(jobs)
+        ws = dev.bytes(dev.lib.mgr_lstm_scan_multi_ws_bytes(2, arr))
+        for rep in range(2):  # second launch re-uses the (re-zeroed) flags
+            _capi.check(dev.lib.mgr_lstm_scan_fwd_multi(dev.ctx, 2, arr, ws.ptr, ws.nbytes))
+            for (Y, G, Cs), (y_ref, cache) in zip(outs, refs):
+                assert rel_err(Y.download(), y_ref) < 3e-5
+                assert rel_err(Cs.download(), cache["c"]) < 3e-5
+                assert rel_err(G.download()[..., 3], cache["o"]) < 3e-5
+    finally:
+        dev.call("mgr_tune", 0, 0)
+        dev.call("mgr_tune", 1, 0)
