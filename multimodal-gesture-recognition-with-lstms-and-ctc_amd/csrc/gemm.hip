@@ -125,7 +125,9 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const float* __restrict__ X, in
   const float* Xb = X + (size_t)b * T * ldx;
   f32x16 acc[2][2];
   zero_acc(acc);
-  RegTile ra, rb;
+  RegTile ra, rb, rm;
+  // The mask factors are only LOADED here and multiplied in at the LDS-store phase, so that the prefetch of the
+  // next stage stays in flight under the current stage's MFMAs (a multiply here would force vmcnt(0) right away).
   auto fetch = [&](int k0) {
     load_kc(ra, Xb, (size_t)ldx, r0, k0, T, F, vecA != 0, tid);
     load_mc(rb, Wp, (size_t)N, n0, k0, N, F, true, tid);
@@ -134,17 +136,23 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const float* __restrict__ X, in
       for (int i = 0; i < 2; ++i) {
         int idx4 = tid + i * 256;
         int k = k0 + (idx4 >> 5);
-        if (k < F) {
-          // n is a multiple of 4: the 4 lanes of the float4 are gates 0..3 of one unit
+        k = k < F ? k : F - 1;
+        // n is a multiple of 4: the 4 lanes of the float4 are gates 0..3 of one unit
 #pragma unroll
-          for (int g = 0; g < 4; ++g) rb.v[i * 4 + g] *= mask4[((size_t)g * B + b) * F + k];
-        }
+        for (int g = 0; g < 4; ++g) rm.v[i * 4 + g] = mask4[((size_t)g * B + b) * F + k];
       }
     }
   };
+  auto stash = [&]() {
+    if (mask4) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rb.v[e] *= rm.v[e];
+    }
+    store_kc(As, ra, tid);
+    store_mc(Bs, rb, tid);
+  };
   fetch(0);
-  store_kc(As, ra, tid);
-  store_mc(Bs, rb, tid);
+  stash();
   __syncthreads();
   for (int k0 = 0; k0 < F; k0 += BK) {
     bool more = k0 + BK < F;
@@ -152,8 +160,7 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const float* __restrict__ X, in
     mma_stage(As, Bs, acc, wr, wc, lane);
     __syncthreads();
     if (more) {
-      store_kc(As, ra, tid);
-      store_mc(Bs, rb, tid);
+      stash();
       __syncthreads();
     }
   }
@@ -249,26 +256,33 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ dZ, c
   const float* Zb = dZ + (size_t)b * T * N;
   f32x16 acc[2][2];
   zero_acc(acc);
-  RegTile ra, rb;
+  RegTile ra, rb, rm;
+  // the mask factor of a B element depends only on (gate, f): constant over the K loop -> load once
+  if (mask4) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int idx4 = tid + i * 256;
+      int f = f0 + (idx4 >> 2);
+      f = f < F ? f : F - 1;
+      // k0 and k4 are multiples of 4: the float4 covers gates 0..3 of one unit
+#pragma unroll
+      for (int g = 0; g < 4; ++g) rm.v[i * 4 + g] = mask4[((size_t)g * B + b) * F + f];
+    }
+  }
   auto fetch = [&](int k0) {
     load_kc(ra, Zb, (size_t)N, r0, k0, T, N, true, tid);
     load_kc(rb, Wp, (size_t)N, f0, k0, F, N, true, tid);
+  };
+  auto stash = [&]() {
     if (mask4) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        int idx4 = tid + i * 256;
-        int f = f0 + (idx4 >> 2);
-        if (f < F) {
-          // k0 and k4 are multiples of 4: the float4 covers gates 0..3 of one unit
-#pragma unroll
-          for (int g = 0; g < 4; ++g) rb.v[i * 4 + g] *= mask4[((size_t)g * B + b) * F + f];
-        }
-      }
+      for (int e = 0; e < 8; ++e) rb.v[e] *= rm.v[e];
     }
+    store_kc(As, ra, tid);
+    store_kc(Bs, rb, tid);
   };
   fetch(0);
-  store_kc(As, ra, tid);
-  store_kc(Bs, rb, tid);
+  stash();
   __syncthreads();
   for (int k0 = 0; k0 < N; k0 += BK) {
     bool more = k0 + BK < N;
@@ -276,8 +290,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ dZ, c
     mma_stage(As, Bs, acc, wr, wc, lane);
     __syncthreads();
     if (more) {
-      store_kc(As, ra, tid);
-      store_kc(Bs, rb, tid);
+      stash();
       __syncthreads();
     }
   }

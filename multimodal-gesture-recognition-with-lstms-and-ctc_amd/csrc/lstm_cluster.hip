@@ -6,16 +6,19 @@
 //   1. runs its MFMA chain  D[gate-col, sample] += U^T . h_{t-1}^T  (v_mfma_f32_16x16x4_f32, B operand from an LDS
 //      image of h_{t-1} laid out [k/16][k%4][sample][(k/4)%4], same as lstm_mfma.hip),
 //   2. applies the cell update in registers, writes its h_t slice into the next LDS image,
-//   3. PUBLISHES that slice: its slice is one or more contiguous 1 KiB blocks of the image, copied by wave 0 to
-//      the cluster's exchange slot (t&1) with 16-byte write-through (sc1) stores, drained with s_waitcnt vmcnt(0),
-//      then flagged with a relaxed agent-scope store of the epoch t+1,
-//   4. wave 0 polls the G flags (one lane each, relaxed sc1 loads, s_sleep back-off, bounded), the workgroup
-//      barriers, and all 8 waves gather the peers' blocks with 16-byte sc1 loads straight into the LDS image.
-// This is the placement-independent hand-off of the CDNA guide (Guideline 16 R1 with sc1 loads in place of the
-// acquire: every payload store is sc1 and drained by the one storing wave before its flag; every payload load
-// is an sc1 buffer load issued after the polling wave's match + a workgroup barrier; hipMalloc memory; one
-// workgroup per CU, enforced by requesting > 80 KiB of LDS).  Two exchange slots suffice: a workgroup can only
-// publish h_{t+2} after every peer has published h_{t+1}, i.e. after every peer finished reading h_t.
+//   3. PUBLISHES every h value the moment it is computed: a 4-byte write-through (sc1) store into the cluster's
+//      exchange slot (t&1), in the same image layout.  THE DATA IS THE FLAG: the least-significant mantissa bit of
+//      each value carries the epoch parity ((t>>1)&1)^1, which flips every time a slot word is rewritten (the
+//      local copy, Y and the recurrence all use the same 1-ulp-adjusted value, so all replicas agree bit for bit),
+//   4. GATHERS the peers' slices: each of the 8 waves sweeps its share of the image's 1 KiB blocks with 16-byte
+//      sc1 loads, accepts a block once all of its words show the expected parity, and writes it to the next LDS
+//      image; one workgroup barrier per time step.
+// This is the guide's granule hand-off (Guideline 16 R2, "the data is the flag") with a 4-byte granule: every word
+// is written by exactly one aligned store per epoch; a reader of epoch t can only ever see the word of epoch t-2
+// (opposite parity) or t, never t+2, because a producer cannot publish epoch t+2 before every peer has published
+// t+1, i.e. finished consuming t.  It needs no fence, no flag round trip and no drain, so a step costs ONE
+// store->load flight instead of three.  hipMalloc memory; one workgroup per CU (enforced by requesting > 80 KiB
+// of LDS); slots are zeroed by a memset node ahead of every launch.
 // Every spin is bounded; a give-up sets status[0] and the host reports an error instead of hanging the GPU.
 //
 // Several layer-directions ("jobs": audio fwd/rev, skeletal fwd/rev) share ONE launch so that all spinning
@@ -27,11 +30,12 @@ namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int CL_WAVES = 8;
-constexpr unsigned POLL_LIMIT = 1u << 21;
+constexpr unsigned POLL_LIMIT = 1u << 20;
 
 template <int KS, int TPW>
 __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float* smem, unsigned* status) {
   constexpr int H = 4 * KS, N = 4 * H, QN = (KS + 3) / 4, IMG = QN * 256;
+  static_assert(QN <= 4 * CL_WAVES, "gather sweep covers at most 32 image blocks (H <= 512)");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, uq = lane >> 4;
   const int G = jb.G_;
@@ -61,7 +65,6 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float*
 
   const int q0 = (ug * tiles_per_wg) >> 2, nq = tiles_per_wg >> 2;  // own 1 KiB blocks of the image
   float* xb = jb.xbuf + (size_t)bg * 2 * IMG;
-  unsigned* fl = jb.flags + bg * 64;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, 2 * IMG * 4, 0x00020000);
 
   float c[TPW];
@@ -89,6 +92,8 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float*
     for (int jt = 0; jt < TPW; ++jt) acc[jt] = zc[jt];
     const float* hb = img + cur * IMG;
     float* hn = img + (cur ^ 1) * IMG;
+    const int slot = step & 1;
+    const unsigned par = (((unsigned)step >> 1) & 1u) ^ 1u;
     if (wave < nw) {
 #pragma unroll
       for (int q = 0; q < QN; ++q) {
@@ -109,7 +114,13 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float*
           const int unit = tile * 4 + uq;
           float4 g4;
           float h = mgr_cell_fwd(acc[jt][0], acc[jt][1], acc[jt][2], acc[jt][3], c[jt], g4);
-          hn[(((tile >> 2) * 4 + uq) * 16 + j) * 4 + (tile & 3)] = h;
+          const int idx = (((tile >> 2) * 4 + uq) * 16 + j) * 4 + (tile & 3);
+          if (G > 1) {
+            const unsigned hbits = (__float_as_uint(h) & ~1u) | par;  // epoch parity rides in the mantissa LSB
+            h = __uint_as_float(hbits);
+            if (step + 1 < T) __builtin_amdgcn_raw_buffer_store_b32(hbits, rs, (slot * IMG + idx) * 4, 0, 16);  // sc1
+          }
+          hn[idx] = h;
           if (bvalid) {
             size_t row = (size_t)b * T + t;
             float yo = h;
@@ -123,48 +134,56 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float*
     }
 #pragma unroll
     for (int jt = 0; jt < TPW; ++jt) zc[jt] = zn[jt];
-    __syncthreads();  // own slice of h_t is in the next image
     if (G > 1 && step + 1 < T) {
-      const int slot = step & 1;
-      const unsigned epoch = (unsigned)step + 1u;
-      if (wave == 0) {
-        for (int qq = 0; qq < nq; ++qq) {
-          int q = q0 + qq;
-          if (q < QN) {
-            u32x4 v = *reinterpret_cast<const u32x4*>(hn + q * 256 + lane * 4);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs, (slot * IMG + q * 256 + lane * 4) * 4, 0, 16);  // sc1
+      // gather: wave w sweeps blocks w, w+8, w+16, w+24 of the exchange slot until every word has this epoch's parity
+      u32x4 v[4];
+      unsigned pend = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int q = wave + CL_WAVES * i;
+        if (q < QN && (q < q0 || q >= q0 + nq)) pend |= 1u << i;
+      }
+      unsigned spins = 0;
+      while (pend && !failed) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (pend & (1u << i))
+            v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (slot * IMG + (wave + CL_WAVES * i) * 256 + lane * 4) * 4, 0, 16);  // sc1
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (pend & (1u << i)) {
+            const int q = wave + CL_WAVES * i;
+            const int nvalid = KS - 4 * q;  // k-steps of this block that exist (words r >= nvalid are never written)
+            unsigned a = par ? 0xFFFFFFFFu : 0u;
+            if (par) {
+              a &= v[i].x;
+              if (nvalid > 1) a &= v[i].y;
+              if (nvalid > 2) a &= v[i].z;
+              if (nvalid > 3) a &= v[i].w;
+            } else {
+              a |= v[i].x;
+              if (nvalid > 1) a |= v[i].y;
+              if (nvalid > 2) a |= v[i].z;
+              if (nvalid > 3) a |= v[i].w;
+            }
+            if (__all((a & 1u) == par)) {
+              *reinterpret_cast<u32x4*>(hn + q * 256 + lane * 4) = v[i];
+              pend &= ~(1u << i);
+            }
           }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the one storing wave drains before it flags
-        if (lane == 0) __hip_atomic_store(fl + ug, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!failed) {
-          unsigned spins = 0;
-          for (;;) {
-            bool ok = lane >= G || __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
-            if (__all(ok)) break;
-            __builtin_amdgcn_s_sleep(1);
-            ++spins;
-            if ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-              failed = true;
-              break;
-            }
-            if (spins > POLL_LIMIT) {
-              failed = true;
-              if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              break;
-            }
+        if (pend) {
+          __builtin_amdgcn_s_sleep(1);
+          ++spins;
+          if ((spins & 255u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) failed = true;
+          if (spins > POLL_LIMIT) {
+            failed = true;
+            if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
       }
-      __syncthreads();
-      for (int q = wave; q < QN; q += CL_WAVES) {
-        if (q < q0 || q >= q0 + nq) {
-          u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (slot * IMG + q * 256 + lane * 4) * 4, 0, 16);  // sc1
-          *reinterpret_cast<u32x4*>(hn + q * 256 + lane * 4) = v;
-        }
-      }
-      __syncthreads();
     }
+    __syncthreads();  // next image complete (own slice + gathered peers); everyone is done reading the current one
     cur ^= 1;
   }
 }

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of individual libmgr kernels at the F-config shapes (device time via HIP events)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mgr_amd  # noqa: E402,F401
+from mgr_amd import _capi  # noqa: E402
+
+
+def timeit(dev, fn, reps=5):
+    fn()
+    dev.sync()
+    dev.record(0)
+    for _ in range(reps):
+        fn()
+    dev.record(1)
+    return dev.elapsed_ms(0, 1) / reps
+
+
+def gemm(dev, B, T, F, H, mask=True):
+    rng = np.random.default_rng(0)
+    X = dev.array(rng.standard_normal((B, T, F)).astype(np.float32))
+    Wp = dev.array(rng.standard_normal((F, 4 * H)).astype(np.float32) * 0.05)
+    bp = dev.zeros((4 * H,))
+    m = dev.array(((rng.random((4, B, F)) > 0.5) * 2.0).astype(np.float32)) if mask else 0
+    Z = dev.empty((B, T, 4 * H))
+    ms = timeit(dev, lambda: dev.call("mgr_lstm_input_proj", X, F, m, Wp, bp, Z, B, T, F, H))
+    fl = 2.0 * B * T * F * 4 * H
+    print("gemm_nn  B=%d T=%d F=%4d H=%3d mask=%d : %7.3f ms  %6.1f TF" % (B, T, F, H, mask, ms, fl / ms / 1e9))
+    dZ = Z
+    gW, gU, gb = dev.empty((F, 4 * H)), dev.empty((H, 4 * H)), dev.empty((4 * H,))
+    Y = dev.array(rng.standard_normal((B, T, H)).astype(np.float32))
+    ws = dev.bytes(dev.lib.mgr_lstm_param_grads_ws_bytes(B, T, F, H))
+    ms = timeit(dev, lambda: dev.call("mgr_lstm_param_grads", X, F, m, Y, H, dZ, gW, gU, gb, B, T, F, H, 0, ws, ws.nbytes))
+    fl = 2.0 * B * T * (F + H) * 4 * H
+    print("gemm_tn  (dW,dU,db)                       : %7.3f ms  %6.1f TF" % (ms, fl / ms / 1e9))
+    for a in (X, Wp, bp, Z, gW, gU, gb, Y, ws):
+        a.free()
+
+
+def scan(dev, B, T, H):
+    rng = np.random.default_rng(0)
+    Z = dev.array((rng.standard_normal((B, T, 4 * H)) * 0.5).astype(np.float32))
+    Up = dev.array((rng.standard_normal((H, 4 * H)) * 0.05).astype(np.float32))
+    Y, G, Cs = dev.empty((B, T, H)), dev.empty((B, T, H, 4)), dev.empty((B, T, H))
+    ws = dev.bytes(dev.lib.mgr_lstm_scan_ws_bytes(B, T, H))
+    ms = timeit(dev, lambda: dev.call("mgr_lstm_scan_fwd", Z, Up, Y, H, 0, 0, G, Cs, B, T, H, 0, ws, ws.nbytes), reps=3)
+    print("scan_fwd B=%d T=%d H=%3d : %7.3f ms  %6.2f us/step" % (B, T, H, ms, ms * 1e3 / T))
+    if H <= 128:
+        dY, dZ = Y, dev.empty((B, T, 4 * H))
+        ms = timeit(dev, lambda: dev.call("mgr_lstm_scan_bwd", dY, H, G, Cs, Up, dZ, B, T, H, 0, ws, ws.nbytes), reps=3)
+        print("scan_bwd B=%d T=%d H=%3d : %7.3f ms  %6.2f us/step" % (B, T, H, ms, ms * 1e3 / T))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="gemm,scan")
+    a = ap.parse_args()
+    dev = _capi.Device(0)
+    print(dev.name, dev.cu_count, "CUs")
+    if "gemm" in a.what:
+        gemm(dev, 64, 1900, 1000, 500)
+        gemm(dev, 64, 1900, 1000, 500, mask=False)
+        gemm(dev, 64, 1900, 600, 300)
+        gemm(dev, 64, 1900, 1600, 100)
+        gemm(dev, 64, 1900, 39, 500)
+    if "scan" in a.what:
+        scan(dev, 64, 1900, 100)
+        scan(dev, 64, 1900, 128)
+        scan(dev, 64, 1900, 300)
+        scan(dev, 64, 1900, 500)
