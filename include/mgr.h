@@ -107,8 +107,8 @@ typedef struct mgr_scan_job {
 size_t mgr_lstm_scan_multi_ws_bytes(int njobs, const mgr_scan_job* jobs);
 int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, void* ws, size_t ws_bytes);
 /* Tuning / test hooks.  key 0 (MGR_TUNE_SCAN_PATH): 0 auto, 1 force the L2-streaming fallback kernels,
- * 2 force single-CU MFMA kernels where instantiated, 3 force the cluster kernel with 4 tiles per workgroup,
- * 4 same with 8 tiles per workgroup. */
+ * 2 force one workgroup per batch group (no inter-CU exchange) where it fits, 3 force clusters with 4 tiles per
+ * workgroup, 4 same with 8 tiles per workgroup.  key 1: !=0 makes scan_fwd check the give-up word synchronously. */
 enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 4 };
 int mgr_tune(mgr_ctx* ctx, int key, int value);
 /* BPTT: dY[b,t,0:H] (row stride lddy) is dLoss/dh_t from above; Y (stride ldy) is the layer's own output as

@@ -39,6 +39,7 @@ def build(force=False, verbose=True, jobs=4):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
+    flags += os.environ.get("MGR_CXXFLAGS", "").split()  # e.g. -DMGR_STAMP for the diagnostic build
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     procs = []
     objs = []

@@ -1,7 +1,8 @@
 // C-ABI entry points of the LSTM recurrence (K3, K7-scan): pick the kernel family for each shape.
-//   H with a weight-stationary single-CU instantiation (<= 128)  -> lstm_mfma.hip
-//   H = 300 / 500 (and test sizes)                               -> lstm_cluster.hip (persistent multi-CU clusters)
-//   anything else (H <= 1024)                                    -> lstm_simple.hip (U streamed from L2; fallback)
+//   forward:  H/4 with an instantiation (H = 100, 128, 300, 500 and test sizes) -> lstm_cluster.hip: persistent
+//             weight-stationary MFMA kernel, one CU per batch group (H <= 128) or clusters of CUs exchanging h_t
+//   backward: H <= 128 -> lstm_mfma.hip (single-CU weight-stationary MFMA)
+//   anything else (H <= 1024) -> lstm_simple.hip (U streamed from L2; correctness fallback)
 #include <algorithm>
 
 #include "common.h"
@@ -9,26 +10,25 @@
 
 int mgr_scan_fwd_simple(mgr_ctx*, const float*, const float*, float*, int, const float*, int, float*, float*, int, int, int, int);
 int mgr_scan_bwd_simple(mgr_ctx*, const float*, int, const float*, const float*, const float*, float*, int, int, int, int);
-int mgr_scan_fwd_mfma(mgr_ctx*, const float*, const float*, float*, int, const float*, int, float*, float*, int, int, int, int);
 int mgr_scan_bwd_mfma(mgr_ctx*, const float*, int, const float*, const float*, const float*, float*, int, int, int, int);
 
 namespace {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-bool has_mfma_fwd(int H) { return H == 4 || H == 8 || H == 16 || H == 32 || H == 64 || H == 100 || H == 128; }
 
 struct Cfg {
   int nw, tpw;
 };
 // candidate (active waves, tiles per wave) configurations, most parallel first
-const Cfg kCfgs[3] = {{4, 1}, {8, 1}, {8, 2}};
+constexpr int NCFG = 4;
+const Cfg kCfgs[NCFG] = {{4, 1}, {8, 1}, {8, 2}, {8, 4}};
 
 struct Plan {
   bool cluster[MGR_MAX_SCAN_JOBS];
   Cfg cfg[MGR_MAX_SCAN_JOBS];
   int G[MGR_MAX_SCAN_JOBS], nbg[MGR_MAX_SCAN_JOBS], wgs[MGR_MAX_SCAN_JOBS];
   int total;
-  bool any;
+  bool any, exchange;
 };
 
 size_t job_ws(const mgr_scan_job& j) {
@@ -43,13 +43,17 @@ size_t job_ws(const mgr_scan_job& j) {
 void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
   int path = c->tune[MGR_TUNE_SCAN_PATH];
   P.any = false;
+  P.exchange = false;
   P.total = 0;
   int idx[MGR_MAX_SCAN_JOBS], n = 0;
   for (int i = 0; i < njobs; ++i) {
     int H = jobs[i].H, ks = H / 4;
-    bool ok = (H % 4 == 0) && (mgr_cluster_supported(ks, 1));
-    if (path == 1 || path == 2) ok = false;
-    if (path == 0 && has_mfma_fwd(H)) ok = false;  // single-CU kernel needs no exchange
+    bool ok = (H % 4 == 0);
+    if (ok) {
+      ok = false;
+      for (int k = 0; k < NCFG; ++k) ok = ok || mgr_cluster_supported(ks, kCfgs[k].tpw);
+    }
+    if (path == 1) ok = false;
     P.cluster[i] = ok;
     if (ok) idx[n++] = i;
   }
@@ -57,30 +61,35 @@ void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
   int best[MGR_MAX_SCAN_JOBS], cur[MGR_MAX_SCAN_JOBS];
   long best_cost = -1;
   int combos = 1;
-  for (int k = 0; k < n; ++k) combos *= 3;
+  for (int k = 0; k < n; ++k) combos *= NCFG;
   for (int code = 0; code < combos; ++code) {
     int x = code, total = 0;
     long worst = 0, sum = 0;
-    bool feas = true;
+    bool feas = true, exch = false;
     for (int k = 0; k < n; ++k) {
-      cur[k] = x % 3;
-      x /= 3;
+      cur[k] = x % NCFG;
+      x /= NCFG;
       const mgr_scan_job& j = jobs[idx[k]];
       Cfg f = kCfgs[cur[k]];
       int ks = j.H / 4;
       if (!mgr_cluster_supported(ks, f.tpw)) feas = false;
       if (path == 3 && cur[k] != 0) feas = false;
       if (path == 4 && cur[k] != 1) feas = false;
+      if (path == 2 && (f.nw * f.tpw < ks)) feas = false;  // force single-CU (no exchange)
       int tiles = f.nw * f.tpw;
       int G = (ks + tiles - 1) / tiles;
       if (G > 64) feas = false;
+      if (G > 1) exch = true;
       int nbg = (j.B + 15) / 16;
       total += G * nbg;
-      long t = (long)(f.nw / 4) * f.tpw * ks * 32 + (G > 1 ? 6000 : 0);  // MFMA cycles per SIMD + exchange estimate
+      // per-step estimate in cycles: MFMA chain per SIMD (+15% issue overhead) + cell update + exchange / barrier
+      int tiles_here = std::min(tiles, ks);
+      int per_simd = (tiles_here + 3) / 4;
+      long t = (long)per_simd * ks * 37 + 700 + (G > 1 ? 3300 : 400);
       worst = std::max(worst, t);
       sum += t;
     }
-    if (!feas || total > c->cu_count) continue;
+    if (!feas || (exch && total > c->cu_count)) continue;
     long cost = worst * 1000 + sum / n;
     if (best_cost < 0 || cost < best_cost) {
       best_cost = cost;
@@ -99,6 +108,7 @@ void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
     P.nbg[i] = (jobs[i].B + 15) / 16;
     P.wgs[i] = P.G[i] * P.nbg[i];
     P.total += P.wgs[i];
+    if (P.G[i] > 1) P.exchange = true;
   }
   P.any = true;
 }
@@ -120,11 +130,11 @@ size_t mgr_lstm_scan_ws_bytes(int B, int T, int H) {
   j.B = B;
   j.H = H;
   size_t fallback = mgr_align_up((size_t)4 * H * H * sizeof(float), 256);  // U^T for the fallback backward kernel
-  return std::max(fallback, job_ws(j) + 256);
+  return std::max(fallback, job_ws(j) + 2048);
 }
 
 size_t mgr_lstm_scan_multi_ws_bytes(int njobs, const mgr_scan_job* jobs) {
-  size_t s = 256;
+  size_t s = 2048;  // status word + diagnostic stamps
   for (int i = 0; i < njobs; ++i) s += job_ws(jobs[i]);
   return s;
 }
@@ -153,7 +163,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     char* w = reinterpret_cast<char*>(ws);
     status = reinterpret_cast<unsigned*>(w);
     char* base = w;
-    w += 256;
+    w += 2048;
     int begin = 0;
     for (int i = 0; i < njobs; ++i) {
       if (!P.cluster[i]) continue;
@@ -174,16 +184,13 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     L.status = status;
     // flags + status must be zero at every launch (epochs count from 1 within the call)
     MGR_HIP(hipMemsetAsync(base, 0, (size_t)(w - base), mgr_stream(c)));
-    r = mgr_cluster_launch(c, L, P.total);
+    r = mgr_cluster_launch(c, L, P.total, P.exchange);
     if (r) return r;
   }
   for (int i = 0; i < njobs; ++i) {
     if (P.cluster[i]) continue;
     const mgr_scan_job& j = jobs[i];
-    int path = c->tune[MGR_TUNE_SCAN_PATH];
-    r = 0;
-    if (path != 1) r = mgr_scan_fwd_mfma(c, j.Z, j.Up, j.Y, j.ldy, j.R, j.ldr, j.gates, j.cs, j.B, j.T, j.H, j.reverse);
-    if (r == 0) r = mgr_scan_fwd_simple(c, j.Z, j.Up, j.Y, j.ldy, j.R, j.ldr, j.gates, j.cs, j.B, j.T, j.H, j.reverse);
+    r = mgr_scan_fwd_simple(c, j.Z, j.Up, j.Y, j.ldy, j.R, j.ldr, j.gates, j.cs, j.B, j.T, j.H, j.reverse);
     if (r < 0) return r;
   }
   r = mgr_prof_end(c, MGR_K_SCAN_FWD);

@@ -28,4 +28,4 @@ struct ClusterLaunch {
 
 // true if (ks, tpw) has an instantiation
 bool mgr_cluster_supported(int ks, int tpw);
-int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs);
+int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool any_exchange);

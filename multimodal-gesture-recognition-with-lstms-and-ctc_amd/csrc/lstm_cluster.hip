@@ -1,28 +1,37 @@
-// K3 for large H (300, 500): persistent, weight-stationary LSTM scan spread over CLUSTERS of CUs.
+// K3: the forward LSTM recurrence - persistent, weight-stationary, on the f32 matrix cores.
 //
-// A cluster = the G workgroups (one per CU) that together hold one direction's recurrent matrix for one
-// 16-sample batch group: workgroup `ug` keeps the U^T fragments of its nw*TPW M-tiles (4 units x 4 gates each)
-// in VGPRs for all T steps.  Per time step every workgroup
-//   1. runs its MFMA chain  D[gate-col, sample] += U^T . h_{t-1}^T  (v_mfma_f32_16x16x4_f32, B operand from an LDS
-//      image of h_{t-1} laid out [k/16][k%4][sample][(k/4)%4], same as lstm_mfma.hip),
-//   2. applies the cell update in registers, writes its h_t slice into the next LDS image,
-//   3. PUBLISHES every h value the moment it is computed: a 4-byte write-through (sc1) store into the cluster's
-//      exchange slot (t&1), in the same image layout.  THE DATA IS THE FLAG: the least-significant mantissa bit of
-//      each value carries the epoch parity ((t>>1)&1)^1, which flips every time a slot word is rewritten (the
-//      local copy, Y and the recurrence all use the same 1-ulp-adjusted value, so all replicas agree bit for bit),
-//   4. GATHERS the peers' slices: each of the 8 waves sweeps its share of the image's 1 KiB blocks with 16-byte
-//      sc1 loads, accepts a block once all of its words show the expected parity, and writes it to the next LDS
-//      image; one workgroup barrier per time step.
-// This is the guide's granule hand-off (Guideline 16 R2, "the data is the flag") with a 4-byte granule: every word
-// is written by exactly one aligned store per epoch; a reader of epoch t can only ever see the word of epoch t-2
-// (opposite parity) or t, never t+2, because a producer cannot publish epoch t+2 before every peer has published
-// t+1, i.e. finished consuming t.  It needs no fence, no flag round trip and no drain, so a step costs ONE
-// store->load flight instead of three.  hipMalloc memory; one workgroup per CU (enforced by requesting > 80 KiB
-// of LDS); slots are zeroed by a memset node ahead of every launch.
-// Every spin is bounded; a give-up sets status[0] and the host reports an error instead of hanging the GPU.
+// Orientation: the MFMA computes  D[gate-col, sample] += U^T[gate-col, k] * h^T[k, sample]  with
+// v_mfma_f32_16x16x4_f32: M = 16 packed gate columns = one TILE of 4 units x (i,f,c,o), N = 16 samples (one batch
+// group), K = 4 per MFMA k-step.
+//   * A operand (U^T fragment) never changes: a wave keeps the fragments of its tiles in VGPRs for all T steps.
+//   * B operand (h_{t-1}) is read from a double-buffered LDS image laid out [k/16][k%4][sample][(k/4)%4] floats, so one
+//     ds_read_b128 feeds four consecutive k-steps conflict-free; reads run 3 blocks ahead of their MFMAs.
+//   * C/D layout: lane (sample = lane&15, unit-in-tile = lane>>4) receives the 4 gates of ITS (unit, sample) in its
+//     4 accumulator registers, so the cell update needs no cross-lane traffic.
+//   * Z[t] (gate pre-activations from the input projection) is prefetched two steps ahead through a 3-deep register
+//     ring; h_t, the activated gates and c_t stream out with fire-and-forget stores; ONE s_barrier per time step.
 //
-// Several layer-directions ("jobs": audio fwd/rev, skeletal fwd/rev) share ONE launch so that all spinning
-// workgroups are co-resident by construction (grid <= number of CUs).
+// A CLUSTER = the G workgroups (one per CU) that together hold one direction's recurrent matrix for one batch group;
+// workgroup `ug` owns tiles [ug*tpwg, (ug+1)*tpwg), dealt round-robin to its waves.  G = 1 (H <= 128) needs no
+// exchange.  For G > 1 (H = 300, 500) every step ends with an all-gather of h_t inside the cluster:
+//   PUBLISH: each h value is stored the moment it is computed - a 4-byte write-through (sc1) store into the cluster's
+//      exchange slot (t&1), same image layout.  THE DATA IS THE FLAG: the least-significant mantissa bit of each value
+//      carries the epoch parity ((t>>1)&1)^1, which flips every time a slot word is rewritten (the local copy, Y and the
+//      recurrence all use the same 1-ulp-adjusted value, so all replicas agree bit for bit).
+//   GATHER: each of the 8 waves sweeps its share of the image's 1 KiB blocks with 16-byte sc1 loads, accepts a block
+//      once all of its words show the expected parity, and writes it to the next LDS image.
+// This is the CDNA guide's granule hand-off (Guideline 16 R2, "the data is the flag") with a 4-byte granule: every
+// word is written by exactly one aligned store per epoch; a reader of epoch t can only ever see the word of epoch t-2
+// (opposite parity) or t, never t+2, because a producer cannot publish epoch t+2 before every peer has published t+1,
+// i.e. finished consuming t.  No fence, no flag round trip, no drain: a step costs ONE store->load flight.
+// hipMalloc memory; one workgroup per CU (enforced by requesting > 80 KiB of LDS); slots are zeroed by a memset node
+// ahead of every launch.  Every spin is bounded; a give-up sets status[0] and the host reports an error instead of
+// hanging the GPU.
+//
+// Several layer-directions ("jobs": audio fwd/rev, skeletal fwd/rev) share ONE launch so that all spinning workgroups
+// are co-resident by construction (grid <= number of CUs).
+#include <type_traits>
+
 #include "lstm_cluster.h"
 #include "lstm_common.h"
 
@@ -36,12 +45,13 @@ template <int KS, int TPW>
 __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float* smem, unsigned* status) {
   constexpr int H = 4 * KS, N = 4 * H, QN = (KS + 3) / 4, IMG = QN * 256;
   static_assert(QN <= 4 * CL_WAVES, "gather sweep covers at most 32 image blocks (H <= 512)");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches
   const int j = lane & 15, uq = lane >> 4;
   const int G = jb.G_;
   const int bg = wg / G, ug = wg % G;
   const int nw = jb.nw;
-  const int tiles_per_wg = nw * TPW;  // multiple of 4
+  const int tpwg = nw * TPW;  // tiles per workgroup, a multiple of 4
   const int B = jb.B, T = jb.T, reverse = jb.reverse;
   const int b = bg * 16 + j;
   const bool bvalid = b < B;
@@ -50,90 +60,148 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float*
   const float* __restrict__ Up = jb.Up;
   float* img = smem;  // [2][IMG]
 
+  // this wave's tiles: ug*tpwg + jt*nw + wave, jt < nt   (nt is wave-uniform)
+  int own = KS - ug * tpwg;
+  own = own > tpwg ? tpwg : own;
+  int nt = 0;
+  if (wave < nw) {
+    for (int jt = 0; jt < TPW; ++jt)
+      if (jt * nw + wave < own) nt = jt + 1;
+  }
+  nt = __builtin_amdgcn_readfirstlane(nt);
+
   float uf[TPW][KS];
-  bool tv[TPW];
   int tl[TPW];
 #pragma unroll
   for (int jt = 0; jt < TPW; ++jt) {
-    int tile = ug * tiles_per_wg + wave * TPW + jt;
-    tv[jt] = wave < nw && tile < KS;
-    tl[jt] = tv[jt] ? tile : 0;
+    const bool v = jt < nt;
+    tl[jt] = v ? ug * tpwg + jt * nw + wave : 0;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) uf[jt][s] = tv[jt] ? Up[(size_t)(4 * s + uq) * N + tl[jt] * 16 + j] : 0.f;
+    for (int s = 0; s < KS; ++s) uf[jt][s] = v ? Up[(size_t)(4 * s + uq) * N + tl[jt] * 16 + j] : 0.f;
   }
   for (int i = tid; i < 2 * IMG; i += CL_WAVES * 64) img[i] = 0.f;
 
-  const int q0 = (ug * tiles_per_wg) >> 2, nq = tiles_per_wg >> 2;  // own 1 KiB blocks of the image
+  const int q0 = (ug * tpwg) >> 2, nq = tpwg >> 2;  // own 1 KiB blocks of the image
   float* xb = jb.xbuf + (size_t)bg * 2 * IMG;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, 2 * IMG * 4, 0x00020000);
 
   float c[TPW];
-  f32x4 zc[TPW], zn[TPW];
-  auto loadz = [&](f32x4 (&z)[TPW], int t) {
 #pragma unroll
-    for (int jt = 0; jt < TPW; ++jt)
-      if (tv[jt]) z[jt] = *reinterpret_cast<const f32x4*>(Z + ((size_t)bc * T + t) * N + (tl[jt] * 4 + uq) * 4);
+  for (int jt = 0; jt < TPW; ++jt) c[jt] = 0.f;
+  // Z ring: step s uses ring[s % 3]; the load for step s+2 is issued at step s
+  f32x4 zr0[TPW], zr1[TPW], zr2[TPW];
+  auto loadz = [&](f32x4 (&z)[TPW], int step) {
+    if (step < T) {
+      const int t = reverse ? T - 1 - step : step;
+#pragma unroll
+      for (int jt = 0; jt < TPW; ++jt)
+        if (jt < nt) z[jt] = *reinterpret_cast<const f32x4*>(Z + ((size_t)bc * T + t) * N + (tl[jt] * 4 + uq) * 4);
+    }
   };
 #pragma unroll
   for (int jt = 0; jt < TPW; ++jt) {
-    c[jt] = 0.f;
-    zc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    zn[jt] = zc[jt];
+    zr0[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    zr1[jt] = zr0[jt];
+    zr2[jt] = zr0[jt];
   }
-  loadz(zc, reverse ? T - 1 : 0);
+  loadz(zr0, 0);
+  loadz(zr1, 1);
   bool failed = false;
   __syncthreads();
   int cur = 0;
-  for (int step = 0; step < T; ++step) {
+#ifdef MGR_STAMP
+  unsigned long long st_mfma = 0, st_cell = 0, st_gather = 0, st_bar = 0, st_passes = 0;
+#define STAMP(x) unsigned long long x = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0)
+#else
+#define STAMP(x)
+#endif
+
+  // the MFMA chain of one step, specialised on the number of tiles this wave really owns
+  auto mfma_phase = [&](auto ntc, f32x4 (&acc)[TPW], const float* hb) {
+    constexpr int NT = decltype(ntc)::value;
+    if constexpr (NT > 0) {
+      constexpr int PD = 3;
+      f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+      f32x4 hbuf[4];
+      const float* hlane = hb + (uq * 16 + j) * 4;
+#pragma unroll
+      for (int q = 0; q < PD && q < QN; ++q) hbuf[q] = *reinterpret_cast<const f32x4*>(hlane + q * 256);
+#pragma unroll
+      for (int q = 0; q < QN; ++q) {
+        // B-operand reads run PD blocks ahead of their MFMAs (sched_barrier pins the order; left alone, hipcc sinks
+        // each ds_read next to its use and the LDS latency shows between MFMA groups)
+        if (q + PD < QN) hbuf[(q + PD) & 3] = *reinterpret_cast<const f32x4*>(hlane + (q + PD) * 256);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 hv = hbuf[q & 3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (4 * q + r < KS) {
+            if (NT == 1 && (r & 1)) {  // one tile: two accumulators hide the 40-cycle dependent-MFMA latency
+              acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[0][4 * q + r], hv[r], acc2, 0, 0, 0);
+            } else {
+#pragma unroll
+              for (int jt = 0; jt < NT; ++jt)
+                acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[jt][4 * q + r], hv[r], acc[jt], 0, 0, 0);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (NT == 1) acc[0] += acc2;
+    }
+  };
+
+  auto do_step = [&](int step, f32x4 (&zuse)[TPW], f32x4 (&zload)[TPW]) {
     const int t = reverse ? T - 1 - step : step;
-    if (step + 1 < T) loadz(zn, reverse ? t - 1 : t + 1);
+    loadz(zload, step + 2);
     f32x4 acc[TPW];
 #pragma unroll
-    for (int jt = 0; jt < TPW; ++jt) acc[jt] = zc[jt];
+    for (int jt = 0; jt < TPW; ++jt) acc[jt] = zuse[jt];
     const float* hb = img + cur * IMG;
     float* hn = img + (cur ^ 1) * IMG;
     const int slot = step & 1;
     const unsigned par = (((unsigned)step >> 1) & 1u) ^ 1u;
-    if (wave < nw) {
+    STAMP(s0);
+    // wave-uniform dispatch on the owned tile count (scalar branches): no per-MFMA exec masking
+    if (nt == 1) {
+      mfma_phase(std::integral_constant<int, 1>{}, acc, hb);
+    } else if (nt == 2) {
+      if constexpr (TPW >= 2) mfma_phase(std::integral_constant<int, 2>{}, acc, hb);
+    } else if (nt == 3) {
+      if constexpr (TPW >= 3) mfma_phase(std::integral_constant<int, 3>{}, acc, hb);
+    } else if (nt == 4) {
+      if constexpr (TPW >= 4) mfma_phase(std::integral_constant<int, 4>{}, acc, hb);
+    }
+#ifdef MGR_STAMP
+    asm volatile("" ::"v"(acc[0][0]));
+#endif
+    STAMP(s1);
 #pragma unroll
-      for (int q = 0; q < QN; ++q) {
-        f32x4 hv = *reinterpret_cast<const f32x4*>(hb + ((q * 4 + uq) * 16 + j) * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (4 * q + r < KS) {
-#pragma unroll
-            for (int jt = 0; jt < TPW; ++jt)
-              if (tv[jt]) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[jt][4 * q + r], hv[r], acc[jt], 0, 0, 0);
-          }
+    for (int jt = 0; jt < TPW; ++jt) {
+      if (jt < nt) {
+        const int tile = tl[jt];
+        const int unit = tile * 4 + uq;
+        float4 g4;
+        float h = mgr_cell_fwd(acc[jt][0], acc[jt][1], acc[jt][2], acc[jt][3], c[jt], g4);
+        // unit k = 4*tile + uq -> k-step s = tile, kk = uq -> image [q = tile>>2][kk = uq][j][r = tile&3]
+        const int idx = (((tile >> 2) * 4 + uq) * 16 + j) * 4 + (tile & 3);
+        if (G > 1) {
+          const unsigned hbits = (__float_as_uint(h) & ~1u) | par;  // epoch parity rides in the mantissa LSB
+          h = __uint_as_float(hbits);
+          if (step + 1 < T) __builtin_amdgcn_raw_buffer_store_b32(hbits, rs, (slot * IMG + idx) * 4, 0, 16);  // sc1
         }
-      }
-#pragma unroll
-      for (int jt = 0; jt < TPW; ++jt) {
-        if (tv[jt]) {
-          const int tile = tl[jt];
-          const int unit = tile * 4 + uq;
-          float4 g4;
-          float h = mgr_cell_fwd(acc[jt][0], acc[jt][1], acc[jt][2], acc[jt][3], c[jt], g4);
-          const int idx = (((tile >> 2) * 4 + uq) * 16 + j) * 4 + (tile & 3);
-          if (G > 1) {
-            const unsigned hbits = (__float_as_uint(h) & ~1u) | par;  // epoch parity rides in the mantissa LSB
-            h = __uint_as_float(hbits);
-            if (step + 1 < T) __builtin_amdgcn_raw_buffer_store_b32(hbits, rs, (slot * IMG + idx) * 4, 0, 16);  // sc1
-          }
-          hn[idx] = h;
-          if (bvalid) {
-            size_t row = (size_t)b * T + t;
-            float yo = h;
-            if (jb.R) yo += jb.R[row * jb.ldr + unit];
-            jb.Y[row * jb.ldy + unit] = yo;
-            if (jb.G) *reinterpret_cast<float4*>(jb.G + (row * H + unit) * 4) = g4;
-            if (jb.Cs) jb.Cs[row * H + unit] = c[jt];
-          }
+        hn[idx] = h;
+        if (bvalid) {
+          size_t row = (size_t)b * T + t;
+          float yo = h;
+          if (jb.R) yo += jb.R[row * jb.ldr + unit];
+          jb.Y[row * jb.ldy + unit] = yo;
+          if (jb.G) *reinterpret_cast<float4*>(jb.G + (row * H + unit) * 4) = g4;
+          if (jb.Cs) jb.Cs[row * H + unit] = c[jt];
         }
       }
     }
-#pragma unroll
-    for (int jt = 0; jt < TPW; ++jt) zc[jt] = zn[jt];
+    STAMP(s2);
     if (G > 1 && step + 1 < T) {
       // gather: wave w sweeps blocks w, w+8, w+16, w+24 of the exchange slot until every word has this epoch's parity
       u32x4 v[4];
@@ -172,6 +240,9 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float*
             }
           }
         }
+#ifdef MGR_STAMP
+        st_passes += 1;
+#endif
         if (pend) {
           __builtin_amdgcn_s_sleep(1);
           ++spins;
@@ -183,10 +254,36 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float*
         }
       }
     }
+    STAMP(s3);
     __syncthreads();  // next image complete (own slice + gathered peers); everyone is done reading the current one
+#ifdef MGR_STAMP
+    {
+      STAMP(s4);
+      st_mfma += s1 - s0;
+      st_cell += s2 - s0;  // whole compute phase incl. MFMA
+      st_gather += s3 - s2;
+      st_bar += s4 - s3;
+    }
+#endif
     cur ^= 1;
+  };
+
+  for (int s0 = 0; s0 < T; s0 += 3) {
+    do_step(s0, zr0, zr2);
+    if (s0 + 1 < T) do_step(s0 + 1, zr1, zr0);
+    if (s0 + 2 < T) do_step(s0 + 2, zr2, zr1);
   }
+#ifdef MGR_STAMP
+  if (lane == 0 && wg < 2) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(status + 16) + (wg * CL_WAVES + wave) * 8;
+    dbg[0] = st_mfma; dbg[1] = st_cell; dbg[2] = st_gather; dbg[3] = st_bar; dbg[4] = st_passes;
+  }
+#endif
 }
+
+#define CL_FOREACH(X) \
+  X(125, 1) X(75, 1) X(75, 2) X(32, 1) X(32, 2) X(32, 4) X(25, 1) X(25, 2) X(25, 4) X(16, 1) X(16, 2) X(8, 1) X(8, 2) \
+  X(4, 1) X(3, 1) X(2, 1) X(1, 1)
 
 __global__ __launch_bounds__(CL_WAVES * 64) void k_scan_cluster(ClusterLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -199,37 +296,30 @@ __global__ __launch_bounds__(CL_WAVES * 64) void k_scan_cluster(ClusterLaunch L)
   if (wg >= jb.G_ * jb.nbg) return;
 #define CL_CASE(KS, TPW) \
   if (jb.ks == KS && jb.tpw == TPW) return cluster_run<KS, TPW>(jb, wg, smem, L.status);
-  CL_CASE(125, 1)
-  CL_CASE(75, 1)
-  CL_CASE(75, 2)
-  CL_CASE(32, 1)
-  CL_CASE(32, 2)
-  CL_CASE(25, 1)
-  CL_CASE(25, 2)
-  CL_CASE(8, 1)
-  CL_CASE(8, 2)
-  CL_CASE(3, 1)
+  CL_FOREACH(CL_CASE)
 #undef CL_CASE
 }
 
 }  // namespace
 
 bool mgr_cluster_supported(int ks, int tpw) {
-  switch (ks) {
-    case 125: return tpw == 1;
-    case 3: return tpw == 1;
-    case 75: case 32: case 25: case 8: return tpw == 1 || tpw == 2;
-    default: return false;
-  }
+#define CL_CASE(KS, TPW) \
+  if (ks == KS && tpw == TPW) return true;
+  CL_FOREACH(CL_CASE)
+#undef CL_CASE
+  return false;
 }
 
-int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs) {
+int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool any_exchange) {
   int maxks = 0;
   for (int i = 0; i < L.njobs; ++i) maxks = L.job[i].ks > maxks ? L.job[i].ks : maxks;
   size_t img = (size_t)((maxks + 3) / 4) * 256 * sizeof(float);
   size_t lds = 2 * img;
-  if (lds < 84 * 1024) lds = 84 * 1024;  // > half of the 160 KiB LDS: at most one workgroup per CU
-  MGR_REQUIRE(total_wgs <= c->cu_count, "cluster scan needs %d co-resident workgroups but the device has %d CUs", total_wgs, c->cu_count);
+  if (any_exchange) {
+    if (lds < 84 * 1024) lds = 84 * 1024;  // > half of the 160 KiB LDS: at most one workgroup per CU
+    MGR_REQUIRE(total_wgs <= c->cu_count, "cluster scan needs %d co-resident workgroups but the device has %d CUs", total_wgs,
+                c->cu_count);
+  }
   static bool attr_set = false;
   if (!attr_set) {
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -1,115 +1,13 @@
-// K3 / K7-scan: weight-stationary LSTM recurrence on the f32 matrix cores, one workgroup per
-// (direction, 16-sample batch group), for layers whose recurrent matrix fits one CU's register file (H <= 128).
-//
-// Orientation: the MFMA computes  D[gate-col, sample] += U^T[gate-col, k] * h^T[k, sample]  with
-// v_mfma_f32_16x16x4_f32, M = 16 packed gate columns = 4 units x (i,f,c,o), N = 16 samples, K = 4 per step.
-//   * A operand (U^T fragment) never changes: each wave keeps its tiles' fragments in VGPRs for all T steps.
-//   * B operand (h_{t-1}) is read from a double-buffered LDS image laid out [k/16][k%4][sample][(k/4)%4] so one
-//     ds_read_b128 feeds four consecutive MFMA k-steps, conflict-free.
-//   * C/D layout: lane (sample = lane&15, unit-in-tile = lane>>4) receives the 4 gates of ITS (unit, sample)
-//     in its 4 accumulator registers, so the cell update needs no cross-lane traffic at all.
-// Z[t] (gate pre-activations from the input projection) is prefetched one step ahead; h_t, the activated gates
-// and c_t stream out with fire-and-forget stores; one s_barrier per time step.
-//
-// The backward kernel mirrors it with  D[unit, sample] += U[unit, gate-col] * dz^T[gate-col, sample].
+// K7-scan: BPTT of one LSTM direction, weight-stationary on the f32 matrix cores, one workgroup per 16-sample
+// batch group, for layers whose recurrent matrix fits one CU's register file (H <= 128; the trainable fusion layer).
+// It mirrors the forward kernel (lstm_cluster.hip) with  D[unit, sample] += U[unit, gate-col] * dz^T[gate-col, sample]:
+// A operand = U rows (stationary in VGPRs), B operand = dz_t from a double-buffered LDS image
+// [gate-col/16][gate][sample][unit%4], C/D = dh_rec for 4 consecutive units of the lane's sample.
 #include "lstm_common.h"
 
 namespace {
 
 constexpr int NW = 8;  // waves per workgroup (2 per SIMD)
-
-template <int KS, int TPW>
-__global__ __launch_bounds__(NW * 64) void k_scan_fwd_mfma(const float* __restrict__ Z, const float* __restrict__ Up,
-                                                           float* __restrict__ Y, int ldy, const float* __restrict__ R,
-                                                           int ldr, float* __restrict__ G, float* __restrict__ Cs, int B,
-                                                           int T, int reverse) {
-  constexpr int H = 4 * KS;
-  constexpr int N = 4 * H;
-  constexpr int MT = KS;  // M tiles of 4 units
-  constexpr int QN = (KS + 3) / 4;
-  constexpr int HS = QN * 4 * 16 * 4;  // floats per h image
-  __shared__ __attribute__((aligned(16))) float hs[2 * HS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j = lane & 15, uq = lane >> 4;
-  const int b0 = blockIdx.x * 16;
-  const int b = b0 + j;
-  const bool bvalid = b < B;
-  const int bc = bvalid ? b : B - 1;
-
-  float uf[TPW][KS];
-  bool tv[TPW];
-#pragma unroll
-  for (int jt = 0; jt < TPW; ++jt) {
-    int tile = wave + jt * NW;
-    tv[jt] = tile < MT;
-    int tl = tv[jt] ? tile : 0;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) uf[jt][s] = tv[jt] ? Up[(size_t)(4 * s + uq) * N + tl * 16 + j] : 0.f;
-  }
-  for (int i = tid; i < 2 * HS; i += NW * 64) hs[i] = 0.f;
-  float c[TPW];
-  f32x4 zc[TPW], zn[TPW];
-  auto loadz = [&](f32x4 (&z)[TPW], int t) {
-#pragma unroll
-    for (int jt = 0; jt < TPW; ++jt) {
-      int tile = wave + jt * NW;
-      if (tv[jt]) z[jt] = *reinterpret_cast<const f32x4*>(Z + ((size_t)bc * T + t) * N + (tile * 4 + uq) * 4);
-    }
-  };
-#pragma unroll
-  for (int jt = 0; jt < TPW; ++jt) {
-    c[jt] = 0.f;
-    zc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    zn[jt] = zc[jt];
-  }
-  loadz(zc, reverse ? T - 1 : 0);
-  __syncthreads();
-  int cur = 0;
-  for (int step = 0; step < T; ++step) {
-    const int t = reverse ? T - 1 - step : step;
-    if (step + 1 < T) loadz(zn, reverse ? t - 1 : t + 1);
-    f32x4 acc[TPW];
-#pragma unroll
-    for (int jt = 0; jt < TPW; ++jt) acc[jt] = zc[jt];
-    const float* hb = hs + cur * HS;
-#pragma unroll
-    for (int q = 0; q < QN; ++q) {
-      f32x4 hv = *reinterpret_cast<const f32x4*>(hb + ((q * 4 + uq) * 16 + j) * 4);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (4 * q + r < KS) {
-#pragma unroll
-          for (int jt = 0; jt < TPW; ++jt)
-            if (tv[jt]) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[jt][4 * q + r], hv[r], acc[jt], 0, 0, 0);
-        }
-      }
-    }
-    float* hn = hs + (cur ^ 1) * HS;
-#pragma unroll
-    for (int jt = 0; jt < TPW; ++jt) {
-      if (tv[jt]) {
-        int tile = wave + jt * NW;
-        int unit = tile * 4 + uq;
-        float4 g4;
-        float h = mgr_cell_fwd(acc[jt][0], acc[jt][1], acc[jt][2], acc[jt][3], c[jt], g4);
-        // unit k = 4*tile + uq  ->  k-step s = tile, kk = uq  ->  image [q = tile>>2][kk = uq][j][r = tile&3]
-        hn[(((tile >> 2) * 4 + uq) * 16 + j) * 4 + (tile & 3)] = h;
-        if (bvalid) {
-          size_t row = (size_t)b * T + t;
-          float yo = h;
-          if (R) yo += R[row * ldr + unit];
-          Y[row * ldy + unit] = yo;
-          if (G) *reinterpret_cast<float4*>(G + (row * H + unit) * 4) = g4;
-          if (Cs) Cs[row * H + unit] = c[jt];
-        }
-      }
-    }
-#pragma unroll
-    for (int jt = 0; jt < TPW; ++jt) zc[jt] = zn[jt];
-    __syncthreads();
-    cur ^= 1;
-  }
-}
 
 // Backward.  H units -> MTB = ceil(H/16) tiles of 16 units, one tile per wave; K = 4H packed gate columns,
 // i.e. H MFMA k-steps (k-step s = unit s, kk = gate).
@@ -124,7 +22,8 @@ __global__ __launch_bounds__(NW * 64) void k_scan_bwd_mfma(const float* __restri
   constexpr int DS = QN * 4 * 16 * 4;
   static_assert(MTB <= NW, "H too large for the single-CU backward kernel");
   __shared__ __attribute__((aligned(16))) float dzs[2 * DS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
   const int j = lane & 15, uq = lane >> 4;
   const int b0 = blockIdx.x * 16;
   const int b = b0 + j;
@@ -182,9 +81,16 @@ __global__ __launch_bounds__(NW * 64) void k_scan_bwd_mfma(const float* __restri
     if (tvalid && has_prev) {
       const float* db = dzs + cur * DS;
       f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+      constexpr int PD = 3;
+      f32x4 dbuf[4];
+      const float* dlane = db + (uq * 16 + j) * 4;
+#pragma unroll
+      for (int q = 0; q < PD && q < QN; ++q) dbuf[q] = *reinterpret_cast<const f32x4*>(dlane + q * 256);
 #pragma unroll
       for (int q = 0; q < QN; ++q) {
-        f32x4 dv = *reinterpret_cast<const f32x4*>(db + ((q * 4 + uq) * 16 + j) * 4);
+        if (q + PD < QN) dbuf[(q + PD) & 3] = *reinterpret_cast<const f32x4*>(dlane + (q + PD) * 256);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 dv = dbuf[q & 3];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (4 * q + r < H) {
@@ -194,6 +100,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_bwd_mfma(const float* __restri
               a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[4 * q + r], dv[r], a0, 0, 0, 0);
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
       dhr = a0 + a1;
     }
@@ -203,30 +110,6 @@ __global__ __launch_bounds__(NW * 64) void k_scan_bwd_mfma(const float* __restri
 }  // namespace
 
 // returns 1 if launched, 0 if the shape has no instantiation, <0 on error
-int mgr_scan_fwd_mfma(mgr_ctx* c, const float* Z, const float* Up, float* Y, int ldy, const float* R, int ldr, float* G,
-                      float* Cs, int B, int T, int H, int reverse) {
-  int grid = (B + 15) / 16;
-  hipStream_t s = mgr_stream(c);
-#define FWD_CASE(KS, TPW)                                                                                                  \
-  case 4 * KS:                                                                                                             \
-    hipLaunchKernelGGL((k_scan_fwd_mfma<KS, TPW>), dim3(grid), dim3(NW * 64), 0, s, Z, Up, Y, ldy, R, ldr, G, Cs, B, T, reverse); \
-    break;
-  switch (H) {
-    FWD_CASE(1, 1)
-    FWD_CASE(2, 1)
-    FWD_CASE(4, 1)
-    FWD_CASE(8, 1)
-    FWD_CASE(16, 2)
-    FWD_CASE(25, 4)
-    FWD_CASE(32, 4)
-    default:
-      return 0;
-  }
-#undef FWD_CASE
-  MGR_LAUNCH_CHECK();
-  return 1;
-}
-
 int mgr_scan_bwd_mfma(mgr_ctx* c, const float* dY, int lddy, const float* G, const float* Cs, const float* Up, float* dZ, int B,
                       int T, int H, int reverse) {
   int grid = (B + 15) / 16;

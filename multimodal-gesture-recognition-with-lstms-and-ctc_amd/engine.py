@@ -332,6 +332,7 @@ class Engine:
         if sp.fusion:
             Hf = sp.fusion["H"]
             dev.wait(1, 0)
+            jobs = []
             for di, (dname, st) in enumerate((("fwd", 0), ("bwd", 1))):
                 L = self.dirs["fusion/%s" % dname]
                 dev.stream(st)
@@ -339,12 +340,12 @@ class Engine:
                 mptr = self._prep_mask(L, train, rand, slot)
                 self._masks[(L.prefix, L.d)] = mptr
                 dev.call("mgr_lstm_input_proj", self.FEAT, W, mptr, L.Wp, L.bp, self.ZF[di], B, T, W, Hf)
-                g = L.gates if save else 0
-                cs = L.cs if save else 0
-                dev.call("mgr_lstm_scan_fwd", self.ZF[di], L.Up, self.YF.view(di * Hf, (1,)), 2 * Hf, 0, 0, g, cs,
-                         B, T, Hf, L.reverse, 0, 0)
+                jobs.append(dict(Z=self.ZF[di], Up=L.Up, Y=self.YF.view(di * Hf, (1,)), ldy=2 * Hf, R=0, ldr=0,
+                                 gates=L.gates if save else 0, cs=L.cs if save else 0, B=B, T=T, H=Hf,
+                                 reverse=L.reverse))
             dev.stream(0)
             dev.wait(0, 1)
+            self._scan_multi(jobs)
             feat, ldf = self.YF, 2 * Hf
         # head
         D, Cn = sp.head_width, sp.num_classes

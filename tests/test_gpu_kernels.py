@@ -157,7 +157,7 @@ def test_lstm_direction_fwd_bwd(device, B, T, F, H, p, reverse):
     Z = dev.empty((B, T, 4 * H))
     dev.call("mgr_lstm_input_proj", dX, F, dmask, Wp, bp, Z, B, T, F, H)
     Y, G, Cs = dev.empty((B, T, H)), dev.empty((B, T, H, 4)), dev.empty((B, T, H))
-    dev.call("mgr_lstm_scan_fwd", Z, Up, Y, H, 0, 0, G, Cs, B, T, H, reverse, 0, 0)
+    ws0 = dev.bytes(dev.lib.mgr_lstm_scan_ws_bytes(B, T, H)); dev.call("mgr_lstm_scan_fwd", Z, Up, Y, H, 0, 0, G, Cs, B, T, H, reverse, ws0, ws0.nbytes)
     y = Y.download()
     assert rel_err(y, y_ref) < 2e-5, rel_err(y, y_ref)
     assert rel_err(Cs.download(), cache["c"]) < 2e-5
@@ -202,7 +202,7 @@ def test_scan_residual_and_strides(device):
     ld = 3 * H + 4
     OUT = dev.zeros((B, T, ld))
     dR = dev.array(R)
-    dev.call("mgr_lstm_scan_fwd", Z, Up, OUT.view(H, (1,)), ld, dR.view(H, (1,)), 2 * H, 0, 0, B, T, H, 0, 0, 0)
+    ws0 = dev.bytes(dev.lib.mgr_lstm_scan_ws_bytes(B, T, H)); dev.call("mgr_lstm_scan_fwd", Z, Up, OUT.view(H, (1,)), ld, dR.view(H, (1,)), 2 * H, 0, 0, B, T, H, 0, ws0, ws0.nbytes)
     out = OUT.download()
     assert rel_err(out[:, :, H:2 * H], y_ref + R[:, :, H:]) < 2e-5
     assert np.all(out[:, :, :H] == 0) and np.all(out[:, :, 2 * H:] == 0)
@@ -276,6 +276,33 @@ def test_cluster_scan_matches_oracle(device, B, T, H, path):
                 assert rel_err(Y.download(), y_ref) < 3e-5
                 assert rel_err(Cs.download(), cache["c"]) < 3e-5
                 assert rel_err(G.download()[..., 3], cache["o"]) < 3e-5
+    finally:
+        dev.call("mgr_tune", 0, 0)
+        dev.call("mgr_tune", 1, 0)
+
+
+@pytest.mark.parametrize("path", [1, 2, 3])
+def test_scan_paths_agree(device, path):
+    """fallback (1), single-CU (2) and 4-tile clusters (3) give the same recurrence (tolerance: fp32 summation order)."""
+    dev = device
+    rng = np.random.default_rng(11)
+    B, T, F, H = 19, 11, 7, 100
+    x, W, U, b, _ = _lstm_case(rng, B, T, F, H, 0.0)
+    y_ref, _ = kr.lstm_forward(x, W, U, b, None, True)
+    f32 = np.float32
+    Wp, Up, bp = dev.empty((F, 4 * H)), dev.empty((H, 4 * H)), dev.empty((4 * H,))
+    dev.call("mgr_lstm_pack", dev.array(W.astype(f32)), Wp, F, H, 0)
+    dev.call("mgr_lstm_pack", dev.array(U.astype(f32)), Up, H, H, 0)
+    dev.call("mgr_lstm_pack", dev.array(b.astype(f32)), bp, 1, H, 0)
+    Z = dev.empty((B, T, 4 * H))
+    dev.call("mgr_lstm_input_proj", dev.array(x.astype(f32)), F, 0, Wp, bp, Z, B, T, F, H)
+    Y = dev.zeros((B, T, H))
+    ws = dev.bytes(dev.lib.mgr_lstm_scan_ws_bytes(B, T, H))
+    dev.call("mgr_tune", 0, path)
+    dev.call("mgr_tune", 1, 1)
+    try:
+        dev.call("mgr_lstm_scan_fwd", Z, Up, Y, H, 0, 0, 0, 0, B, T, H, 1, ws, ws.nbytes)
+        assert rel_err(Y.download(), y_ref) < 3e-5
     finally:
         dev.call("mgr_tune", 0, 0)
         dev.call("mgr_tune", 1, 0)
