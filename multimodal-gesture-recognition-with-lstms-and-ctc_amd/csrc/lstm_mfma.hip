@@ -44,41 +44,60 @@ __global__ __launch_bounds__(NW * 64) void k_scan_bwd_mfma(const float* __restri
   for (int i = tid; i < 2 * DS; i += NW * 64) dzs[i] = 0.f;
   float dcc[4] = {0.f, 0.f, 0.f, 0.f};
   f32x4 dhr = {0.f, 0.f, 0.f, 0.f};
+  const bool lv = tvalid && u0 < H;  // H % 4 == 0: a lane's 4 units are valid together
+
+  // Saved forward state and dY of one time step for this lane's 4 units.  Iteration k (= T-1-n) uses ring[k % 3];
+  // the loads for iteration k+2 are issued at iteration k, so c_{t-1} (= the c of iteration k+1) has already landed.
+  struct Saved {
+    float dy[4];
+    float4 g[4];
+    f32x4 c;
+  };
+  Saved r0, r1, r2;
+  auto load = [&](Saved& sv, int k) {
+    if (lv && k < T) {
+      const int n = T - 1 - k;
+      const int t = reverse ? T - 1 - n : n;
+      const size_t row = (size_t)bc * T + t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sv.dy[e] = dY[row * lddy + u0 + e];
+        sv.g[e] = *reinterpret_cast<const float4*>(G + (row * H + u0 + e) * 4);
+      }
+      sv.c = *reinterpret_cast<const f32x4*>(Cs + row * H + u0);
+    }
+  };
+  load(r0, 0);
+  load(r1, 1);
   __syncthreads();
   int cur = 0;
-  for (int n = T - 1; n >= 0; --n) {
+
+  auto do_step = [&](int k, Saved& use, Saved& prev, Saved& ld) {
+    const int n = T - 1 - k;
     const int t = reverse ? T - 1 - n : n;
-    const int tp = reverse ? t + 1 : t - 1;
     const bool has_prev = n > 0;
+    load(ld, k + 2);
     float* dn = dzs + (cur ^ 1) * DS;
-    if (tvalid) {
-      size_t row = (size_t)bc * T + t;
+    if (lv) {
+      const size_t row = (size_t)bc * T + t;
       float4 dz[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        int u = u0 + e;
-        dz[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (u < H) {
-          float dh = dY[row * lddy + u] + dhr[e];
-          float4 g4 = *reinterpret_cast<const float4*>(G + (row * H + u) * 4);
-          float cc = Cs[row * H + u];
-          float cp = has_prev ? Cs[((size_t)bc * T + tp) * H + u] : 0.f;
-          dz[e] = mgr_cell_bwd(dh, g4, cc, cp, dcc[e]);
-          if (bvalid) *reinterpret_cast<float4*>(dZ + row * N + u * 4) = dz[e];
-        }
+        float dh = use.dy[e] + dhr[e];
+        float cp = has_prev ? prev.c[e] : 0.f;
+        dz[e] = mgr_cell_bwd(dh, use.g[e], use.c[e], cp, dcc[e]);
+        if (bvalid) *reinterpret_cast<float4*>(dZ + row * N + (u0 + e) * 4) = dz[e];
       }
       // image [q = unit>>2][kk = gate][j][r = unit&3]; this lane's units u0..u0+3 share q = u0>>2
       const int q = u0 >> 2;
-      if (q < QN) {
-        *reinterpret_cast<f32x4*>(dn + ((q * 4 + 0) * 16 + j) * 4) = (f32x4){dz[0].x, dz[1].x, dz[2].x, dz[3].x};
-        *reinterpret_cast<f32x4*>(dn + ((q * 4 + 1) * 16 + j) * 4) = (f32x4){dz[0].y, dz[1].y, dz[2].y, dz[3].y};
-        *reinterpret_cast<f32x4*>(dn + ((q * 4 + 2) * 16 + j) * 4) = (f32x4){dz[0].z, dz[1].z, dz[2].z, dz[3].z};
-        *reinterpret_cast<f32x4*>(dn + ((q * 4 + 3) * 16 + j) * 4) = (f32x4){dz[0].w, dz[1].w, dz[2].w, dz[3].w};
-      }
+      *reinterpret_cast<f32x4*>(dn + ((q * 4 + 0) * 16 + j) * 4) = (f32x4){dz[0].x, dz[1].x, dz[2].x, dz[3].x};
+      *reinterpret_cast<f32x4*>(dn + ((q * 4 + 1) * 16 + j) * 4) = (f32x4){dz[0].y, dz[1].y, dz[2].y, dz[3].y};
+      *reinterpret_cast<f32x4*>(dn + ((q * 4 + 2) * 16 + j) * 4) = (f32x4){dz[0].z, dz[1].z, dz[2].z, dz[3].z};
+      *reinterpret_cast<f32x4*>(dn + ((q * 4 + 3) * 16 + j) * 4) = (f32x4){dz[0].w, dz[1].w, dz[2].w, dz[3].w};
     }
     __syncthreads();
     cur ^= 1;
-    if (tvalid && has_prev) {
+    if (tvalid && has_prev) {  // wave-uniform
       const float* db = dzs + cur * DS;
       f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
       constexpr int PD = 3;
@@ -104,6 +123,12 @@ __global__ __launch_bounds__(NW * 64) void k_scan_bwd_mfma(const float* __restri
       }
       dhr = a0 + a1;
     }
+  };
+
+  for (int k0 = 0; k0 < T; k0 += 3) {
+    do_step(k0, r0, r1, r2);
+    if (k0 + 1 < T) do_step(k0 + 1, r1, r2, r0);
+    if (k0 + 2 < T) do_step(k0 + 2, r2, r0, r1);
   }
 }
 
