@@ -16,19 +16,26 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16, LDS_LD = BM + 4;
+#ifndef MGR_GEMM_BK
+#define MGR_GEMM_BK 16
+#endif
+#ifndef MGR_GEMM_NBUF
+#define MGR_GEMM_NBUF 2
+#endif
+constexpr int BM = 128, BN = 128, BK = MGR_GEMM_BK, NBUF = MGR_GEMM_NBUF, LDS_LD = BM + 4;
+constexpr int LPT = BK / 8;  // float4 loads per thread per operand per stage (256 threads)
 
 // element (m,k) at base[m*ld + k]  ("k-contiguous"); thread handles 2 float4 along k
 struct RegTile {
-  float v[8];
+  float v[4 * LPT];
 };
 
 __device__ __forceinline__ void load_kc(RegTile& r, const float* __restrict__ base, size_t ld, int m0, int k0, int Mlim,
                                         int Klim, bool vec, int tid) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < LPT; ++i) {
     int idx4 = tid + i * 256;
-    int m = idx4 >> 2, k4 = (idx4 & 3) * 4;
+    int m = idx4 / (BK / 4), k4 = (idx4 % (BK / 4)) * 4;
     int gm = m0 + m, gk = k0 + k4;
     const float* p = base + (size_t)gm * ld + gk;
     if (vec && gm < Mlim && gk + 3 < Klim) {
@@ -45,9 +52,9 @@ __device__ __forceinline__ void load_kc(RegTile& r, const float* __restrict__ ba
 }
 __device__ __forceinline__ void store_kc(float (*S)[LDS_LD], const RegTile& r, int tid) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < LPT; ++i) {
     int idx4 = tid + i * 256;
-    int m = idx4 >> 2, k4 = (idx4 & 3) * 4;
+    int m = idx4 / (BK / 4), k4 = (idx4 % (BK / 4)) * 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) S[k4 + e][m] = r.v[i * 4 + e];
   }
@@ -57,7 +64,7 @@ __device__ __forceinline__ void store_kc(float (*S)[LDS_LD], const RegTile& r, i
 __device__ __forceinline__ void load_mc(RegTile& r, const float* __restrict__ base, size_t ld, int m0, int k0, int Mlim,
                                         int Klim, bool vec, int tid, int kshift = 0) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < LPT; ++i) {
     int idx4 = tid + i * 256;
     int k = idx4 >> 5, m4 = (idx4 & 31) * 4;
     int gm = m0 + m4, gk = k0 + k + kshift;
@@ -77,10 +84,43 @@ __device__ __forceinline__ void load_mc(RegTile& r, const float* __restrict__ ba
 }
 __device__ __forceinline__ void store_mc(float (*S)[LDS_LD], const RegTile& r, int tid) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < LPT; ++i) {
     int idx4 = tid + i * 256;
     int k = idx4 >> 5, m4 = (idx4 & 31) * 4;
     *reinterpret_cast<float4*>(&S[k][m4]) = make_float4(r.v[i * 4 + 0], r.v[i * 4 + 1], r.v[i * 4 + 2], r.v[i * 4 + 3]);
+  }
+}
+
+// Branch-free interior loaders: out-of-range M indices are CLAMPED (they read valid memory; the rows / columns they
+// feed are never stored), so the main loop carries no exec-mask games and its loads stay in flight under the MFMAs.
+__device__ __forceinline__ void load_kc_fast(RegTile& r, const float* __restrict__ base, size_t ld, int m0, int k0, int Mlim,
+                                             int tid) {
+#pragma unroll
+  for (int i = 0; i < LPT; ++i) {
+    int idx4 = tid + i * 256;
+    int m = idx4 / (BK / 4), k4 = (idx4 % (BK / 4)) * 4;
+    int gm = m0 + m;
+    gm = gm < Mlim ? gm : Mlim - 1;
+    float4 t = *reinterpret_cast<const float4*>(base + (size_t)gm * ld + k0 + k4);
+    r.v[i * 4 + 0] = t.x;
+    r.v[i * 4 + 1] = t.y;
+    r.v[i * 4 + 2] = t.z;
+    r.v[i * 4 + 3] = t.w;
+  }
+}
+__device__ __forceinline__ void load_mc_fast(RegTile& r, const float* __restrict__ base, size_t ld, int m0, int k0, int Mlim,
+                                             int tid, int kshift = 0) {
+#pragma unroll
+  for (int i = 0; i < LPT; ++i) {
+    int idx4 = tid + i * 256;
+    int k = idx4 >> 5, m4 = (idx4 & 31) * 4;
+    int gm = m0 + m4;
+    gm = gm + 3 < Mlim ? gm : Mlim - 4;
+    float4 t = *reinterpret_cast<const float4*>(base + (ptrdiff_t)(k0 + k + kshift) * (ptrdiff_t)ld + gm);
+    r.v[i * 4 + 0] = t.x;
+    r.v[i * 4 + 1] = t.y;
+    r.v[i * 4 + 2] = t.z;
+    r.v[i * 4 + 3] = t.w;
   }
 }
 
@@ -115,25 +155,23 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
 
 // ------------------------------------------------------------------------------------------------ nn
 // grid: (ceil(N/128), ceil(T/128), B)
-__global__ __launch_bounds__(256) void k_gemm_nn(const float* __restrict__ X, int ldx, const float* __restrict__ mask4,
+__global__ __launch_bounds__(256, 2) void k_gemm_nn(const float* __restrict__ X, int ldx, const float* __restrict__ mask4,
                                                  const float* __restrict__ Wp, const float* __restrict__ bp,
                                                  float* __restrict__ Z, int B, int T, int F, int N, int vecA) {
-  __shared__ __attribute__((aligned(16))) float As[BK][LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[BK][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float As2[NBUF][BK][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs2[NBUF][BK][LDS_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
   const int n0 = blockIdx.x * BN, r0 = blockIdx.y * BM, b = blockIdx.z;
   const float* Xb = X + (size_t)b * T * ldx;
   f32x16 acc[2][2];
   zero_acc(acc);
   RegTile ra, rb, rm;
-  // The mask factors are only LOADED here and multiplied in at the LDS-store phase, so that the prefetch of the
-  // next stage stays in flight under the current stage's MFMAs (a multiply here would force vmcnt(0) right away).
-  auto fetch = [&](int k0) {
-    load_kc(ra, Xb, (size_t)ldx, r0, k0, T, F, vecA != 0, tid);
-    load_mc(rb, Wp, (size_t)N, n0, k0, N, F, true, tid);
+  // The mask factors are only LOADED at fetch time and multiplied in at the LDS-store phase, so that the prefetch of
+  // the next stage stays in flight under the current stage's MFMAs (a multiply at fetch would force vmcnt(0) at once).
+  auto fetch_mask = [&](int k0) {
     if (mask4) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < LPT; ++i) {
         int idx4 = tid + i * 256;
         int k = k0 + (idx4 >> 5);
         k = k < F ? k : F - 1;
@@ -143,26 +181,47 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const float* __restrict__ X, in
       }
     }
   };
-  auto stash = [&]() {
+  auto stash = [&](int buf) {
     if (mask4) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) rb.v[e] *= rm.v[e];
+      for (int e = 0; e < 4 * LPT; ++e) rb.v[e] *= rm.v[e];
     }
-    store_kc(As, ra, tid);
-    store_mc(Bs, rb, tid);
+    store_kc(As2[buf], ra, tid);
+    store_mc(Bs2[buf], rb, tid);
   };
-  fetch(0);
-  stash();
-  __syncthreads();
-  for (int k0 = 0; k0 < F; k0 += BK) {
-    bool more = k0 + BK < F;
-    if (more) fetch(k0 + BK);
-    mma_stage(As, Bs, acc, wr, wc, lane);
+  // interior K stages: software-pipelined, branch-free loads (separate code from the guarded tail so that no
+  // register-merging moves - and hence no early vmcnt waits - appear between the loads and the MFMAs)
+  const int nfast = vecA ? F / BK : 0;
+  if (nfast > 0) {
+    load_kc_fast(ra, Xb, (size_t)ldx, r0, 0, T, tid);
+    load_mc_fast(rb, Wp, (size_t)N, n0, 0, N, tid);
+    fetch_mask(0);
+    stash(0);
     __syncthreads();
-    if (more) {
-      stash();
+    int buf = 0;
+    for (int kt = 0; kt < nfast; ++kt) {
+      const bool more = kt + 1 < nfast;
+      if (more) {
+        load_kc_fast(ra, Xb, (size_t)ldx, r0, (kt + 1) * BK, T, tid);
+        load_mc_fast(rb, Wp, (size_t)N, n0, (kt + 1) * BK, N, tid);
+        fetch_mask((kt + 1) * BK);
+      }
+      mma_stage(As2[buf], Bs2[buf], acc, wr, wc, lane);
+      if (NBUF == 1) __syncthreads();
+      if (more) stash(buf ^ (NBUF - 1));  // NBUF == 2: the other buffer was last read before the previous barrier
       __syncthreads();
+      buf ^= (NBUF - 1);
     }
+  }
+  // guarded stages (K tail, or everything when the operands are not 16-byte aligned), not pipelined
+  for (int k0 = nfast * BK; k0 < F; k0 += BK) {
+    load_kc(ra, Xb, (size_t)ldx, r0, k0, T, F, vecA != 0, tid);
+    load_mc(rb, Wp, (size_t)N, n0, k0, N, F, true, tid);
+    fetch_mask(k0);
+    stash(0);
+    __syncthreads();
+    mma_stage(As2[0], Bs2[0], acc, wr, wc, lane);
+    __syncthreads();
   }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -181,11 +240,11 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const float* __restrict__ X, in
 // ------------------------------------------------------------------------------------------------ tn
 // slab[z][f][n] = sum over samples b = z, z+SG, ...  of  mask(b,f,n) * sum_t A[b,t+shift,f] * dZ[b,t,n]
 // grid: (ceil(N/128), ceil(F/128), SG)
-__global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, int lda, int shift,
+__global__ __launch_bounds__(256, 2) void k_gemm_tn(const float* __restrict__ A, int lda, int shift,
                                                  const float* __restrict__ mask4, const float* __restrict__ dZ,
                                                  float* __restrict__ slab, int B, int T, int F, int N, int SG, int vecA) {
-  __shared__ __attribute__((aligned(16))) float As[BK][LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[BK][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float As2[NBUF][BK][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs2[NBUF][BK][LDS_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
   const int n0 = blockIdx.x * BN, f0 = blockIdx.y * BM, z = blockIdx.z;
   f32x16 tot[2][2];
@@ -196,26 +255,47 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
     const float* Zb = dZ + (size_t)b * T * N;
     f32x16 acc[2][2];
     zero_acc(acc);
-    auto fetch = [&](int k0) {
+    auto slow_stage = [&](int k0) {
       load_mc(ra, Ab, (size_t)lda, f0, k0, F, T, vecA != 0, tid, shift);
       load_mc(rb, Zb, (size_t)N, n0, k0, N, T, true, tid);
-    };
-    fetch(0);
-    __syncthreads();
-    store_mc(As, ra, tid);
-    store_mc(Bs, rb, tid);
-    __syncthreads();
-    for (int k0 = 0; k0 < T; k0 += BK) {
-      bool more = k0 + BK < T;
-      if (more) fetch(k0 + BK);
-      mma_stage(As, Bs, acc, wr, wc, lane);
       __syncthreads();
-      if (more) {
-        store_mc(As, ra, tid);
-        store_mc(Bs, rb, tid);
+      store_mc(As2[0], ra, tid);
+      store_mc(Bs2[0], rb, tid);
+      __syncthreads();
+      mma_stage(As2[0], Bs2[0], acc, wr, wc, lane);
+      __syncthreads();
+    };
+    // interior stages [kbeg, kend): all rows (and their time-shifted partners) in range -> branch-free pipelined loads
+    int kbeg = 0, kend = vecA ? T / BK : 0;
+    if (shift < 0 && kend > 0) kbeg = 1;                       // stage 0 touches row -1
+    if (shift > 0 && kend > 0 && kend * BK - 1 + shift >= T) kend -= 1;  // last full stage touches row T
+    if (kend <= kbeg) kbeg = kend = 0;
+    for (int kt = 0; kt < kbeg; ++kt) slow_stage(kt * BK);
+    if (kend > kbeg) {
+      load_mc_fast(ra, Ab, (size_t)lda, f0, kbeg * BK, F, tid, shift);
+      load_mc_fast(rb, Zb, (size_t)N, n0, kbeg * BK, N, tid);
+      __syncthreads();
+      store_mc(As2[0], ra, tid);
+      store_mc(Bs2[0], rb, tid);
+      __syncthreads();
+      int buf = 0;
+      for (int kt = kbeg; kt < kend; ++kt) {
+        const bool more = kt + 1 < kend;
+        if (more) {
+          load_mc_fast(ra, Ab, (size_t)lda, f0, (kt + 1) * BK, F, tid, shift);
+          load_mc_fast(rb, Zb, (size_t)N, n0, (kt + 1) * BK, N, tid);
+        }
+        mma_stage(As2[buf], Bs2[buf], acc, wr, wc, lane);
+        if (NBUF == 1) __syncthreads();
+        if (more) {
+          store_mc(As2[buf ^ (NBUF - 1)], ra, tid);
+          store_mc(Bs2[buf ^ (NBUF - 1)], rb, tid);
+        }
         __syncthreads();
+        buf ^= (NBUF - 1);
       }
     }
+    for (int k0 = kend * BK; k0 < T; k0 += BK) slow_stage(k0);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -246,11 +326,11 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
 
 // ------------------------------------------------------------------------------------------------ nt
 // dX[b,r,f] (+)= sum_j dZ[b,r,j] * Wp[f,j] * mask4[j&3,b,f];  grid: (ceil(F/128), ceil(T/128), B)
-__global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ dZ, const float* __restrict__ Wp,
+__global__ __launch_bounds__(256, 2) void k_gemm_nt(const float* __restrict__ dZ, const float* __restrict__ Wp,
                                                  const float* __restrict__ mask4, float* __restrict__ dX, int lddx,
                                                  int accumulate, int B, int T, int F, int N) {
-  __shared__ __attribute__((aligned(16))) float As[BK][LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[BK][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float As2[NBUF][BK][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs2[NBUF][BK][LDS_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
   const int f0 = blockIdx.x * BN, r0 = blockIdx.y * BM, b = blockIdx.z;
   const float* Zb = dZ + (size_t)b * T * N;
@@ -260,39 +340,50 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ dZ, c
   // the mask factor of a B element depends only on (gate, f): constant over the K loop -> load once
   if (mask4) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < LPT; ++i) {
       int idx4 = tid + i * 256;
-      int f = f0 + (idx4 >> 2);
+      int f = f0 + idx4 / (BK / 4);
       f = f < F ? f : F - 1;
       // k0 and k4 are multiples of 4: the float4 covers gates 0..3 of one unit
 #pragma unroll
       for (int g = 0; g < 4; ++g) rm.v[i * 4 + g] = mask4[((size_t)g * B + b) * F + f];
     }
   }
-  auto fetch = [&](int k0) {
-    load_kc(ra, Zb, (size_t)N, r0, k0, T, N, true, tid);
-    load_kc(rb, Wp, (size_t)N, f0, k0, F, N, true, tid);
-  };
-  auto stash = [&]() {
+  auto stash = [&](int buf) {
     if (mask4) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) rb.v[e] *= rm.v[e];
+      for (int e = 0; e < 4 * LPT; ++e) rb.v[e] *= rm.v[e];
     }
-    store_kc(As, ra, tid);
-    store_kc(Bs, rb, tid);
+    store_kc(As2[buf], ra, tid);
+    store_kc(Bs2[buf], rb, tid);
   };
-  fetch(0);
-  stash();
-  __syncthreads();
-  for (int k0 = 0; k0 < N; k0 += BK) {
-    bool more = k0 + BK < N;
-    if (more) fetch(k0 + BK);
-    mma_stage(As, Bs, acc, wr, wc, lane);
+  const int nfast = N / BK;
+  if (nfast > 0) {
+    load_kc_fast(ra, Zb, (size_t)N, r0, 0, T, tid);
+    load_kc_fast(rb, Wp, (size_t)N, f0, 0, F, tid);
+    stash(0);
     __syncthreads();
-    if (more) {
-      stash();
+    int buf = 0;
+    for (int kt = 0; kt < nfast; ++kt) {
+      const bool more = kt + 1 < nfast;
+      if (more) {
+        load_kc_fast(ra, Zb, (size_t)N, r0, (kt + 1) * BK, T, tid);
+        load_kc_fast(rb, Wp, (size_t)N, f0, (kt + 1) * BK, F, tid);
+      }
+      mma_stage(As2[buf], Bs2[buf], acc, wr, wc, lane);
+      if (NBUF == 1) __syncthreads();
+      if (more) stash(buf ^ (NBUF - 1));
       __syncthreads();
+      buf ^= (NBUF - 1);
     }
+  }
+  for (int k0 = nfast * BK; k0 < N; k0 += BK) {
+    load_kc(ra, Zb, (size_t)N, r0, k0, T, N, true, tid);
+    load_kc(rb, Wp, (size_t)N, f0, k0, F, N, true, tid);
+    stash(0);
+    __syncthreads();
+    mma_stage(As2[0], Bs2[0], acc, wr, wc, lane);
+    __syncthreads();
   }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -357,7 +448,7 @@ int mgr_lstm_input_proj(mgr_ctx* c, const float* X, int ldx, const float* mask4,
   MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0 && ldx >= F, "bad shape");
   MGR_REQUIRE(aligned16(Wp) && aligned16(Z), "Wp/Z must be 16-byte aligned");
   int N = 4 * H;
-  int vecA = (ldx % 4 == 0) && aligned16(X);
+  int vecA = (ldx % 4 == 0) && (F % 4 == 0) && aligned16(X);
   dim3 grid((N + BN - 1) / BN, (T + BM - 1) / BM, B);
   mgr_prof_begin(c, MGR_K_GEMM_NN);
   hipLaunchKernelGGL(k_gemm_nn, grid, dim3(256), 0, mgr_stream(c), X, ldx, mask4, Wp, bp, Z, B, T, F, N, vecA);
@@ -392,7 +483,7 @@ int mgr_lstm_param_grads(mgr_ctx* c, const float* X, int ldx, const float* mask4
   hipStream_t s = mgr_stream(c);
   mgr_prof_begin(c, MGR_K_GEMM_TN);
   {
-    int vecA = (ldx % 4 == 0) && aligned16(X);
+    int vecA = (ldx % 4 == 0) && (F % 4 == 0) && aligned16(X);
     dim3 grid((N + BN - 1) / BN, (F + BM - 1) / BM, sgW);
     hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, s, X, ldx, 0, mask4, dZ, slabW, B, T, F, N, sgW, vecA);
     size_t n = (size_t)F * N;
@@ -400,7 +491,7 @@ int mgr_lstm_param_grads(mgr_ctx* c, const float* X, int ldx, const float* mask4
   }
   {
     // h_prev: forward direction uses h[t-1], reverse direction uses h[t+1]
-    int vecA = (ldh % 4 == 0) && aligned16(Hs);
+    int vecA = (ldh % 4 == 0) && (H % 4 == 0) && aligned16(Hs);
     dim3 grid((N + BN - 1) / BN, (H + BM - 1) / BM, sgU);
     hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, s, Hs, ldh, reverse ? 1 : -1, (const float*)nullptr, dZ, slabU, B, T, H, N, sgU, vecA);
     size_t n = (size_t)H * N;
