@@ -1,0 +1,100 @@
+"""world_size-2 gloo test (CPU) of the data-parallel update rule: two ranks, each with half of the global batch,
+all-reduce(sum) of the local mean-gradients, /world, THEN clip + Adam + max-norm  ==  one process on the full batch.
+The compute backend here is the oracle (tests may use it); what is under test is mgr_amd.parallel's sharding and
+reduction order, the same code path bench.py drives with RcclComm on GPUs."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import network_ref as nr
+from tests.helpers import load_case
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _is_lstm_mask(key):
+    """LSTM input-dropout masks are [4,B,F]; noise and the head mask are [B,T,*]."""
+    return key.endswith("/mask") and key != "head/mask"
+
+
+def _extend_rand(rand):
+    """Duplicate sample 0 so that the 3-sample fixture becomes a 4-sample global batch."""
+    return {k: (np.concatenate([v, v[:, :1]], 1) if _is_lstm_mask(k) else np.concatenate([v, v[:1]], 0))
+            for k, v in rand.items()}
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    import mgr_amd  # noqa: F401
+    from mgr_amd.parallel import data_parallel_update, shard_batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z, meta, grab = load_case("fusion_tiny")
+    spec = meta["spec"]
+    B = meta["B"] + 1  # 4 samples: duplicate one so the batch splits evenly
+    inputs = {k: np.concatenate([v, v[:1]], 0) for k, v in grab("x__").items()}
+    labels = np.concatenate([z["labels"], z["labels"][:1]], 0)
+    il = np.concatenate([z["input_length"], z["input_length"][:1]], 0)
+    ll = np.concatenate([z["label_length"], z["label_length"][:1]], 0)
+    rand = _extend_rand(grab("r__"))
+    batch = dict(inputs, the_labels=labels, input_length=il, label_length=ll)
+    mine = shard_batch(batch, rank, world)
+    per = B // world
+    my_rand = {k: (v[:, rank * per:(rank + 1) * per] if _is_lstm_mask(k) else v[rank * per:(rank + 1) * per])
+               for k, v in rand.items()}
+    w = {k: v.copy() for k, v in grab("w__").items()}
+    loss, _, grads, _ = nr.loss_and_grads(spec, w, {k: mine[k] for k in inputs}, mine["the_labels"], mine["input_length"],
+                                          mine["label_length"], my_rand)
+
+    def allreduce_sum(a):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.numpy()
+
+    names = sorted(grads)
+    flat = np.concatenate([grads[n].ravel() for n in names])
+    flat = data_parallel_update(flat, allreduce_sum, world)
+    off = 0
+    g2 = {}
+    for n in names:
+        g2[n] = flat[off:off + grads[n].size].reshape(grads[n].shape)
+        off += grads[n].size
+    tr = nr.Trainer(spec, w)
+    tr.apply(g2)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), loss=loss, **{k.replace("/", "__"): v for k, v in tr.w.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_equals_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    # single process, global batch of 4
+    z, meta, grab = load_case("fusion_tiny")
+    inputs = {k: np.concatenate([v, v[:1]], 0) for k, v in grab("x__").items()}
+    labels = np.concatenate([z["labels"], z["labels"][:1]], 0)
+    il = np.concatenate([z["input_length"], z["input_length"][:1]], 0)
+    ll = np.concatenate([z["label_length"], z["label_length"][:1]], 0)
+    rand = _extend_rand(grab("r__"))
+    tr = nr.Trainer(meta["spec"], {k: v.copy() for k, v in grab("w__").items()})
+    loss = tr.train_on_batch(inputs, labels, il, ll, rand)
+    assert abs((float(r0["loss"]) + float(r1["loss"])) / 2 - loss) < 1e-10 * abs(loss)
+    for k, v in tr.w.items():
+        kk = k.replace("/", "__")
+        assert np.array_equal(r0[kk], r1[kk]), k           # replicas stay bit-identical
+        assert np.allclose(r0[kk], v, rtol=1e-10, atol=1e-14), k
