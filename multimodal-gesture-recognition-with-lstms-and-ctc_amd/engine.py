@@ -19,6 +19,34 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
+class _Arena:
+    """Allocations that live and die with one Engine (the Device itself may be shared)."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.arrays = []
+
+    def _keep(self, a):
+        self.arrays.append(a)
+        return a
+
+    def empty(self, shape, dtype=np.float32):
+        return self._keep(self.dev.empty(shape, dtype))
+
+    def zeros(self, shape, dtype=np.float32):
+        return self._keep(self.dev.zeros(shape, dtype))
+
+    def bytes(self, nbytes):
+        return self._keep(self.dev.bytes(nbytes))
+
+    def free_all(self):
+        dead = set(id(a) for a in self.arrays)
+        for a in self.arrays:
+            a.free()
+        self.dev._arrays = [a for a in self.dev._arrays if id(a) not in dead]
+        self.arrays = []
+
+
 class _LstmDir:
     """Device state of one direction of one Bidirectional(LSTM) layer."""
 
@@ -41,7 +69,9 @@ class Engine:
     def __init__(self, spec, B, T, Lmax, device=0, seed=1234, comm=None, world=1, inference_only=False):
         self.spec = spec
         self.B, self.T, self.Lmax = int(B), int(T), int(Lmax)
+        self._own_dev = not isinstance(device, Device)
         self.dev = device if isinstance(device, Device) else Device(device)
+        self.mem = _Arena(self.dev)           # device buffers owned by this engine
         self.lib = self.dev.lib
         self.seed = int(seed)
         self.comm = comm
@@ -53,7 +83,7 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------ build
     def _build(self):
-        sp, dev, B, T = self.spec, self.dev, self.B, self.T
+        sp, dev, B, T = self.spec, self.mem, self.B, self.T
         table = sp.weight_table()
         # flat trainable buffer layout (every segment padded to 4 floats)
         self.seg = {}
@@ -141,7 +171,7 @@ class Engine:
             self.llen_d = dev.empty((B,), np.int32)
             self.ws_ctc = dev.bytes(self.lib.mgr_ctc_ws_bytes(B, T, Cn, self.Lmax))
             self.ws_dense = dev.bytes(self.lib.mgr_dense_bwd_ws_bytes(B, T, D, Cn))
-        dev.sync()
+        self.dev.sync()
 
     def _wview(self, name):
         if name in self.seg:
@@ -356,7 +386,7 @@ class Engine:
             p_head = 0.0
             if rand.get("head/mask") is not None:
                 if self.head_mask is None:
-                    self.head_mask = dev.empty((B, T, D))
+                    self.head_mask = self.mem.empty((B, T, D))
                 self.head_mask.upload(np.asarray(rand["head/mask"], dtype=np.float32))
                 hm = self.head_mask.ptr
         elif train and p_head > 0:
@@ -372,7 +402,7 @@ class Engine:
         arr = _capi.make_scan_jobs(jobs)
         need = self.lib.mgr_lstm_scan_multi_ws_bytes(len(jobs), arr)
         if getattr(self, "_ws_multi", None) is None or self._ws_multi.nbytes < need:
-            self._ws_multi = self.dev.bytes(need)
+            self._ws_multi = self.mem.bytes(need)
         _capi.check(self.lib.mgr_lstm_scan_fwd_multi(self.dev.ctx, len(jobs), arr, self._ws_multi.ptr,
                                                      self._ws_multi.nbytes))
 
@@ -523,4 +553,11 @@ class Engine:
         self.iterations += 1
 
     def close(self):
-        self.dev.close()
+        """Free this engine's device buffers; destroy the context only if the engine created it."""
+        if self.dev.ctx is None:
+            return
+        self.dev.sync()
+        if self._own_dev:
+            self.dev.close()
+            return
+        self.mem.free_all()
