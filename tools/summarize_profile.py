@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/<tag>_* (bench JSON, rocprofv3 kernel stats, PMC passes) into profiles/<tag>_summary.md
+and copy the raw per-kernel CSV summaries next to it."""
+import collections
+import csv
+import json
+import os
+import re
+import shutil
+import sys
+
+tag = sys.argv[1]
+G = "gpurun_out"
+os.makedirs("profiles", exist_ok=True)
+
+
+def short(name):
+    m = re.search(r"(k_[a-z_0-9]+|__amd_rocclr_[A-Za-z]+)", name)
+    return m.group(1) if m else name[:40]
+
+
+out = ["# %s — bench + rocprofv3 summary (MI355X, config F: B=64, T=1900)\n" % tag]
+j = json.loads(open("%s/%s_bench.json" % (G, tag)).read())
+out.append("## bench.py line\n```json\n%s\n```\n" % json.dumps(j, indent=1))
+shutil.copy("%s/%s_kernel_stats.csv" % (G, tag), "profiles/%s_kernel_stats.csv" % tag)
+rows = list(csv.DictReader(open("%s/%s_kernel_stats.csv" % (G, tag))))
+out.append("## rocprofv3 --kernel-trace --stats (3 timed steps + 1 warm-up)\n")
+out.append("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
+for r in rows[:14]:
+    out.append("| %s | %s | %.2f | %.1f | %s |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                               float(r["AverageNs"]) / 1e3, r["Percentage"]))
+
+
+def pmc(name):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    path = "%s/%s_pmc_%s.csv" % (G, tag, name)
+    if not os.path.exists(path):
+        return agg, cnt
+    seen = set()
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if (r["Dispatch_Id"]) not in seen:
+            seen.add(r["Dispatch_Id"])
+            cnt[k] += 1
+    return agg, cnt
+
+
+f, fc = pmc("FETCH_SIZE")
+w, wc = pmc("WRITE_SIZE")
+out.append("\n## HBM traffic per launch (PMC, separate passes; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md)\n")
+out.append("| kernel | launches | fetch MB/launch (x2-corrected) | write MB/launch |\n|---|---|---|---|")
+for k in sorted(f, key=lambda k: -f[k]["FETCH_SIZE"]):
+    if fc[k] == 0:
+        continue
+    out.append("| %s | %d | %.1f | %.1f |" % (k, fc[k], 2 * f[k]["FETCH_SIZE"] / fc[k] / 1024,
+                                           w[k]["WRITE_SIZE"] / max(1, wc[k]) / 1024))
+s, sc = pmc("SQ_VALU_MFMA_BUSY_CYCLES")
+out.append("\n## SQ counters per kernel (sums over launches)\n")
+out.append("| kernel | launches | MFMA busy / (1024 SIMD x GUI_ACTIVE/8) | WAIT_INST_ANY/WAVE_CYCLES | WAIT_ANY/WAVE_CYCLES | ACTIVE/WAVE_CYCLES | LDS bank conflict cycles |\n|---|---|---|---|---|---|---|")
+for k in sorted(s, key=lambda k: -s[k]["SQ_VALU_MFMA_BUSY_CYCLES"]):
+    v = s[k]
+    if v["GRBM_GUI_ACTIVE"] == 0 or v["SQ_WAVE_CYCLES"] == 0:
+        continue
+    out.append("| %s | %d | %.3f | %.2f | %.2f | %.2f | %.3g |" % (
+        k, sc[k], v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * v["GRBM_GUI_ACTIVE"] / 8), v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"],
+        v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], v["SQ_ACTIVE_INST_ANY"] / v["SQ_WAVE_CYCLES"], v["SQ_LDS_BANK_CONFLICT"]))
+open("profiles/%s_summary.md" % tag, "w").write("\n".join(out) + "\n")
+print("\n".join(out[3:]))
