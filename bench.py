@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
     ap.add_argument("--maxlen", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--show-plan", action="store_true")
+    ap.add_argument("--scan-path", type=int, default=0)
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-T", type=int, default=400)
     ap.add_argument("--cpu-B", type=int, default=64)
@@ -72,6 +74,10 @@ def main():
     if args.maxlen:
         T = args.maxlen
     dev = _capi.Device(local_rank)
+    if args.show_plan:
+        dev.call("mgr_tune", 2, 1)
+    if args.scan_path:
+        dev.call("mgr_tune", 0, args.scan_path)
 
     comm = None
     if world > 1:

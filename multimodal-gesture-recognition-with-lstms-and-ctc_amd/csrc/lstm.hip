@@ -86,10 +86,20 @@ void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
       int tiles_here = std::min(tiles, ks);
       int per_simd = (tiles_here + 3) / 4;
       long t = (long)per_simd * ks * 37 + 700 + (G > 1 ? 3300 : 400);
+      if (total > c->cu_count) t += (long)per_simd * ks * 12;  // a second workgroup on the CU competes for the MFMA pipe part of the time
       worst = std::max(worst, t);
       sum += t;
     }
-    if (!feas || (exch && total > c->cu_count)) continue;
+    // capacity: one 8-wave workgroup per CU, or two 4-wave workgroups (<= 80 KiB LDS each) per CU
+    bool all4 = true;
+    int maxks = 0;
+    for (int k = 0; k < n; ++k) {
+      if (kCfgs[cur[k]].nw != 4) all4 = false;
+      maxks = std::max(maxks, jobs[idx[k]].H / 4);
+    }
+    size_t lds2 = (size_t)2 * ((maxks + 3) / 4) * 1024;
+    int capacity = (all4 && lds2 <= 80 * 1024) ? 2 * c->cu_count : c->cu_count;
+    if (!feas || (exch && total > capacity)) continue;
     long cost = worst * 1000 + sum / n;
     if (best_cost < 0 || cost < best_cost) {
       best_cost = cost;
@@ -182,6 +192,12 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
       w += mgr_align_up((size_t)P.nbg[i] * 2 * img * sizeof(float), 256);
     }
     L.status = status;
+    if (c->tune[2]) {  // tune key 2: print the plan
+      for (int i = 0; i < L.njobs; ++i)
+        fprintf(stderr, "[mgr scan plan] job %d: H=%d ks=%d nw=%d tpw=%d G=%d nbg=%d wgs=[%d,%d)\n", i, L.job[i].H, L.job[i].ks,
+                L.job[i].nw, L.job[i].tpw, L.job[i].G_, L.job[i].nbg, L.job[i].wg_begin, L.job[i].wg_begin + L.job[i].G_ * L.job[i].nbg);
+      fprintf(stderr, "[mgr scan plan] total %d workgroups, exchange=%d\n", P.total, (int)P.exchange);
+    }
     // flags + status must be zero at every launch (epochs count from 1 within the call)
     MGR_HIP(hipMemsetAsync(base, 0, (size_t)(w - base), mgr_stream(c)));
     r = mgr_cluster_launch(c, L, P.total, P.exchange);

@@ -44,8 +44,9 @@ constexpr unsigned POLL_LIMIT = 1u << 20;
 template <int KS, int TPW>
 __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float* smem, unsigned* status) {
   constexpr int H = 4 * KS, N = 4 * H, QN = (KS + 3) / 4, IMG = QN * 256;
-  static_assert(QN <= 4 * CL_WAVES, "gather sweep covers at most 32 image blocks (H <= 512)");
+  static_assert(QN <= 32, "gather sweep covers at most 32 image blocks (H <= 512)");
   const int tid = threadIdx.x, lane = tid & 63;
+  const int nwv = blockDim.x >> 6;  // waves in this workgroup: 8, or 4 when every job runs one tile per SIMD
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches
   const int j = lane & 15, uq = lane >> 4;
   const int G = jb.G_;
@@ -79,7 +80,7 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float*
 #pragma unroll
     for (int s = 0; s < KS; ++s) uf[jt][s] = v ? Up[(size_t)(4 * s + uq) * N + tl[jt] * 16 + j] : 0.f;
   }
-  for (int i = tid; i < 2 * IMG; i += CL_WAVES * 64) img[i] = 0.f;
+  for (int i = tid; i < 2 * IMG; i += nwv * 64) img[i] = 0.f;
 
   const int q0 = (ug * tpwg) >> 2, nq = tpwg >> 2;  // own 1 KiB blocks of the image
   float* xb = jb.xbuf + (size_t)bg * 2 * IMG;
@@ -203,53 +204,57 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float*
     }
     STAMP(s2);
     if (G > 1 && step + 1 < T) {
-      // gather: wave w sweeps blocks w, w+8, w+16, w+24 of the exchange slot until every word has this epoch's parity
-      u32x4 v[4];
-      unsigned pend = 0;
+      // gather: wave w sweeps blocks w, w+nwv, w+2*nwv, ... of the exchange slot (up to 8 loads in flight per round) until
+      // every word of a block shows this epoch's parity
+      constexpr int NF = 8;  // loads in flight per wave and round
+      for (int base = 0; base < QN && !failed; base += NF * nwv) {
+        u32x4 v[NF];
+        unsigned pend = 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int q = wave + CL_WAVES * i;
-        if (q < QN && (q < q0 || q >= q0 + nq)) pend |= 1u << i;
-      }
-      unsigned spins = 0;
-      while (pend && !failed) {
+        for (int i = 0; i < NF; ++i) {
+          int q = base + wave + nwv * i;
+          if (q < QN && (q < q0 || q >= q0 + nq)) pend |= 1u << i;
+        }
+        unsigned spins = 0;
+        while (pend && !failed) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (pend & (1u << i))
-            v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (slot * IMG + (wave + CL_WAVES * i) * 256 + lane * 4) * 4, 0, 16);  // sc1
+          for (int i = 0; i < NF; ++i)
+            if (pend & (1u << i))
+              v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (slot * IMG + (base + wave + nwv * i) * 256 + lane * 4) * 4, 0, 16);  // sc1
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (pend & (1u << i)) {
-            const int q = wave + CL_WAVES * i;
-            const int nvalid = KS - 4 * q;  // k-steps of this block that exist (words r >= nvalid are never written)
-            unsigned a = par ? 0xFFFFFFFFu : 0u;
-            if (par) {
-              a &= v[i].x;
-              if (nvalid > 1) a &= v[i].y;
-              if (nvalid > 2) a &= v[i].z;
-              if (nvalid > 3) a &= v[i].w;
-            } else {
-              a |= v[i].x;
-              if (nvalid > 1) a |= v[i].y;
-              if (nvalid > 2) a |= v[i].z;
-              if (nvalid > 3) a |= v[i].w;
-            }
-            if (__all((a & 1u) == par)) {
-              *reinterpret_cast<u32x4*>(hn + q * 256 + lane * 4) = v[i];
-              pend &= ~(1u << i);
+          for (int i = 0; i < NF; ++i) {
+            if (pend & (1u << i)) {
+              const int q = base + wave + nwv * i;
+              const int nvalid = KS - 4 * q;  // k-steps of this block that exist (words r >= nvalid are never written)
+              unsigned a = par ? 0xFFFFFFFFu : 0u;
+              if (par) {
+                a &= v[i].x;
+                if (nvalid > 1) a &= v[i].y;
+                if (nvalid > 2) a &= v[i].z;
+                if (nvalid > 3) a &= v[i].w;
+              } else {
+                a |= v[i].x;
+                if (nvalid > 1) a |= v[i].y;
+                if (nvalid > 2) a |= v[i].z;
+                if (nvalid > 3) a |= v[i].w;
+              }
+              if (__all((a & 1u) == par)) {
+                *reinterpret_cast<u32x4*>(hn + q * 256 + lane * 4) = v[i];
+                pend &= ~(1u << i);
+              }
             }
           }
-        }
 #ifdef MGR_STAMP
-        st_passes += 1;
+          st_passes += 1;
 #endif
-        if (pend) {
-          __builtin_amdgcn_s_sleep(1);
-          ++spins;
-          if ((spins & 255u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) failed = true;
-          if (spins > POLL_LIMIT) {
-            failed = true;
-            if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (pend) {
+            __builtin_amdgcn_s_sleep(1);
+            ++spins;
+            if ((spins & 255u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) failed = true;
+            if (spins > POLL_LIMIT) {
+              failed = true;
+              if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
           }
         }
       }
@@ -275,7 +280,7 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float*
   }
 #ifdef MGR_STAMP
   if (lane == 0 && wg < 2) {
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(status + 16) + (wg * CL_WAVES + wave) * 8;
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(status + 16) + (wg * 8 + wave) * 8;
     dbg[0] = st_mfma; dbg[1] = st_cell; dbg[2] = st_gather; dbg[3] = st_bar; dbg[4] = st_passes;
   }
 #endif
@@ -311,21 +316,32 @@ bool mgr_cluster_supported(int ks, int tpw) {
 }
 
 int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool any_exchange) {
-  int maxks = 0;
-  for (int i = 0; i < L.njobs; ++i) maxks = L.job[i].ks > maxks ? L.job[i].ks : maxks;
+  int maxks = 0, maxnw = 0;
+  for (int i = 0; i < L.njobs; ++i) {
+    maxks = L.job[i].ks > maxks ? L.job[i].ks : maxks;
+    maxnw = L.job[i].nw > maxnw ? L.job[i].nw : maxnw;
+  }
+  const int waves = maxnw <= 4 ? 4 : CL_WAVES;
   size_t img = (size_t)((maxks + 3) / 4) * 256 * sizeof(float);
   size_t lds = 2 * img;
+  int per_cu = 1;
   if (any_exchange) {
-    if (lds < 84 * 1024) lds = 84 * 1024;  // > half of the 160 KiB LDS: at most one workgroup per CU
-    MGR_REQUIRE(total_wgs <= c->cu_count, "cluster scan needs %d co-resident workgroups but the device has %d CUs", total_wgs,
-                c->cu_count);
+    // co-residency of every spinning workgroup is what makes the in-launch hand-off deadlock-free.  4-wave workgroups
+    // with <= 80 KiB of LDS fit two per CU (8 waves, <= 256 VGPRs each); otherwise force one per CU through the LDS size.
+    if (waves == 4 && lds <= 80 * 1024) {
+      per_cu = 2;
+    } else if (lds < 84 * 1024) {
+      lds = 84 * 1024;
+    }
+    MGR_REQUIRE(total_wgs <= per_cu * c->cu_count, "cluster scan needs %d co-resident workgroups but the device holds %d",
+                total_wgs, per_cu * c->cu_count);
   }
   static bool attr_set = false;
   if (!attr_set) {
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_scan_cluster, dim3(total_wgs), dim3(CL_WAVES * 64), lds, mgr_stream(c), L);
+  hipLaunchKernelGGL(k_scan_cluster, dim3(total_wgs), dim3(waves * 64), lds, mgr_stream(c), L);
   MGR_LAUNCH_CHECK();
   return 0;
 }

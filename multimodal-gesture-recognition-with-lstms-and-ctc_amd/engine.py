@@ -304,6 +304,9 @@ class Engine:
                 X = self.X[name]
             self._xcur[name] = X
             dev.wait(sb, sa)
+        dev.stream(0)
+        for st in used_streams:
+            dev.wait(0, st)
         depth = max(len(s["layers"]) for s in sp.streams)
         for k in range(depth):
             jobs = []
@@ -323,7 +326,7 @@ class Engine:
                     cur, ldcur, fin = self.Y1[name], 2 * Hp, 2 * Hp
                 for di, (dname, st) in enumerate((("fwd", sa), ("bwd", sb))):
                     L = self.dirs["%s/l%d/%s" % (name, k, dname)]
-                    dev.stream(st)
+                    dev.stream(0)   # every projection GEMM fills the chip: one stream keeps their timings honest
                     slot += 1
                     mptr = self._prep_mask(L, train, rand, slot)
                     self._masks[(L.prefix, L.d)] = mptr
@@ -343,16 +346,12 @@ class Engine:
                                      cs=L.cs if keep else 0, B=B, T=T, H=H, reverse=L.reverse))
             # all recurrences of this depth in ONE call (one persistent multi-CU launch when H is large)
             dev.stream(0)
-            for st in used_streams:
-                dev.wait(0, st)
             self._scan_multi(jobs)
-            for st in used_streams:
-                dev.wait(st, 0)
         for si, s in enumerate(sp.streams):
             name = s["name"]
             if len(s["layers"]) == 2 and s["residual"] and name in self.Y2 and save:
                 H = s["layers"][-1]["H"]
-                dev.stream(1 + 2 * si)
+                dev.stream(0)
                 dev.call("mgr_add2d", self.Y1[name], 2 * H, self.Y2[name], 2 * H, self.FEAT.view(cols[name], (1,)), W,
                          B * T, 2 * H)
         dev.stream(0)
@@ -361,9 +360,8 @@ class Engine:
         feat, ldf = self.FEAT, W
         if sp.fusion:
             Hf = sp.fusion["H"]
-            dev.wait(1, 0)
             jobs = []
-            for di, (dname, st) in enumerate((("fwd", 0), ("bwd", 1))):
+            for di, (dname, st) in enumerate((("fwd", 0), ("bwd", 0))):
                 L = self.dirs["fusion/%s" % dname]
                 dev.stream(st)
                 slot += 1
@@ -374,7 +372,6 @@ class Engine:
                                  gates=L.gates if save else 0, cs=L.cs if save else 0, B=B, T=T, H=Hf,
                                  reverse=L.reverse))
             dev.stream(0)
-            dev.wait(0, 1)
             self._scan_multi(jobs)
             feat, ldf = self.YF, 2 * Hf
         # head
@@ -498,11 +495,14 @@ class Engine:
             dYv = dY.view(di * H, (1,)) if isinstance(dY, DeviceArray) else dY
             dev.call("mgr_lstm_scan_bwd", dYv, lddy, L.gates, L.cs, L.Up, L.dZ, B, T, H, L.reverse, L.ws_scan,
                      L.ws_scan.nbytes)
+        dev.stream(0)
+        dev.wait(0, 1)
+        for di, dname in enumerate(("fwd", "bwd")):
+            L = self.dirs["%s/%s" % (prefix, dname)]
+            H = L.H
             mptr = self._masks.get((L.prefix, L.d), 0)
             dev.call("mgr_lstm_param_grads", Xin, ldx, mptr, Hbuf.view(di * H, (1,)), ldh, L.dZ, L.gWp, L.gUp, L.gbp,
                      B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes)
-        dev.stream(0)
-        dev.wait(0, 1)
         if dX is not None:
             for di, dname in enumerate(("fwd", "bwd")):
                 L = self.dirs["%s/%s" % (prefix, dname)]
