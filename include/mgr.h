@@ -115,6 +115,18 @@ int mgr_tune(mgr_ctx* ctx, int key, int value);
  * written by scan_fwd WITHOUT residual (needed only through gates/cs here).  Produces dZ [B,T,4H] packed. */
 int mgr_lstm_scan_bwd(mgr_ctx* ctx, const float* dY, int lddy, const float* gates, const float* cs,
                       const float* Up, float* dZ, int B, int T, int H, int reverse, void* ws, size_t ws_bytes);
+/* Several BPTT recurrences (both directions of a Bidirectional layer) in ONE call; layers with a multi-CU
+ * instantiation run as a single persistent launch of CU clusters exchanging dz_t each step (lstm_cluster_bwd.hip). */
+typedef struct mgr_scan_bwd_job {
+  const float* dY;
+  const float* gates;
+  const float* cs;
+  const float* Up;
+  float* dZ;
+  int lddy, B, T, H, reverse;
+} mgr_scan_bwd_job;
+size_t mgr_lstm_scan_bwd_multi_ws_bytes(int njobs, const mgr_scan_bwd_job* jobs);
+int mgr_lstm_scan_bwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_bwd_job* jobs, void* ws, size_t ws_bytes);
 /* Parameter gradients from dZ (all packed layouts, f32 MFMA split-K GEMMs, deterministic slab reduce):
  *   dWp[F,4H] = sum_rows (X (.) mask4)^T dZ ;  dUp[H,4H] = sum_rows hprev^T dZ ;  dbp[4H] = sum_rows dZ
  * Hs is the layer's own un-residualed output h (row stride ldh); hprev is its time-shifted view. */

@@ -46,6 +46,8 @@ SIGNATURES = {
     "mgr_lstm_scan_multi_ws_bytes": (sz, [i32, vp]),
     "mgr_lstm_scan_fwd_multi": (i32, [vp, i32, vp, vp, sz]),
     "mgr_tune": (i32, [vp, i32, i32]),
+    "mgr_lstm_scan_bwd_multi_ws_bytes": (sz, [i32, vp]),
+    "mgr_lstm_scan_bwd_multi": (i32, [vp, i32, vp, vp, sz]),
     "mgr_lstm_scan_bwd": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz]),
     "mgr_lstm_param_grads_ws_bytes": (sz, [i32, i32, i32, i32]),
     "mgr_lstm_param_grads": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz]),
@@ -78,6 +80,23 @@ class ScanJob(C.Structure):
     """struct mgr_scan_job"""
     _fields_ = [("Z", vp), ("Up", vp), ("Y", vp), ("R", vp), ("gates", vp), ("cs", vp),
                 ("ldy", i32), ("ldr", i32), ("B", i32), ("T", i32), ("H", i32), ("reverse", i32)]
+
+
+class ScanBwdJob(C.Structure):
+    """struct mgr_scan_bwd_job"""
+    _fields_ = [("dY", vp), ("gates", vp), ("cs", vp), ("Up", vp), ("dZ", vp),
+                ("lddy", i32), ("B", i32), ("T", i32), ("H", i32), ("reverse", i32)]
+
+
+def make_scan_bwd_jobs(jobs):
+    arr = (ScanBwdJob * len(jobs))()
+    for a, j in zip(arr, jobs):
+        for k in ("dY", "gates", "cs", "Up", "dZ"):
+            v = j[k]
+            setattr(a, k, v.ptr if isinstance(v, DeviceArray) else v)
+        for k in ("lddy", "B", "T", "H", "reverse"):
+            setattr(a, k, int(j[k]))
+    return arr
 
 
 def make_scan_jobs(jobs):

@@ -133,6 +133,19 @@ int mgr_tune(mgr_ctx* c, int key, int value) {
   return 0;
 }
 
+static size_t bwd_job_ws(const mgr_scan_bwd_job& j) {
+  int nbg = (j.B + 15) / 16;
+  size_t cluster = mgr_align_up((size_t)nbg * 2 * mgr_cluster_bwd_img_floats(j.H) * sizeof(float), 256);
+  size_t fallback = mgr_align_up((size_t)4 * j.H * j.H * sizeof(float), 256);
+  return std::max(cluster, fallback);
+}
+
+size_t mgr_lstm_scan_bwd_multi_ws_bytes(int njobs, const mgr_scan_bwd_job* jobs) {
+  size_t s = 2048;
+  for (int i = 0; i < njobs; ++i) s += bwd_job_ws(jobs[i]);
+  return s;
+}
+
 size_t mgr_lstm_scan_ws_bytes(int B, int T, int H) {
   (void)T;
   mgr_scan_job j;
@@ -140,7 +153,11 @@ size_t mgr_lstm_scan_ws_bytes(int B, int T, int H) {
   j.B = B;
   j.H = H;
   size_t fallback = mgr_align_up((size_t)4 * H * H * sizeof(float), 256);  // U^T for the fallback backward kernel
-  return std::max(fallback, job_ws(j) + 2048);
+  mgr_scan_bwd_job bj;
+  memset(&bj, 0, sizeof(bj));
+  bj.B = B;
+  bj.H = H;
+  return std::max(std::max(fallback, job_ws(j) + 2048), mgr_lstm_scan_bwd_multi_ws_bytes(1, &bj));
 }
 
 size_t mgr_lstm_scan_multi_ws_bytes(int njobs, const mgr_scan_job* jobs) {
@@ -228,24 +245,86 @@ int mgr_lstm_scan_fwd(mgr_ctx* c, const float* Z, const float* Up, float* Y, int
   return mgr_lstm_scan_fwd_multi(c, 1, &j, ws, ws_bytes);
 }
 
-int mgr_lstm_scan_bwd(mgr_ctx* c, const float* dY, int lddy, const float* gates, const float* cs, const float* Up,
-                      float* dZ, int B, int T, int H, int reverse, void* ws, size_t ws_bytes) {
-  MGR_REQUIRE(c && dY && gates && cs && Up && dZ, "null argument");
-  MGR_REQUIRE(B > 0 && T > 0 && H > 0 && lddy >= H, "bad shape");
-  MGR_REQUIRE(aligned16(gates) && aligned16(Up) && aligned16(dZ), "gates/Up/dZ must be 16-byte aligned");
+int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs, void* ws, size_t ws_bytes) {
+  MGR_REQUIRE(c && jobs && njobs > 0 && njobs <= MGR_MAX_SCAN_JOBS, "bad job list");
+  MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_scan_bwd_multi_ws_bytes(njobs, jobs), "workspace too small");
+  for (int i = 0; i < njobs; ++i) {
+    const mgr_scan_bwd_job& j = jobs[i];
+    MGR_REQUIRE(j.dY && j.gates && j.cs && j.Up && j.dZ, "job %d: null argument", i);
+    MGR_REQUIRE(j.B > 0 && j.T > 0 && j.H > 0 && j.lddy >= j.H, "job %d: bad shape", i);
+    MGR_REQUIRE(aligned16(j.gates) && aligned16(j.Up) && aligned16(j.dZ), "job %d: gates/Up/dZ must be 16-byte aligned", i);
+  }
   int r = mgr_prof_begin(c, MGR_K_SCAN_BWD);
   if (r) return r;
-  r = 0;
-  if (c->tune[MGR_TUNE_SCAN_PATH] != 1) r = mgr_scan_bwd_mfma(c, dY, lddy, gates, cs, Up, dZ, B, T, H, reverse);
-  if (r == 0) {
-    MGR_REQUIRE(ws && ws_bytes >= mgr_align_up((size_t)4 * H * H * sizeof(float), 256), "workspace too small");
-    float* UpT = reinterpret_cast<float*>(ws);
-    r = mgr_transpose(c, Up, UpT, H, 4 * H);
-    if (r) return r;
-    r = mgr_scan_bwd_simple(c, dY, lddy, gates, cs, UpT, dZ, B, T, H, reverse);
+  const int path = c->tune[MGR_TUNE_SCAN_PATH];
+  char* w = reinterpret_cast<char*>(ws);
+  char* base = w;
+  unsigned* status = reinterpret_cast<unsigned*>(w);
+  w += 2048;
+  ClusterBwdLaunch L;
+  memset(&L, 0, sizeof(L));
+  L.status = status;
+  int total = 0;
+  bool use_cluster[MGR_MAX_SCAN_JOBS];
+  // cluster kernel when instantiated and the whole launch is co-resident (two 4-wave workgroups per CU)
+  for (int i = 0; i < njobs; ++i) {
+    const mgr_scan_bwd_job& j = jobs[i];
+    use_cluster[i] = (path == 0 || path == 3) && mgr_cluster_bwd_supported(j.H);
+    if (use_cluster[i]) total += ((j.H + 15) / 16) * ((j.B + 15) / 16);
   }
-  if (r < 0) return r;
-  return mgr_prof_end(c, MGR_K_SCAN_BWD);
+  if (total > 2 * c->cu_count)
+    for (int i = 0; i < njobs; ++i) use_cluster[i] = false;
+  char* wj[MGR_MAX_SCAN_JOBS];
+  for (int i = 0; i < njobs; ++i) {
+    wj[i] = w;
+    w += bwd_job_ws(jobs[i]);
+  }
+  int begin = 0;
+  for (int i = 0; i < njobs; ++i) {
+    if (!use_cluster[i]) continue;
+    const mgr_scan_bwd_job& j = jobs[i];
+    ClusterBwdJob& cj = L.job[L.njobs++];
+    cj.dY = j.dY; cj.gates = j.gates; cj.cs = j.cs; cj.Up = j.Up; cj.dZ = j.dZ;
+    cj.lddy = j.lddy; cj.B = j.B; cj.T = j.T; cj.H = j.H; cj.reverse = j.reverse;
+    cj.G_ = (j.H + 15) / 16; cj.nbg = (j.B + 15) / 16; cj.wg_begin = begin;
+    begin += cj.G_ * cj.nbg;
+    cj.xbuf = reinterpret_cast<float*>(wj[i]);
+  }
+  if (L.njobs > 0) {
+    MGR_HIP(hipMemsetAsync(base, 0, (size_t)(w - base), mgr_stream(c)));
+    r = mgr_cluster_bwd_launch(c, L, begin);
+    if (r) return r;
+  }
+  for (int i = 0; i < njobs; ++i) {
+    if (use_cluster[i]) continue;
+    const mgr_scan_bwd_job& j = jobs[i];
+    r = 0;
+    if (path != 1) r = mgr_scan_bwd_mfma(c, j.dY, j.lddy, j.gates, j.cs, j.Up, j.dZ, j.B, j.T, j.H, j.reverse);
+    if (r == 0) {
+      float* UpT = reinterpret_cast<float*>(wj[i]);
+      r = mgr_transpose(c, j.Up, UpT, j.H, 4 * j.H);
+      if (r) return r;
+      r = mgr_scan_bwd_simple(c, j.dY, j.lddy, j.gates, j.cs, UpT, j.dZ, j.B, j.T, j.H, j.reverse);
+    }
+    if (r < 0) return r;
+  }
+  r = mgr_prof_end(c, MGR_K_SCAN_BWD);
+  if (r) return r;
+  if (L.njobs > 0 && c->tune[1]) {
+    unsigned st = 0;
+    MGR_HIP(hipMemcpyAsync(&st, status, sizeof(st), hipMemcpyDeviceToHost, mgr_stream(c)));
+    MGR_HIP(hipStreamSynchronize(mgr_stream(c)));
+    MGR_REQUIRE(st == 0, "cluster BPTT: a bounded spin gave up (status %u)", st);
+  }
+  return 0;
+}
+
+int mgr_lstm_scan_bwd(mgr_ctx* c, const float* dY, int lddy, const float* gates, const float* cs, const float* Up,
+                      float* dZ, int B, int T, int H, int reverse, void* ws, size_t ws_bytes) {
+  mgr_scan_bwd_job j;
+  j.dY = dY; j.gates = gates; j.cs = cs; j.Up = Up; j.dZ = dZ;
+  j.lddy = lddy; j.B = B; j.T = T; j.H = H; j.reverse = reverse;
+  return mgr_lstm_scan_bwd_multi(c, 1, &j, ws, ws_bytes);
 }
 
 }  // extern "C"

@@ -29,3 +29,23 @@ struct ClusterLaunch {
 // true if (ks, tpw) has an instantiation
 bool mgr_cluster_supported(int ks, int tpw);
 int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool any_exchange);
+
+// ---- backward (lstm_cluster_bwd.hip)
+struct ClusterBwdJob {
+  const float* dY;
+  const float* gates;
+  const float* cs;
+  const float* Up;
+  float* dZ;
+  float* xbuf;  // [nbg][2][IMG]
+  int lddy, B, T, H, reverse;
+  int wg_begin, G_, nbg;
+};
+struct ClusterBwdLaunch {
+  int njobs;
+  unsigned* status;
+  ClusterBwdJob job[MGR_MAX_SCAN_JOBS];
+};
+bool mgr_cluster_bwd_supported(int H);
+size_t mgr_cluster_bwd_img_floats(int H);
+int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs);

@@ -487,16 +487,20 @@ class Engine:
     def _bilstm_backward(self, prefix, dY, lddy, Xin, ldx, fin, Hbuf, ldh, dX, lddx):
         """BPTT + parameter grads of one Bidirectional layer; the two directions run on streams 0 and 1."""
         dev, B, T = self.dev, self.B, self.T
-        dev.wait(1, 0)
-        for di, (dname, st) in enumerate((("fwd", 0), ("bwd", 1))):
+        jobs = []
+        for di, dname in enumerate(("fwd", "bwd")):
             L = self.dirs["%s/%s" % (prefix, dname)]
             H = L.H
-            dev.stream(st)
             dYv = dY.view(di * H, (1,)) if isinstance(dY, DeviceArray) else dY
-            dev.call("mgr_lstm_scan_bwd", dYv, lddy, L.gates, L.cs, L.Up, L.dZ, B, T, H, L.reverse, L.ws_scan,
-                     L.ws_scan.nbytes)
+            jobs.append(dict(dY=dYv, gates=L.gates, cs=L.cs, Up=L.Up, dZ=L.dZ, lddy=lddy, B=B, T=T, H=H,
+                             reverse=L.reverse))
         dev.stream(0)
-        dev.wait(0, 1)
+        arr = _capi.make_scan_bwd_jobs(jobs)   # both directions in ONE call (one persistent launch of CU clusters)
+        need = self.lib.mgr_lstm_scan_bwd_multi_ws_bytes(len(jobs), arr)
+        if getattr(self, "_ws_bwd_multi", None) is None or self._ws_bwd_multi.nbytes < need:
+            self._ws_bwd_multi = self.mem.bytes(need)
+        _capi.check(self.lib.mgr_lstm_scan_bwd_multi(dev.ctx, len(jobs), arr, self._ws_bwd_multi.ptr,
+                                                     self._ws_bwd_multi.nbytes))
         for di, dname in enumerate(("fwd", "bwd")):
             L = self.dirs["%s/%s" % (prefix, dname)]
             H = L.H
