@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--maxlen", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--show-plan", action="store_true")
-    ap.add_argument("--scan-path", type=int, default=0)
+    ap.add_argument("--scan-path", type=int, default=0, help="0 auto, 3/4 clusters of 4/8 tiles, 5 paired batch groups")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-T", type=int, default=400)
     ap.add_argument("--cpu-B", type=int, default=64)

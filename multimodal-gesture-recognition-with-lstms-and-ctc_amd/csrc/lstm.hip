@@ -17,11 +17,11 @@ namespace {
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 struct Cfg {
-  int nw, tpw;
+  int nw, tpw, pair;
 };
-// candidate (active waves, tiles per wave) configurations, most parallel first
-constexpr int NCFG = 4;
-const Cfg kCfgs[NCFG] = {{4, 1}, {8, 1}, {8, 2}, {8, 4}};
+// candidate (active waves, tiles per wave, batch groups per workgroup) configurations
+constexpr int NCFG = 5;
+const Cfg kCfgs[NCFG] = {{4, 1, 1}, {8, 1, 1}, {8, 2, 1}, {8, 4, 1}, {4, 1, 2}};
 
 struct Plan {
   bool cluster[MGR_MAX_SCAN_JOBS];
@@ -52,6 +52,7 @@ void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
     if (ok) {
       ok = false;
       for (int k = 0; k < NCFG; ++k) ok = ok || mgr_cluster_supported(ks, kCfgs[k].tpw);
+      ok = ok || mgr_cluster_pair_supported(ks);
     }
     if (path == 1) ok = false;
     P.cluster[i] = ok;
@@ -65,28 +66,33 @@ void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
   for (int code = 0; code < combos; ++code) {
     int x = code, total = 0;
     long worst = 0, sum = 0;
-    bool feas = true, exch = false;
+    bool feas = true, exch = false, anypair = false;
     for (int k = 0; k < n; ++k) {
       cur[k] = x % NCFG;
       x /= NCFG;
       const mgr_scan_job& j = jobs[idx[k]];
       Cfg f = kCfgs[cur[k]];
       int ks = j.H / 4;
-      if (!mgr_cluster_supported(ks, f.tpw)) feas = false;
+      if (f.pair == 2 ? !mgr_cluster_pair_supported(ks) : !mgr_cluster_supported(ks, f.tpw)) feas = false;
       if (path == 3 && cur[k] != 0) feas = false;
       if (path == 4 && cur[k] != 1) feas = false;
+      if (path == 5 && cur[k] != 4) feas = false;
+      if (path != 5 && f.pair == 2) feas = false;  // measured slower than one group per workgroup: opt-in only
       if (path == 2 && (f.nw * f.tpw < ks)) feas = false;  // force single-CU (no exchange)
       int tiles = f.nw * f.tpw;
       int G = (ks + tiles - 1) / tiles;
       if (G > 64) feas = false;
       if (G > 1) exch = true;
       int nbg = (j.B + 15) / 16;
-      total += G * nbg;
+      if (f.pair == 2 && (G == 1 || nbg < 2)) feas = false;  // pairing only pays when there is a hand-off to hide
+      total += G * ((nbg + f.pair - 1) / f.pair);
+      if (f.pair == 2) anypair = true;
       // per-step estimate in cycles: MFMA chain per SIMD (+15% issue overhead) + cell update + exchange / barrier
       int tiles_here = std::min(tiles, ks);
       int per_simd = (tiles_here + 3) / 4;
       long t = (long)per_simd * ks * 37 + 700 + (G > 1 ? 3300 : 400);
-      if (total > c->cu_count) t += (long)per_simd * ks * 12;  // a second workgroup on the CU competes for the MFMA pipe part of the time
+      if (f.pair == 2) t = 2 * ((long)ks * 37 + 700 + 500);  // two groups back to back, hand-off hidden
+      if (total > c->cu_count && f.pair == 1) t += (long)per_simd * ks * 12;  // a second workgroup on the CU competes for the MFMA pipe part of the time
       worst = std::max(worst, t);
       sum += t;
     }
@@ -97,8 +103,14 @@ void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
       if (kCfgs[cur[k]].nw != 4) all4 = false;
       maxks = std::max(maxks, jobs[idx[k]].H / 4);
     }
-    size_t lds2 = (size_t)2 * ((maxks + 3) / 4) * 1024;
+    size_t lds2 = (size_t)(anypair ? 4 : 2) * ((maxks + 3) / 4) * 1024;
     int capacity = (all4 && lds2 <= 80 * 1024) ? 2 * c->cu_count : c->cu_count;
+    // the paired kernel is its own launch configuration (4 waves, one workgroup per CU): all jobs or none
+    bool allpair = true;
+    for (int k = 0; k < n; ++k)
+      if (kCfgs[cur[k]].pair != 2) allpair = false;
+    if (anypair && !allpair) feas = false;
+    if (anypair) capacity = c->cu_count;
     if (!feas || (exch && total > capacity)) continue;
     long cost = worst * 1000 + sum / n;
     if (best_cost < 0 || cost < best_cost) {
@@ -116,7 +128,7 @@ void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
     int tiles = P.cfg[i].nw * P.cfg[i].tpw;
     P.G[i] = (jobs[i].H / 4 + tiles - 1) / tiles;
     P.nbg[i] = (jobs[i].B + 15) / 16;
-    P.wgs[i] = P.G[i] * P.nbg[i];
+    P.wgs[i] = P.G[i] * ((P.nbg[i] + P.cfg[i].pair - 1) / P.cfg[i].pair);
     P.total += P.wgs[i];
     if (P.G[i] > 1) P.exchange = true;
   }
@@ -200,7 +212,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
       size_t img = (size_t)((ks + 3) / 4) * 256;
       cj.Z = j.Z; cj.Up = j.Up; cj.Y = j.Y; cj.R = j.R; cj.G = j.gates; cj.Cs = j.cs;
       cj.ldy = j.ldy; cj.ldr = j.ldr; cj.B = j.B; cj.T = j.T; cj.H = j.H; cj.reverse = j.reverse;
-      cj.ks = ks; cj.tpw = P.cfg[i].tpw; cj.nw = P.cfg[i].nw;
+      cj.ks = ks; cj.tpw = P.cfg[i].tpw; cj.nw = P.cfg[i].nw; cj.pair = P.cfg[i].pair;
       cj.wg_begin = begin; cj.G_ = P.G[i]; cj.nbg = P.nbg[i];
       begin += P.wgs[i];
       cj.flags = reinterpret_cast<unsigned*>(w);
@@ -211,8 +223,8 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     L.status = status;
     if (c->tune[2]) {  // tune key 2: print the plan
       for (int i = 0; i < L.njobs; ++i)
-        fprintf(stderr, "[mgr scan plan] job %d: H=%d ks=%d nw=%d tpw=%d G=%d nbg=%d wgs=[%d,%d)\n", i, L.job[i].H, L.job[i].ks,
-                L.job[i].nw, L.job[i].tpw, L.job[i].G_, L.job[i].nbg, L.job[i].wg_begin, L.job[i].wg_begin + L.job[i].G_ * L.job[i].nbg);
+        fprintf(stderr, "[mgr scan plan] job %d: H=%d ks=%d nw=%d tpw=%d pair=%d G=%d nbg=%d wg_begin=%d\n", i, L.job[i].H,
+                L.job[i].ks, L.job[i].nw, L.job[i].tpw, L.job[i].pair, L.job[i].G_, L.job[i].nbg, L.job[i].wg_begin);
       fprintf(stderr, "[mgr scan plan] total %d workgroups, exchange=%d\n", P.total, (int)P.exchange);
     }
     // flags + status must be zero at every launch (epochs count from 1 within the call)

@@ -18,6 +18,7 @@ struct ClusterJob {
   int wg_begin;     // first blockIdx of this job
   int G_;           // workgroups per cluster (one cluster = one 16-sample batch group)
   int nbg;          // batch groups
+  int pair;         // batch groups per workgroup: 1, or 2 = software-pipelined pair (cluster_run2)
 };
 
 struct ClusterLaunch {
@@ -28,6 +29,7 @@ struct ClusterLaunch {
 
 // true if (ks, tpw) has an instantiation
 bool mgr_cluster_supported(int ks, int tpw);
+bool mgr_cluster_pair_supported(int ks);
 int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool any_exchange);
 
 // ---- backward (lstm_cluster_bwd.hip)

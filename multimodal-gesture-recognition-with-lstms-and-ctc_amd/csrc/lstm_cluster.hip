@@ -286,6 +286,242 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float*
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Two batch groups per workgroup, software-pipelined, with dedicated gather waves.
+// The workgroup keeps ONE copy of its U^T fragments (compute waves 0-3, one tile each) and alternates between batch
+// groups A and B of the same direction.  Waves 4-7 never compute and never store to global memory: while the compute
+// waves run group A's MFMA chain + cell update, the gather waves poll and fetch group B's h_{t-1} from the cluster's
+// exchange slot into B's next LDS image, and vice versa; one barrier per half-step joins the two roles.  The hand-off
+// flight (write-through store -> sc1 load, ~2-4k cycles under load) is thereby hidden behind the other group's MFMA
+// work, and - because the gather waves issue no stores - their s_waitcnt never waits on a store acknowledgement (in
+// the one-group kernel the compiler's vmcnt(0) in front of the gathered data also drains the wave's own sc1 stores).
+// Cost: 2 x 16 samples per workgroup, i.e. half as many CUs per job; the MFMA pipe becomes the bound.
+template <int KS>
+__device__ __forceinline__ void cluster_run2(const ClusterJob& jb, int wg, float* smem, unsigned* status) {
+  constexpr int H = 4 * KS, N = 4 * H, QN = (KS + 3) / 4, IMG = QN * 256;
+  constexpr int NGW = 3;   // gather waves (5, 6, 7); wave 4 publishes
+  constexpr int NF = 11;   // gather loads in flight per gather wave
+  static_assert(QN <= NGW * NF, "gather covers at most 33 image blocks");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0-3 compute, 4 publish, 5-7 gather
+  const bool is_compute = wave < 4;
+  const int j = lane & 15, uq = lane >> 4;
+  const int G = jb.G_;
+  const int pr = wg / G, ug = wg % G;   // pair index, unit group
+  const int B = jb.B, T = jb.T, reverse = jb.reverse;
+  const float* __restrict__ Z = jb.Z;
+  const int tile = ug * 4 + (wave & 3);
+  const bool tvalid = is_compute && tile < KS;  // wave-uniform
+  const int tl = tile < KS ? tile : 0;
+  float uf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) uf[s] = tvalid ? jb.Up[(size_t)(4 * s + uq) * N + tl * 16 + j] : 0.f;
+  float* img = smem;  // [group][2][IMG]
+  for (int i = tid; i < 4 * IMG; i += 512) img[i] = 0.f;
+  const int q0 = ug;  // own image block (4 tiles = 1 block)
+  const int unit = tl * 4 + uq;
+  const int idx_own = (((tl >> 2) * 4 + uq) * 16 + j) * 4 + (tl & 3);
+
+  int bgi[2], bcl[2];
+  bool gvalid[2], bvalid[2];
+  __amdgpu_buffer_rsrc_t rs[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    bgi[g] = pr * 2 + g;
+    gvalid[g] = bgi[g] < jb.nbg;  // workgroup-uniform
+    const int b = bgi[g] * 16 + j;
+    bvalid[g] = gvalid[g] && b < B;
+    bcl[g] = b < B ? b : B - 1;
+    rs[g] = __builtin_amdgcn_make_buffer_rsrc(jb.xbuf + (size_t)(gvalid[g] ? bgi[g] : 0) * 2 * IMG, 0, 2 * IMG * 4, 0x00020000);
+  }
+  float c[2] = {0.f, 0.f};
+  f32x4 zr[2][3];
+  auto loadz = [&](f32x4& z, int g, int step) {
+    if (tvalid && gvalid[g] && step < T) {
+      const int t = reverse ? T - 1 - step : step;
+      z = *reinterpret_cast<const f32x4*>(Z + ((size_t)bcl[g] * T + t) * N + unit * 4);
+    }
+  };
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) zr[g][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    loadz(zr[g][0], g, 0);
+    loadz(zr[g][1], g, 1);
+  }
+  bool failed = false;
+  __syncthreads();
+#ifdef MGR_STAMP
+  unsigned long long st2_comp = 0, st2_fin = 0, st2_bar = 0, st2_retry = 0;
+#endif
+
+  // ---- gather role: fetch group g's h_step into its next image; returns when every block carries the epoch parity
+  auto gather = [&](int g, int step) {
+    if (!(G > 1 && gvalid[g] && step >= 0 && step + 1 < T)) return;  // workgroup-uniform
+    const int gw = wave - 5;
+    const int slot = step & 1;
+    const unsigned par = (((unsigned)step >> 1) & 1u) ^ 1u;
+    float* hn = img + (g * 2 + ((step + 1) & 1)) * IMG;
+    u32x4 gv[NF];
+    unsigned pend = 0;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      const int q = gw + NGW * i;
+      if (q < QN && q != q0) pend |= 1u << i;
+    }
+    unsigned spins = 0;
+    // the peers publish this epoch right after the barrier we just left; polling earlier than the store->load flight
+    // only adds fabric traffic that delays those very stores
+    __builtin_amdgcn_s_sleep(48);
+    while (pend && !failed) {
+#pragma unroll
+      for (int i = 0; i < NF; ++i)
+        if (pend & (1u << i))
+          gv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs[g], (slot * IMG + (gw + NGW * i) * 256 + lane * 4) * 4, 0, 16);  // sc1
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        if (pend & (1u << i)) {
+          const int q = gw + NGW * i;
+          const int nvalid = KS - 4 * q;
+          unsigned a = par ? 0xFFFFFFFFu : 0u;
+          if (par) {
+            a &= gv[i].x;
+            if (nvalid > 1) a &= gv[i].y;
+            if (nvalid > 2) a &= gv[i].z;
+            if (nvalid > 3) a &= gv[i].w;
+          } else {
+            a |= gv[i].x;
+            if (nvalid > 1) a |= gv[i].y;
+            if (nvalid > 2) a |= gv[i].z;
+            if (nvalid > 3) a |= gv[i].w;
+          }
+          if (__all((a & 1u) == par)) {
+            *reinterpret_cast<u32x4*>(hn + q * 256 + lane * 4) = gv[i];
+            pend &= ~(1u << i);
+          }
+        }
+      }
+      if (pend) {
+#ifdef MGR_STAMP
+        st2_retry += 1;
+#endif
+        __builtin_amdgcn_s_sleep(2);
+        ++spins;
+        if ((spins & 255u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) failed = true;
+        if (spins > POLL_LIMIT) {
+          failed = true;
+          if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  };
+  // ---- publisher role (wave 4): after the barrier that completes group g's own slice in LDS, copy the workgroup's
+  // 1 KiB block to the exchange slot as eight whole 128-byte lines (one 16-byte sc1 store per lane).  Full-line
+  // write-through keeps the memory side free of the 256 partial-line writes per step that 4-byte stores would cost.
+  auto publish = [&](int g, int step) {
+    if (!(G > 1 && gvalid[g] && step >= 0 && step + 1 < T) || q0 >= QN) return;
+    const float* hn = img + (g * 2 + ((step + 1) & 1)) * IMG;
+    u32x4 v = *reinterpret_cast<const u32x4*>(hn + q0 * 256 + lane * 4);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs[g], ((step & 1) * IMG + q0 * 256 + lane * 4) * 4, 0, 16);  // sc1
+  };
+  // ---- compute role: one time step of group g
+  auto compute = [&](int g, int step, f32x4& zuse, f32x4& zload) {
+    if (!gvalid[g]) return;  // workgroup-uniform
+    const int t = reverse ? T - 1 - step : step;
+    loadz(zload, g, step + 2);
+    if (!tvalid) return;  // wave-uniform
+    const float* hb = img + (g * 2 + (step & 1)) * IMG;
+    float* hn = img + (g * 2 + ((step + 1) & 1)) * IMG;
+    f32x4 acc = zuse, acc2 = {0.f, 0.f, 0.f, 0.f};
+    {
+      constexpr int PD = 3;
+      f32x4 hbuf[4];
+      const float* hlane = hb + (uq * 16 + j) * 4;
+#pragma unroll
+      for (int q = 0; q < PD && q < QN; ++q) hbuf[q] = *reinterpret_cast<const f32x4*>(hlane + q * 256);
+#pragma unroll
+      for (int q = 0; q < QN; ++q) {
+        if (q + PD < QN) hbuf[(q + PD) & 3] = *reinterpret_cast<const f32x4*>(hlane + (q + PD) * 256);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 hv = hbuf[q & 3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (4 * q + r < KS) {
+            if (r & 1)
+              acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[4 * q + r], hv[r], acc2, 0, 0, 0);
+            else
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[4 * q + r], hv[r], acc, 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      acc += acc2;
+    }
+    float4 g4;
+    float h = mgr_cell_fwd(acc[0], acc[1], acc[2], acc[3], c[g], g4);
+    if (G > 1) {
+      const unsigned par = (((unsigned)step >> 1) & 1u) ^ 1u;
+      const unsigned hbits = (__float_as_uint(h) & ~1u) | par;
+      h = __uint_as_float(hbits);   // published after the barrier by the publisher wave, as whole 128-byte lines
+    }
+    hn[idx_own] = h;
+    if (bvalid[g]) {
+      const size_t row = (size_t)(bgi[g] * 16 + j) * T + t;
+      float yo = h;
+      if (jb.R) yo += jb.R[row * jb.ldr + unit];
+      jb.Y[row * jb.ldy + unit] = yo;
+      if (jb.G) *reinterpret_cast<float4*>(jb.G + (row * H + unit) * 4) = g4;
+      if (jb.Cs) jb.Cs[row * H + unit] = c[g];
+    }
+  };
+  auto do_step = [&](int step, f32x4& zua, f32x4& zla, f32x4& zub, f32x4& zlb) {
+#ifdef MGR_STAMP
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+    if (is_compute)
+      compute(0, step, zua, zla);     // A's step ...
+    else if (wave == 4)
+      publish(1, step - 1);           // ... B's h_{t-1} block (completed at the last barrier) goes out ...
+    else
+      gather(1, step - 1);            // ... and the peers' B blocks come in
+#ifdef MGR_STAMP
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
+    __syncthreads();
+#ifdef MGR_STAMP
+    unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
+    if (is_compute)
+      compute(1, step, zub, zlb);     // B's step ...
+    else if (wave == 4)
+      publish(0, step);
+    else
+      gather(0, step);                // ... while A's h_t arrives
+#ifdef MGR_STAMP
+    unsigned long long t3 = __builtin_amdgcn_s_memtime();
+#endif
+    __syncthreads();
+#ifdef MGR_STAMP
+    unsigned long long t4 = __builtin_amdgcn_s_memtime();
+    st2_comp += (t1 - t0) + (t3 - t2);
+    st2_bar += (t2 - t1) + (t4 - t3);
+#endif
+  };
+  for (int s0 = 0; s0 < T; s0 += 3) {
+    do_step(s0, zr[0][0], zr[0][2], zr[1][0], zr[1][2]);
+    if (s0 + 1 < T) do_step(s0 + 1, zr[0][1], zr[0][0], zr[1][1], zr[1][0]);
+    if (s0 + 2 < T) do_step(s0 + 2, zr[0][2], zr[0][1], zr[1][2], zr[1][1]);
+  }
+#ifdef MGR_STAMP
+  if (lane == 0 && wg < 2) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(status + 16) + (wg * 8 + wave) * 8;
+    dbg[0] = st2_comp; dbg[1] = st2_comp; dbg[2] = st2_fin; dbg[3] = st2_bar; dbg[4] = st2_retry;
+  }
+#endif
+}
+
+#define CL2_FOREACH(X) X(125) X(75) X(32) X(25) X(8)
+
 #define CL_FOREACH(X) \
   X(125, 1) X(75, 1) X(75, 2) X(32, 1) X(32, 2) X(32, 4) X(25, 1) X(25, 2) X(25, 4) X(16, 1) X(16, 2) X(8, 1) X(8, 2) \
   X(4, 1) X(3, 1) X(2, 1) X(1, 1)
@@ -305,7 +541,31 @@ __global__ __launch_bounds__(CL_WAVES * 64) void k_scan_cluster(ClusterLaunch L)
 #undef CL_CASE
 }
 
+// pair mode: 4 compute + 4 gather waves, one workgroup per CU
+__global__ __launch_bounds__(512) void k_scan_cluster2(ClusterLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int bid = blockIdx.x;
+  int ji = 0;
+  for (int k = 1; k < L.njobs; ++k)
+    if (bid >= L.job[k].wg_begin) ji = k;
+  const ClusterJob& jb = L.job[ji];
+  const int wg = bid - jb.wg_begin;
+  if (wg >= jb.G_ * ((jb.nbg + 1) / 2)) return;
+#define CL2_CASE(KS) \
+  if (jb.ks == KS) return cluster_run2<KS>(jb, wg, smem, L.status);
+  CL2_FOREACH(CL2_CASE)
+#undef CL2_CASE
+}
+
 }  // namespace
+
+bool mgr_cluster_pair_supported(int ks) {
+#define CL2_CASE(KS) \
+  if (ks == KS) return true;
+  CL2_FOREACH(CL2_CASE)
+#undef CL2_CASE
+  return false;
+}
 
 bool mgr_cluster_supported(int ks, int tpw) {
 #define CL_CASE(KS, TPW) \
@@ -322,13 +582,17 @@ int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool a
     maxnw = L.job[i].nw > maxnw ? L.job[i].nw : maxnw;
   }
   const int waves = maxnw <= 4 ? 4 : CL_WAVES;
-  size_t img = (size_t)((maxks + 3) / 4) * 256 * sizeof(float);
-  size_t lds = 2 * img;
+  size_t lds = 0;
+  for (int i = 0; i < L.njobs; ++i) {
+    size_t img = (size_t)((L.job[i].ks + 3) / 4) * 256 * sizeof(float);
+    size_t need = (L.job[i].pair == 2 ? 4 : 2) * img;
+    lds = need > lds ? need : lds;
+  }
   int per_cu = 1;
   if (any_exchange) {
     // co-residency of every spinning workgroup is what makes the in-launch hand-off deadlock-free.  4-wave workgroups
     // with <= 80 KiB of LDS fit two per CU (8 waves, <= 256 VGPRs each); otherwise force one per CU through the LDS size.
-    if (waves == 4 && lds <= 80 * 1024) {
+    if (waves == 4 && lds <= 80 * 1024 && L.job[0].pair != 2) {
       per_cu = 2;
     } else if (lds < 84 * 1024) {
       lds = 84 * 1024;
@@ -339,9 +603,15 @@ int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool a
   static bool attr_set = false;
   if (!attr_set) {
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_scan_cluster, dim3(total_wgs), dim3(waves * 64), lds, mgr_stream(c), L);
+  bool pair = L.njobs > 0 && L.job[0].pair == 2;
+  for (int i = 0; i < L.njobs; ++i) MGR_REQUIRE((L.job[i].pair == 2) == pair, "paired and unpaired jobs cannot share a launch");
+  if (pair)
+    hipLaunchKernelGGL(k_scan_cluster2, dim3(total_wgs), dim3(512), lds, mgr_stream(c), L);
+  else
+    hipLaunchKernelGGL(k_scan_cluster, dim3(total_wgs), dim3(waves * 64), lds, mgr_stream(c), L);
   MGR_LAUNCH_CHECK();
   return 0;
 }

@@ -240,7 +240,7 @@ def test_adam_maxnorm_noise_argmax(device):
     assert np.array_equal(best.download(), P[:, 2:].argmax(-1)) and np.array_equal(prob.download(), P[:, 2:].max(-1))
 
 
-@pytest.mark.parametrize("B,T,H,path", [(5, 9, 32, 3), (33, 6, 32, 3), (17, 7, 100, 3), (17, 7, 100, 4), (20, 5, 300, 0),
+@pytest.mark.parametrize("B,T,H,path", [(5, 9, 32, 3), (33, 6, 32, 3), (17, 7, 100, 3), (17, 7, 100, 4), (20, 5, 300, 0), (40, 7, 32, 5), (64, 6, 100, 5), (33, 5, 500, 5), (64, 4, 300, 5),
                                         (18, 5, 500, 0), (64, 4, 500, 3), (3, 6, 12, 3)])
 def test_cluster_scan_matches_oracle(device, B, T, H, path):
     """Persistent multi-CU scan (per-step sc1 hand-off between workgroups) vs the oracle, both directions in ONE launch."""
