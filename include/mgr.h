@@ -108,9 +108,12 @@ size_t mgr_lstm_scan_multi_ws_bytes(int njobs, const mgr_scan_job* jobs);
 int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, void* ws, size_t ws_bytes);
 /* Tuning / test hooks.  key 0 (MGR_TUNE_SCAN_PATH): 0 auto, 1 force the L2-streaming fallback kernels,
  * 2 force one workgroup per batch group (no inter-CU exchange) where it fits, 3 force clusters with 4 tiles per
- * workgroup, 4 same with 8 tiles per workgroup.  key 1: !=0 makes scan_fwd check the give-up word synchronously. */
+ * workgroup, 4 same with 8 tiles per workgroup.  key 1: !=0 makes scan_fwd check the give-up word synchronously.
+ * key 2: print the scan plan.  key 3: opt into the XCD-local exchange path (measured slower; kept for study). */
 enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 4 };
 int mgr_tune(mgr_ctx* ctx, int key, int value);
+/* Diagnostic: out[b] = XCC (XCD) id the workgroup b of a (nblocks, threads, lds_bytes) launch ran on. */
+int mgr_probe_xcc(mgr_ctx* ctx, int nblocks, int threads, int lds_bytes, int32_t* out);
 /* BPTT: dY[b,t,0:H] (row stride lddy) is dLoss/dh_t from above; Y (stride ldy) is the layer's own output as
  * written by scan_fwd WITHOUT residual (needed only through gates/cs here).  Produces dZ [B,T,4H] packed. */
 int mgr_lstm_scan_bwd(mgr_ctx* ctx, const float* dY, int lddy, const float* gates, const float* cs,

@@ -149,9 +149,24 @@ __global__ void k_frame_argmax(const float* __restrict__ P, int B, int T, int C,
   }
 }
 
+__global__ void k_probe_xcc(int32_t* out) {
+  extern __shared__ float dummy[];
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  if (threadIdx.x == 0) out[blockIdx.x] = (int32_t)(x & 0xF);
+}
+
 }  // namespace
 
 extern "C" {
+
+int mgr_probe_xcc(mgr_ctx* c, int nblocks, int threads, int lds_bytes, int32_t* out) {
+  MGR_REQUIRE(c && out && nblocks > 0 && threads > 0, "bad argument");
+  MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_xcc), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipLaunchKernelGGL(k_probe_xcc, dim3(nblocks), dim3(threads), lds_bytes, mgr_stream(c), out);
+  MGR_LAUNCH_CHECK();
+  return 0;
+}
 
 int mgr_add_gaussian_noise(mgr_ctx* c, const float* X, float* Y, size_t n, float stddev, uint64_t seed) {
   MGR_REQUIRE(c && X && Y, "null argument");

@@ -14,6 +14,8 @@ int mgr_scan_bwd_mfma(mgr_ctx*, const float*, int, const float*, const float*, c
 
 namespace {
 
+constexpr size_t kScanHdrBytes = 8192;  // [0,2048): status + stamps; [2048,8192): XCC id per workgroup of the launch
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 struct Cfg {
@@ -153,7 +155,7 @@ static size_t bwd_job_ws(const mgr_scan_bwd_job& j) {
 }
 
 size_t mgr_lstm_scan_bwd_multi_ws_bytes(int njobs, const mgr_scan_bwd_job* jobs) {
-  size_t s = 2048;
+  size_t s = kScanHdrBytes;
   for (int i = 0; i < njobs; ++i) s += bwd_job_ws(jobs[i]);
   return s;
 }
@@ -169,11 +171,11 @@ size_t mgr_lstm_scan_ws_bytes(int B, int T, int H) {
   memset(&bj, 0, sizeof(bj));
   bj.B = B;
   bj.H = H;
-  return std::max(std::max(fallback, job_ws(j) + 2048), mgr_lstm_scan_bwd_multi_ws_bytes(1, &bj));
+  return std::max(std::max(fallback, job_ws(j) + kScanHdrBytes), mgr_lstm_scan_bwd_multi_ws_bytes(1, &bj));
 }
 
 size_t mgr_lstm_scan_multi_ws_bytes(int njobs, const mgr_scan_job* jobs) {
-  size_t s = 2048;  // status word + diagnostic stamps
+  size_t s = kScanHdrBytes;  // status word + diagnostic stamps + XCC table
   for (int i = 0; i < njobs; ++i) s += job_ws(jobs[i]);
   return s;
 }
@@ -202,8 +204,43 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     char* w = reinterpret_cast<char*>(ws);
     status = reinterpret_cast<unsigned*>(w);
     char* base = w;
-    w += 2048;
-    int begin = 0;
+    L.xcc = reinterpret_cast<unsigned*>(w + 2048);
+    w += kScanHdrBytes;
+    // classes: cluster jobs with identical geometry (same H and configuration, e.g. the two directions of a layer) share
+    // one XCD-interleaved workgroup range
+    int cls_of[MGR_MAX_SCAN_JOBS], ncls = 0, cls_first[MGR_MAX_SCAN_JOBS], cls_clusters[MGR_MAX_SCAN_JOBS];
+    for (int i = 0; i < njobs; ++i) {
+      if (!P.cluster[i]) continue;
+      int found = -1;
+      for (int k = 0; k < ncls; ++k) {
+        int f = cls_first[k];
+        if (jobs[f].H == jobs[i].H && P.cfg[f].nw == P.cfg[i].nw && P.cfg[f].tpw == P.cfg[i].tpw &&
+            P.cfg[f].pair == P.cfg[i].pair)
+          found = k;
+      }
+      if (found < 0) {
+        found = ncls++;
+        cls_first[found] = i;
+        cls_clusters[found] = 0;
+      }
+      cls_of[i] = found;
+      cls_clusters[found] += P.nbg[i];
+    }
+    int cls_begin[MGR_MAX_SCAN_JOBS], begin = 0, cls_next[MGR_MAX_SCAN_JOBS];
+    for (int k = 0; k < ncls; ++k) {
+      begin = (begin + 7) / 8 * 8;  // keep every class aligned to the 8-XCD round-robin
+      cls_begin[k] = begin;
+      cls_next[k] = 0;
+      int f = cls_first[k];
+      int per = cls_clusters[k];
+      if (P.cfg[f].pair == 2) {  // pair mode maps job-major: every member job rounds its own batch groups up to pairs
+        per = 0;
+        for (int i = 0; i < njobs; ++i)
+          if (P.cluster[i] && cls_of[i] == k) per += (P.nbg[i] + 1) / 2;
+      }
+      begin += P.G[f] * per;
+    }
+    P.total = begin;
     for (int i = 0; i < njobs; ++i) {
       if (!P.cluster[i]) continue;
       const mgr_scan_job& j = jobs[i];
@@ -213,14 +250,25 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
       cj.Z = j.Z; cj.Up = j.Up; cj.Y = j.Y; cj.R = j.R; cj.G = j.gates; cj.Cs = j.cs;
       cj.ldy = j.ldy; cj.ldr = j.ldr; cj.B = j.B; cj.T = j.T; cj.H = j.H; cj.reverse = j.reverse;
       cj.ks = ks; cj.tpw = P.cfg[i].tpw; cj.nw = P.cfg[i].nw; cj.pair = P.cfg[i].pair;
-      cj.wg_begin = begin; cj.G_ = P.G[i]; cj.nbg = P.nbg[i];
-      begin += P.wgs[i];
+      cj.G_ = P.G[i]; cj.nbg = P.nbg[i];
+      const int k = cls_of[i];
+      cj.cls_begin = cls_begin[k];
+      cj.cls_nclusters = cls_clusters[k];
+      cj.cls_cluster0 = cls_next[k];
+      cj.wg_begin = cls_begin[k];  // (pair mode maps job-major inside its class range)
+      if (cj.pair == 2) {
+        cj.wg_begin = cls_begin[k] + P.G[i] * cls_next[k];
+        cls_next[k] += (P.nbg[i] + 1) / 2;
+      } else {
+        cls_next[k] += P.nbg[i];
+      }
       cj.flags = reinterpret_cast<unsigned*>(w);
       w += mgr_align_up((size_t)P.nbg[i] * 64 * sizeof(unsigned), 256);
       cj.xbuf = reinterpret_cast<float*>(w);
       w += mgr_align_up((size_t)P.nbg[i] * 2 * img * sizeof(float), 256);
     }
     L.status = status;
+    L.xcd_local = c->tune[3];
     if (c->tune[2]) {  // tune key 2: print the plan
       for (int i = 0; i < L.njobs; ++i)
         fprintf(stderr, "[mgr scan plan] job %d: H=%d ks=%d nw=%d tpw=%d pair=%d G=%d nbg=%d wg_begin=%d\n", i, L.job[i].H,
@@ -272,10 +320,12 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
   char* w = reinterpret_cast<char*>(ws);
   char* base = w;
   unsigned* status = reinterpret_cast<unsigned*>(w);
-  w += 2048;
+  w += kScanHdrBytes;
   ClusterBwdLaunch L;
   memset(&L, 0, sizeof(L));
   L.status = status;
+  L.xcc = reinterpret_cast<unsigned*>(base + 2048);
+  L.xcd_local = c->tune[3];
   int total = 0;
   bool use_cluster[MGR_MAX_SCAN_JOBS];
   // cluster kernel when instantiated and the whole launch is co-resident (two 4-wave workgroups per CU)
@@ -284,22 +334,48 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
     use_cluster[i] = (path == 0 || path == 3) && mgr_cluster_bwd_supported(j.H);
     if (use_cluster[i]) total += ((j.H + 15) / 16) * ((j.B + 15) / 16);
   }
-  if (total > 2 * c->cu_count)
+  if (total + 8 * njobs > 2 * c->cu_count)
     for (int i = 0; i < njobs; ++i) use_cluster[i] = false;
   char* wj[MGR_MAX_SCAN_JOBS];
   for (int i = 0; i < njobs; ++i) {
     wj[i] = w;
     w += bwd_job_ws(jobs[i]);
   }
-  int begin = 0;
+  // classes of identical geometry (the two directions of a layer) share one XCD-interleaved workgroup range
+  int cls_of[MGR_MAX_SCAN_JOBS], ncls = 0, cls_first[MGR_MAX_SCAN_JOBS], cls_clusters[MGR_MAX_SCAN_JOBS];
+  for (int i = 0; i < njobs; ++i) {
+    if (!use_cluster[i]) continue;
+    int found = -1;
+    for (int k = 0; k < ncls; ++k)
+      if (jobs[cls_first[k]].H == jobs[i].H) found = k;
+    if (found < 0) {
+      found = ncls++;
+      cls_first[found] = i;
+      cls_clusters[found] = 0;
+    }
+    cls_of[i] = found;
+    cls_clusters[found] += (jobs[i].B + 15) / 16;
+  }
+  int cls_begin[MGR_MAX_SCAN_JOBS], cls_next[MGR_MAX_SCAN_JOBS], begin = 0;
+  for (int k = 0; k < ncls; ++k) {
+    begin = (begin + 7) / 8 * 8;
+    cls_begin[k] = begin;
+    cls_next[k] = 0;
+    begin += ((jobs[cls_first[k]].H + 15) / 16) * cls_clusters[k];
+  }
   for (int i = 0; i < njobs; ++i) {
     if (!use_cluster[i]) continue;
     const mgr_scan_bwd_job& j = jobs[i];
     ClusterBwdJob& cj = L.job[L.njobs++];
     cj.dY = j.dY; cj.gates = j.gates; cj.cs = j.cs; cj.Up = j.Up; cj.dZ = j.dZ;
     cj.lddy = j.lddy; cj.B = j.B; cj.T = j.T; cj.H = j.H; cj.reverse = j.reverse;
-    cj.G_ = (j.H + 15) / 16; cj.nbg = (j.B + 15) / 16; cj.wg_begin = begin;
-    begin += cj.G_ * cj.nbg;
+    cj.G_ = (j.H + 15) / 16; cj.nbg = (j.B + 15) / 16;
+    const int k = cls_of[i];
+    cj.cls_begin = cls_begin[k];
+    cj.cls_nclusters = cls_clusters[k];
+    cj.cls_cluster0 = cls_next[k];
+    cj.wg_begin = cls_begin[k];
+    cls_next[k] += cj.nbg;
     cj.xbuf = reinterpret_cast<float*>(wj[i]);
   }
   if (L.njobs > 0) {

@@ -42,7 +42,8 @@ constexpr int CL_WAVES = 8;
 constexpr unsigned POLL_LIMIT = 1u << 20;
 
 template <int KS, int TPW>
-__device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float* smem, unsigned* status) {
+__device__ __forceinline__ void cluster_run(const ClusterJob& jb, int bg, int ug, int cl, unsigned* xcc, int xcd_local,
+                                            float* smem, unsigned* status) {
   constexpr int H = 4 * KS, N = 4 * H, QN = (KS + 3) / 4, IMG = QN * 256;
   static_assert(QN <= 32, "gather sweep covers at most 32 image blocks (H <= 512)");
   const int tid = threadIdx.x, lane = tid & 63;
@@ -50,9 +51,11 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float*
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches
   const int j = lane & 15, uq = lane >> 4;
   const int G = jb.G_;
-  const int bg = wg / G, ug = wg % G;
   const int nw = jb.nw;
   const int tpwg = nw * TPW;  // tiles per workgroup, a multiple of 4
+  // XCD-local exchange (plain stores into the shared L2 + nt loads) measured SLOWER than write-through on MI355X
+  // (65-71 vs 58 ms per F step: the 64 KiB slot hammers a few L2 channels), so it is opt-in (mgr_tune key 3)
+  const bool fast = xcd_local && mgr_cluster_same_xcd(xcc, blockIdx.x, jb.cls_begin, jb.cls_nclusters, cl, G, status);
   const int B = jb.B, T = jb.T, reverse = jb.reverse;
   const int b = bg * 16 + j;
   const bool bvalid = b < B;
@@ -189,7 +192,12 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float*
         if (G > 1) {
           const unsigned hbits = (__float_as_uint(h) & ~1u) | par;  // epoch parity rides in the mantissa LSB
           h = __uint_as_float(hbits);
-          if (step + 1 < T) __builtin_amdgcn_raw_buffer_store_b32(hbits, rs, (slot * IMG + idx) * 4, 0, 16);  // sc1
+          if (step + 1 < T) {
+            if (fast)  // whole cluster on one XCD: a plain store lands in the L2 every peer's sc1 load is served from
+              *reinterpret_cast<volatile unsigned*>(xb + slot * IMG + idx) = hbits;
+            else
+              __builtin_amdgcn_raw_buffer_store_b32(hbits, rs, (slot * IMG + idx) * 4, 0, 16);  // sc1 write-through
+          }
         }
         hn[idx] = h;
         if (bvalid) {
@@ -220,7 +228,8 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float*
 #pragma unroll
           for (int i = 0; i < NF; ++i)
             if (pend & (1u << i))
-              v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (slot * IMG + (base + wave + nwv * i) * 256 + lane * 4) * 4, 0, 16);  // sc1
+              v[i] = fast ? __builtin_amdgcn_raw_buffer_load_b128(rs, (slot * IMG + (base + wave + nwv * i) * 256 + lane * 4) * 4, 0, 2)    // nt: L1 bypass, served by the XCD's L2
+                          : __builtin_amdgcn_raw_buffer_load_b128(rs, (slot * IMG + (base + wave + nwv * i) * 256 + lane * 4) * 4, 0, 16);  // sc1
 #pragma unroll
           for (int i = 0; i < NF; ++i) {
             if (pend & (1u << i)) {
@@ -279,8 +288,8 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int wg, float*
     if (s0 + 2 < T) do_step(s0 + 2, zr2, zr1);
   }
 #ifdef MGR_STAMP
-  if (lane == 0 && wg < 2) {
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(status + 16) + (wg * 8 + wave) * 8;
+  if (lane == 0 && ug == 0 && bg < 2 && jb.cls_cluster0 == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(status + 16) + (bg * 8 + wave) * 8;
     dbg[0] = st_mfma; dbg[1] = st_cell; dbg[2] = st_gather; dbg[3] = st_bar; dbg[4] = st_passes;
   }
 #endif
@@ -529,16 +538,23 @@ __device__ __forceinline__ void cluster_run2(const ClusterJob& jb, int wg, float
 __global__ __launch_bounds__(CL_WAVES * 64) void k_scan_cluster(ClusterLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = blockIdx.x;
-  int ji = 0;
-  for (int k = 1; k < L.njobs; ++k)
-    if (bid >= L.job[k].wg_begin) ji = k;
-  const ClusterJob& jb = L.job[ji];
-  const int wg = bid - jb.wg_begin;
-  if (wg >= jb.G_ * jb.nbg) return;
+  // class-interleaved mapping: (w - cls_begin) % cls_nclusters = cluster within the class, / = unit group
+  for (int k = 0; k < L.njobs; ++k) {
+    const ClusterJob& jb = L.job[k];
+    const int w = bid - jb.cls_begin;
+    if (w < 0 || w >= jb.cls_nclusters * jb.G_) continue;
+    // members of a cluster are CONTIGUOUS workgroup ids by default (the round-robin dispatcher then spreads them over
+    // all XCDs, which measured best for the write-through exchange); the XCD-local experiment interleaves them instead
+    const int cl = L.xcd_local ? w % jb.cls_nclusters : w / jb.G_;
+    const int ug = L.xcd_local ? w / jb.cls_nclusters : w % jb.G_;
+    const int bg = cl - jb.cls_cluster0;
+    if (bg < 0 || bg >= jb.nbg) continue;
 #define CL_CASE(KS, TPW) \
-  if (jb.ks == KS && jb.tpw == TPW) return cluster_run<KS, TPW>(jb, wg, smem, L.status);
-  CL_FOREACH(CL_CASE)
+  if (jb.ks == KS && jb.tpw == TPW) return cluster_run<KS, TPW>(jb, bg, ug, cl, L.xcc, L.xcd_local, smem, L.status);
+    CL_FOREACH(CL_CASE)
 #undef CL_CASE
+    return;
+  }
 }
 
 // pair mode: 4 compute + 4 gather waves, one workgroup per CU

@@ -20,7 +20,8 @@ constexpr unsigned POLL_LIMIT = 1u << 20;
 constexpr int BW_WAVES = 4;
 
 template <int H>
-__device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int wg, float* smem, unsigned* status) {
+__device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg, int ug, int cl, unsigned* xcc, int xcd_local,
+                                                float* smem, unsigned* status) {
   constexpr int N = 4 * H;
   constexpr int QN = (H + 3) / 4;      // image blocks (1 KiB each): 4 units x 4 gates x 16 samples
   constexpr int BQ = (QN + 3) / 4;     // image blocks per wave: the K loop (H k-steps = QN blocks of 4) is split over 4 waves
@@ -30,7 +31,7 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int wg,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, uq = lane >> 4;
   const int G = jb.G_;
-  const int bg = wg / G, ug = wg % G;
+  const bool fast = xcd_local && mgr_cluster_same_xcd(xcc, blockIdx.x, jb.cls_begin, jb.cls_nclusters, cl, G, status);  // opt-in, see lstm_cluster.hip
   const int B = jb.B, T = jb.T, reverse = jb.reverse;
   const int b = bg * 16 + j;
   const bool bvalid = b < B;
@@ -141,7 +142,12 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int wg,
         if (G > 1) {
           const unsigned bits = (__float_as_uint(val) & ~1u) | par;
           val = __uint_as_float(bits);
-          if (has_prev && uvalid) __builtin_amdgcn_raw_buffer_store_b32(bits, rs, (slot * IMG + idx) * 4, 0, 16);  // sc1
+          if (has_prev && uvalid) {
+            if (fast)  // cluster on one XCD: plain store into the shared L2
+              *reinterpret_cast<volatile unsigned*>(xb + slot * IMG + idx) = bits;
+            else
+              __builtin_amdgcn_raw_buffer_store_b32(bits, rs, (slot * IMG + idx) * 4, 0, 16);  // sc1 write-through
+          }
         }
         if (uvalid) dn[idx] = val;
       }
@@ -162,7 +168,8 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int wg,
 #pragma unroll
           for (int i = 0; i < NF; ++i)
             if (pend & (1u << i))
-              v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (slot * IMG + (base + wave + BW_WAVES * i) * 256 + lane * 4) * 4, 0, 16);
+              v[i] = fast ? __builtin_amdgcn_raw_buffer_load_b128(rs, (slot * IMG + (base + wave + BW_WAVES * i) * 256 + lane * 4) * 4, 0, 2)
+                          : __builtin_amdgcn_raw_buffer_load_b128(rs, (slot * IMG + (base + wave + BW_WAVES * i) * 256 + lane * 4) * 4, 0, 16);
 #pragma unroll
           for (int i = 0; i < NF; ++i) {
             if (pend & (1u << i)) {
@@ -214,16 +221,22 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int wg,
 __global__ __launch_bounds__(BW_WAVES * 64) void k_scan_cluster_bwd(ClusterBwdLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = blockIdx.x;
-  int ji = 0;
-  for (int k = 1; k < L.njobs; ++k)
-    if (bid >= L.job[k].wg_begin) ji = k;
-  const ClusterBwdJob& jb = L.job[ji];
-  const int wg = bid - jb.wg_begin;
-  if (wg >= jb.G_ * jb.nbg) return;
+  for (int k = 0; k < L.njobs; ++k) {
+    const ClusterBwdJob& jb = L.job[k];
+    const int w = bid - jb.cls_begin;
+    if (w < 0 || w >= jb.cls_nclusters * jb.G_) continue;
+    // members of a cluster are CONTIGUOUS workgroup ids by default (the round-robin dispatcher then spreads them over
+    // all XCDs, which measured best for the write-through exchange); the XCD-local experiment interleaves them instead
+    const int cl = L.xcd_local ? w % jb.cls_nclusters : w / jb.G_;
+    const int ug = L.xcd_local ? w / jb.cls_nclusters : w % jb.G_;
+    const int bg = cl - jb.cls_cluster0;
+    if (bg < 0 || bg >= jb.nbg) continue;
 #define BW_CASE(HH) \
-  if (jb.H == HH) return cluster_bwd_run<HH>(jb, wg, smem, L.status);
-  BW_FOREACH(BW_CASE)
+  if (jb.H == HH) return cluster_bwd_run<HH>(jb, bg, ug, cl, L.xcc, L.xcd_local, smem, L.status);
+    BW_FOREACH(BW_CASE)
 #undef BW_CASE
+    return;
+  }
 }
 
 }  // namespace
