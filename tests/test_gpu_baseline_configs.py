@@ -1,0 +1,89 @@
+"""-m gpu: the BASELINE.json configs that are parity cases rather than bench lines.
+ A  audio plumbing  : 2-layer BiLSTM(128)+CTC, B=8,  T=200,  39-d, full size, loss + gradients + one Adam step vs oracle
+ S  skeletal        : BiLSTM(128)+CTC,         B=32, T=1000, 22-d, full size, loss vs oracle (1e-4 relative)
+ F  fusion (ref sizes 500/300/100) at B=4, T=96 (the fp64 oracle needs minutes at T=1900): loss + trainable grads
+ D  decode          : beam=10 and thresholded best-path on T=1900 sequences, label sequences bit-exact vs the oracle
+"""
+import numpy as np
+import pytest
+
+from oracle import keras_ref as kr
+from oracle import network_ref as nr
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_case(device, key, B=None, T=None, lmin=3, lmax=10, check_grads=True, seed=0):
+    import mgr_amd  # noqa: F401
+    from mgr_amd.configs import baseline_config
+    from mgr_amd.engine import Engine
+    from mgr_amd.synthetic import synthetic_arrays, synthetic_weights
+    spec, B0, T0, Lmax = baseline_config(key)
+    B, T = B or B0, T or T0
+    eng = Engine(spec, B, T, Lmax, device=device, seed=seed)
+    w = synthetic_weights(spec, 100 + seed)
+    # stronger recurrent / input weights than the init recipe so that gates leave their linear region
+    for k in w:
+        if k.endswith("/W") or k.endswith("/U"):
+            w[k] = w[k] * 2.0
+    eng.set_weights(w)
+    xs, labels, il, ll = synthetic_arrays(spec, B, T, Lmax, 200 + seed, lmin=lmin, lmax=lmax)
+    sd = spec.to_dict()
+    rand = nr.draw_rand(sd, B, T, np.random.default_rng(300 + seed))
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    ref_loss, ref_lb, ref_g, ref_P = nr.loss_and_grads(sd, w64, xs, labels, il, ll, rand)
+    eng.enqueue_train_step(xs, labels, il, ll, rand=rand, apply_update=False)
+    loss = float(eng.loss_mean.download()[0])
+    assert abs(loss - ref_loss) <= 1e-4 * abs(ref_loss), (key, loss, ref_loss)
+    assert np.allclose(eng.loss_b.download(), ref_lb, rtol=1e-4)
+    assert rel_err(eng.P.download(), ref_P) < 2e-4
+    if check_grads:
+        g = eng.get_grads()
+        assert set(g) == set(ref_g)
+        for k in ref_g:
+            assert rel_err(g[k], ref_g[k]) < 1e-3, (key, k, rel_err(g[k], ref_g[k]))
+    eng.close()
+    return loss
+
+
+def test_config_A_audio_plumbing_full_size(device):
+    _run_case(device, "A")
+
+
+def test_config_S_skeletal_full_size(device):
+    _run_case(device, "S", lmin=8, lmax=20)
+
+
+def test_config_F_reference_sizes_short_T(device):
+    _run_case(device, "F", B=4, T=96)
+
+
+def test_config_F_ragged_batch_not_multiple_of_16(device):
+    _run_case(device, "F", B=19, T=40, seed=1)
+
+
+def test_config_D_decode_long_sequences(device):
+    from mgr_amd import decoding
+    rng = np.random.default_rng(5)
+    N, T, C = 3, 1900, 22
+    # run-structured, peaky posteriors like a trained CTC network produces
+    z = rng.standard_normal((N, T, C)) * 1.5
+    z[:, :, C - 1] += 3.0
+    for n in range(N):
+        t = 20
+        while t < T - 40:
+            c = int(rng.integers(0, C - 1))
+            run = int(rng.integers(5, 40))
+            z[n, t:t + run, c] += rng.uniform(3.0, 9.0)
+            t += run + int(rng.integers(10, 90))
+    P = np.exp(z - z.max(-1, keepdims=True))
+    P = (P / P.sum(-1, keepdims=True)).astype(np.float32)
+    assert decoding.greedy_decode(P, 0.5, dev=device) == kr.greedy_decode_quirk(P, 0.5)
+    il = np.full(N, T - 2)
+    ref, rs = kr.ctc_beam_search(P, il, beam_width=10)
+    got, gs = decoding.beam_search_decode(P, il, beam_width=10, dev=device)
+    assert got == ref
+    assert np.allclose(gs, rs, rtol=1e-10)
+    # LER helper: identical hypotheses -> 0
+    assert decoding.label_error_rate(got, ref) == 0.0
