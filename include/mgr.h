@@ -110,7 +110,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
  * 2 force one workgroup per batch group (no inter-CU exchange) where it fits, 3 force clusters with 4 tiles per
  * workgroup, 4 same with 8 tiles per workgroup.  key 1: !=0 makes scan_fwd check the give-up word synchronously.
  * key 2: print the scan plan.  key 3: opt into the XCD-local exchange path (measured slower; kept for study). */
-enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 4 };
+enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 8 };
 int mgr_tune(mgr_ctx* ctx, int key, int value);
 /* Diagnostic: out[b] = XCC (XCD) id the workgroup b of a (nblocks, threads, lds_bytes) launch ran on. */
 int mgr_probe_xcc(mgr_ctx* ctx, int nblocks, int threads, int lds_bytes, int32_t* out);

@@ -79,6 +79,10 @@ void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
       if (path == 3 && cur[k] != 0) feas = false;
       if (path == 4 && cur[k] != 1) feas = false;
       if (path == 5 && cur[k] != 4) feas = false;
+      {  // experiment hooks: tune keys 4 / 5 force the configuration index (+1) of jobs with H >= 400 / H < 400
+        int forced = j.H >= 400 ? c->tune[4] : c->tune[5];
+        if (forced > 0 && cur[k] != forced - 1) feas = false;
+      }
       if (path != 5 && f.pair == 2) feas = false;  // measured slower than one group per workgroup: opt-in only
       if (path == 2 && (f.nw * f.tpw < ks)) feas = false;  // force single-CU (no exchange)
       int tiles = f.nw * f.tpw;

@@ -1,15 +1,20 @@
 // K7-scan, multi-CU: BPTT of LSTM directions spread over clusters of CUs (the backward twin of lstm_cluster.hip).
 //
-// dh_rec_{t-1}[unit, sample] = sum over the 4H packed gate columns of U[unit, col] * dz_t[sample, col].
-// A cluster = the G = ceil(H/16) workgroups serving one (direction, 16-sample batch group); workgroup `ug` owns the
-// 16 output units [16*ug, 16*ug+16) = ONE MFMA M-tile (v_mfma_f32_16x16x4_f32, M = units, N = samples, K = 4 gate
-// columns = one unit's i,f,c,o).  Its 4 waves split the K loop (H k-steps) four ways with the U fragments stationary
-// in VGPRs, reduce the four partial tiles through LDS, and then every thread runs the cell backward for ONE
-// (unit, sample): 256 threads = 16 units x 16 samples.  dz_t is published to the cluster with the same
-// data-is-the-flag write-through hand-off as the forward kernel (epoch parity in the mantissa LSB of every dz word)
-// and gathered into the next LDS image [unit/4][gate][sample][unit%4].  Saved forward state (gates, c) and dY are
-// prefetched two steps ahead through a 3-deep register ring.  Bounded spins, status word, one launch for all
-// concurrently scanned directions (co-residency by construction).
+// dh_rec_{t-1}[unit, sample] = sum over the 4H packed gate columns c of U[unit, c] * dz_t[sample, c].
+// A cluster = the G = ceil(H/16) workgroups serving one (direction, 16-sample batch group).  Workgroup g OWNS the 16
+// units S_g = [16g, 16g+16): their carried dc, their saved gates, and therefore their 64 gate columns of dz_t.
+// The contraction is split over K (REDUCE-SCATTER), not over the output: with its own dz slice as the B operand
+// (a 4 KiB LDS image) and the matching 64 columns of U stationary in VGPRs, workgroup g computes its partial sum for
+// ALL units - G tiles of 16 units x 16 samples, v_mfma_f32_16x16x4_f32, 16 k-steps each - and sends tile m to workgroup
+// m as ONE contiguous 1 KiB block (a 16-byte write-through store per lane: eight whole 128-byte lines).  Workgroup g
+// then only has to fetch the G-1 tiles addressed to it (G-1 KiB) instead of the whole dz_t (4H x 16 floats, 4x more):
+// dh is 4x smaller than dz, so reducing partial dh beats all-gathering dz.  The sums are formed in a fixed order
+// (wave w adds sources g' = w, w+4, ... ascending, then waves 0..3 through LDS) so results are run-to-run identical.
+// Hand-off: the data is the flag - the mantissa LSB of every exchanged word carries the epoch parity (a 1-ulp
+// perturbation of a partial sum); two slots per (destination, source) pair suffice (see lstm_cluster.hip).
+// After the reduction every thread runs the cell backward for ONE (unit, sample): 256 threads = 16 units x 16 samples;
+// saved forward state and dY are prefetched two steps ahead through a 3-deep register ring.
+// Bounded spins, status word, one launch for all concurrently scanned directions (co-residency by construction).
 #include "lstm_cluster.h"
 #include "lstm_common.h"
 
@@ -23,41 +28,43 @@ template <int H>
 __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg, int ug, int cl, unsigned* xcc, int xcd_local,
                                                 float* smem, unsigned* status) {
   constexpr int N = 4 * H;
-  constexpr int QN = (H + 3) / 4;      // image blocks (1 KiB each): 4 units x 4 gates x 16 samples
-  constexpr int BQ = (QN + 3) / 4;     // image blocks per wave: the K loop (H k-steps = QN blocks of 4) is split over 4 waves
-  constexpr int KQ = 4 * BQ;           // k-steps per wave
-  constexpr int IMG = 4 * BQ * 256;    // image padded to whole per-wave ranges (padding stays zero)
+  constexpr int GT = (H + 15) / 16;          // tiles of 16 units = workgroups per cluster
+  constexpr int TPW = (GT + BW_WAVES - 1) / BW_WAVES;  // tiles per wave (tile m = wave + 4*i)
+  (void)xcc;
+  (void)xcd_local;
+  (void)cl;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, uq = lane >> 4;
-  const int G = jb.G_;
-  const bool fast = xcd_local && mgr_cluster_same_xcd(xcc, blockIdx.x, jb.cls_begin, jb.cls_nclusters, cl, G, status);  // opt-in, see lstm_cluster.hip
   const int B = jb.B, T = jb.T, reverse = jb.reverse;
   const int b = bg * 16 + j;
   const bool bvalid = b < B;
   const int bc = bvalid ? b : B - 1;
-  float* img = smem;                       // [2][IMG] dz images
-  float* red = smem + 2 * IMG;             // [4 waves][4 regs][64 lanes] partial tiles
+  float* dzi = smem;                 // [4 blocks][4 gates][16 samples][4] own dz image: k-step s = own unit s, kk = gate
+  float* red = smem + 4 * 256;       // [4 waves][64 lanes][4] per-wave partial sums of the tiles addressed to this workgroup
 
-  // A fragment of k-step s (unit s): A[i = lane&15][kk = lane>>4] = Up[unit 16*ug+i][4s + kk]; this wave owns
-  // k-steps s = wave*KQ + k
-  float uf[KQ];
-  {
-    const int ur = ug * 16 + j;
+  // A fragments: tile m (units 16m..16m+15) x this workgroup's 64 gate columns: k-step s (own unit s), kk = gate
+  //   A[i = lane&15][kk = lane>>4] = Up[unit 16m+i][4*(16*ug + s) + kk]
+  float uf[TPW][16];
 #pragma unroll
-    for (int k = 0; k < KQ; ++k) {
-      const int s = wave * KQ + k;
-      uf[k] = (ur < H && s < H) ? jb.Up[(size_t)ur * N + 4 * s + uq] : 0.f;
+  for (int i = 0; i < TPW; ++i) {
+    const int m = wave + BW_WAVES * i;
+    const int ur = m * 16 + j;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int su = ug * 16 + s;
+      uf[i][s] = (m < GT && ur < H && su < H) ? jb.Up[(size_t)ur * N + 4 * su + uq] : 0.f;
     }
   }
-  for (int i = tid; i < 2 * IMG; i += BW_WAVES * 64) img[i] = 0.f;
+  for (int i = tid; i < 4 * 256; i += BW_WAVES * 64) dzi[i] = 0.f;
 
-  // this thread's (unit, sample) for the cell backward: unit = 16*ug + 4*uq + wave  (D row = 4*(lane>>4) + reg, reg = wave)
+  // cell backward ownership: unit = 16*ug + 4*uq + wave (row 4*(lane>>4)+reg of the reduced tile, reg = wave), sample j
   const int unit = ug * 16 + uq * 4 + wave;
   const bool uvalid = unit < H;
-  const int q0 = ug * 4;  // own image blocks [q0, q0+4)
-  float* xb = jb.xbuf + (size_t)bg * 2 * IMG;
-  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, 2 * IMG * 4, 0x00020000);
+  // exchange slots: [slot][dest GT][src GT][256 floats]
+  constexpr int SLOT = GT * GT * 256;
+  float* xb = jb.xbuf + (size_t)bg * 2 * SLOT;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, 2 * SLOT * 4, 0x00020000);
 
   struct Saved {
     float dy, c;
@@ -79,118 +86,40 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
   load(r0, 0);
   load(r1, 1);
   float dcc = 0.f;
+  f32x4 own_tile = {0.f, 0.f, 0.f, 0.f};  // the partial tile this workgroup computed for itself (held by wave ug % 4)
   bool failed = false;
   __syncthreads();
-  int cur = 0;
 
   auto do_step = [&](int k, Saved& use, Saved& prev, Saved& ld) {
     const int n = T - 1 - k;
     const int t = reverse ? T - 1 - n : n;
     const bool has_prev = n > 0;
     load(ld, k + 2);
-    const float* db = img + cur * IMG;
-    float* dn = img + (cur ^ 1) * IMG;
-    const int slot = k & 1;
-    const unsigned par = (((unsigned)k >> 1) & 1u) ^ 1u;
-    // ---- 1. dh_rec from the previous step's dz (zero at the first iteration: image is zero-initialised)
+    // ---- 1. reduce the partial tiles addressed to this workgroup (published at iteration k-1)
     float dhr = 0.f;
     if (k > 0) {
-      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-      // this wave's k-steps are the blocks q = wave*BQ + bi (4 k-steps each): static fragment indices
-      constexpr int PD = 3;
-      f32x4 dbuf[4];
-      const float* dlane = db + (uq * 16 + j) * 4 + (size_t)wave * BQ * 256;
-#pragma unroll
-      for (int bi = 0; bi < PD && bi < BQ; ++bi) dbuf[bi] = *reinterpret_cast<const f32x4*>(dlane + bi * 256);
-#pragma unroll
-      for (int bi = 0; bi < BQ; ++bi) {
-        if (bi + PD < BQ) dbuf[(bi + PD) & 3] = *reinterpret_cast<const f32x4*>(dlane + (bi + PD) * 256);
-        __builtin_amdgcn_sched_barrier(0);
-        const f32x4 dv = dbuf[bi & 3];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (r & 1)
-            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[4 * bi + r], dv[r], a1, 0, 0, 0);
-          else
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[4 * bi + r], dv[r], a0, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      a0 += a1;
-      // ---- 2. reduce the four K-slices through LDS
-      *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = a0;
-      __syncthreads();
-      dhr = red[(0 * 64 + lane) * 4 + wave] + red[(1 * 64 + lane) * 4 + wave] + red[(2 * 64 + lane) * 4 + wave] +
-            red[(3 * 64 + lane) * 4 + wave];
-    }
-    // ---- 3. cell backward for (unit, sample)
-    float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (uvalid) {
-      const float dh = use.dy + dhr;
-      const float cp = has_prev ? prev.c : 0.f;
-      dz = mgr_cell_bwd(dh, use.g, use.c, cp, dcc);
-      if (bvalid) *reinterpret_cast<float4*>(jb.dZ + ((size_t)b * T + t) * N + unit * 4) = dz;
-    }
-    {
-      // image [q = unit>>2][gate][j][r = unit&3]
-      const int base = ((unit >> 2) * 4 * 16 + j) * 4 + (unit & 3);
-      float v[4] = {dz.x, dz.y, dz.z, dz.w};
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float val = v[g];
-        const int idx = base + g * 64;
-        if (G > 1) {
-          const unsigned bits = (__float_as_uint(val) & ~1u) | par;
-          val = __uint_as_float(bits);
-          if (has_prev && uvalid) {
-            if (fast)  // cluster on one XCD: plain store into the shared L2
-              *reinterpret_cast<volatile unsigned*>(xb + slot * IMG + idx) = bits;
-            else
-              __builtin_amdgcn_raw_buffer_store_b32(bits, rs, (slot * IMG + idx) * 4, 0, 16);  // sc1 write-through
-          }
-        }
-        if (uvalid) dn[idx] = val;
-      }
-    }
-    // ---- 4. gather the peers' dz blocks
-    if (G > 1 && has_prev) {
-      constexpr int NF = 8;
-      for (int base = 0; base < QN && !failed; base += NF * BW_WAVES) {
-        u32x4 v[NF];
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+      if (GT > 1) {
+        const int slot = (k - 1) & 1;
+        const unsigned par = (((unsigned)(k - 1) >> 1) & 1u) ^ 1u;
+        u32x4 v[TPW];
         unsigned pend = 0;
 #pragma unroll
-        for (int i = 0; i < NF; ++i) {
-          int q = base + wave + BW_WAVES * i;
-          if (q < QN && (q < q0 || q >= q0 + 4)) pend |= 1u << i;
+        for (int i = 0; i < TPW; ++i) {
+          const int src = wave + BW_WAVES * i;
+          if (src < GT && src != ug) pend |= 1u << i;
         }
         unsigned spins = 0;
         while (pend && !failed) {
 #pragma unroll
-          for (int i = 0; i < NF; ++i)
+          for (int i = 0; i < TPW; ++i)
             if (pend & (1u << i))
-              v[i] = fast ? __builtin_amdgcn_raw_buffer_load_b128(rs, (slot * IMG + (base + wave + BW_WAVES * i) * 256 + lane * 4) * 4, 0, 2)
-                          : __builtin_amdgcn_raw_buffer_load_b128(rs, (slot * IMG + (base + wave + BW_WAVES * i) * 256 + lane * 4) * 4, 0, 16);
+              v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (slot * SLOT + (ug * GT + wave + BW_WAVES * i) * 256 + lane * 4) * 4, 0, 16);  // sc1
 #pragma unroll
-          for (int i = 0; i < NF; ++i) {
+          for (int i = 0; i < TPW; ++i) {
             if (pend & (1u << i)) {
-              const int q = base + wave + BW_WAVES * i;
-              const int nvalid = H - 4 * q;  // units of this block that exist
-              unsigned a = par ? 0xFFFFFFFFu : 0u;
-              if (par) {
-                a &= v[i].x;
-                if (nvalid > 1) a &= v[i].y;
-                if (nvalid > 2) a &= v[i].z;
-                if (nvalid > 3) a &= v[i].w;
-              } else {
-                a |= v[i].x;
-                if (nvalid > 1) a |= v[i].y;
-                if (nvalid > 2) a |= v[i].z;
-                if (nvalid > 3) a |= v[i].w;
-              }
-              if (__all((a & 1u) == par)) {
-                *reinterpret_cast<u32x4*>(dn + q * 256 + lane * 4) = v[i];
-                pend &= ~(1u << i);
-              }
+              const unsigned a = par ? (v[i].x & v[i].y & v[i].z & v[i].w) : (v[i].x | v[i].y | v[i].z | v[i].w);
+              if (__all((a & 1u) == par)) pend &= ~(1u << i);
             }
           }
           if (pend) {
@@ -203,10 +132,83 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
             }
           }
         }
+        // fixed summation order: sources wave, wave+4, ... ascending (own tile in its place)
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+          const int src = wave + BW_WAVES * i;
+          if (src < GT) {
+            if (src == ug) {
+              sum += own_tile;
+            } else {
+              sum[0] += __uint_as_float(v[i].x);
+              sum[1] += __uint_as_float(v[i].y);
+              sum[2] += __uint_as_float(v[i].z);
+              sum[3] += __uint_as_float(v[i].w);
+            }
+          }
+        }
+      } else {
+        if (wave == 0) sum = own_tile;
       }
+      *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = sum;
+      __syncthreads();
+      dhr = red[(0 * 64 + lane) * 4 + wave] + red[(1 * 64 + lane) * 4 + wave] + red[(2 * 64 + lane) * 4 + wave] +
+            red[(3 * 64 + lane) * 4 + wave];
+    }
+    // ---- 2. cell backward for (unit, sample); own dz slice -> global dZ and the LDS B-operand image
+    float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (uvalid) {
+      const float dh = use.dy + dhr;
+      const float cp = has_prev ? prev.c : 0.f;
+      dz = mgr_cell_bwd(dh, use.g, use.c, cp, dcc);
+      if (bvalid) *reinterpret_cast<float4*>(jb.dZ + ((size_t)b * T + t) * N + unit * 4) = dz;
+    }
+    if (!has_prev) return;  // the first forward step has no predecessor: nothing to send (workgroup-uniform)
+    {
+      // own unit index s = 4*uq + wave -> image [q = s>>2 = uq][kk = gate][j][r = s&3 = wave]
+      float* p = dzi + ((uq * 4) * 16 + j) * 4 + wave;
+      p[0 * 64] = dz.x;
+      p[1 * 64] = dz.y;
+      p[2 * 64] = dz.z;
+      p[3 * 64] = dz.w;
     }
     __syncthreads();
-    cur ^= 1;
+    // ---- 3. partial sums for every tile of 16 units from this workgroup's 64 gate columns; send tile m to workgroup m
+    {
+      const int slot = k & 1;
+      const unsigned par = (((unsigned)k >> 1) & 1u) ^ 1u;
+      f32x4 dv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dv[q] = *reinterpret_cast<const f32x4*>(dzi + ((q * 4 + uq) * 16 + j) * 4);
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const int m = wave + BW_WAVES * i;
+        if (m < GT) {  // wave-uniform
+          f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (r & 1)
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[i][4 * q + r], dv[q][r], a1, 0, 0, 0);
+              else
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[i][4 * q + r], dv[q][r], a0, 0, 0, 0);
+            }
+          }
+          a0 += a1;
+          if (m == ug) {
+            own_tile = a0;
+          } else {
+            u32x4 w;
+            w.x = (__float_as_uint(a0[0]) & ~1u) | par;
+            w.y = (__float_as_uint(a0[1]) & ~1u) | par;
+            w.z = (__float_as_uint(a0[2]) & ~1u) | par;
+            w.w = (__float_as_uint(a0[3]) & ~1u) | par;
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs, (slot * SLOT + (m * GT + ug) * 256 + lane * 4) * 4, 0, 16);  // sc1
+          }
+        }
+      }
+    }
   };
 
   for (int k0 = 0; k0 < T; k0 += 3) {
@@ -216,7 +218,7 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
   }
 }
 
-#define BW_FOREACH(X) X(8) X(16) X(32) X(64) X(100) X(128)
+#define BW_FOREACH(X) X(8) X(16) X(32) X(64) X(100) X(128) X(300) X(500)
 
 __global__ __launch_bounds__(BW_WAVES * 64) void k_scan_cluster_bwd(ClusterBwdLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -241,9 +243,10 @@ __global__ __launch_bounds__(BW_WAVES * 64) void k_scan_cluster_bwd(ClusterBwdLa
 
 }  // namespace
 
+// floats of exchange memory per batch group and slot: [dest G][src G][256]
 size_t mgr_cluster_bwd_img_floats(int H) {
-  int qn = (H + 3) / 4, bq = (qn + 3) / 4;
-  return (size_t)4 * bq * 256;
+  size_t g = (size_t)(H + 15) / 16;
+  return g * g * 256;
 }
 
 bool mgr_cluster_bwd_supported(int H) {
@@ -257,7 +260,8 @@ bool mgr_cluster_bwd_supported(int H) {
 int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs) {
   int maxH = 0;
   for (int i = 0; i < L.njobs; ++i) maxH = L.job[i].H > maxH ? L.job[i].H : maxH;
-  size_t lds = ((size_t)2 * mgr_cluster_bwd_img_floats(maxH) + 4 * 64 * 4) * sizeof(float);
+  (void)maxH;
+  size_t lds = (size_t)(4 * 256 + 4 * 64 * 4) * sizeof(float);
   MGR_REQUIRE(total_wgs <= 2 * c->cu_count, "cluster BPTT needs %d co-resident workgroups", total_wgs);
   static bool attr_set = false;
   if (!attr_set) {

@@ -308,7 +308,7 @@ def test_scan_paths_agree(device, path):
         dev.call("mgr_tune", 1, 0)
 
 
-@pytest.mark.parametrize("B,T,H,path", [(5, 9, 32, 0), (33, 6, 100, 0), (17, 7, 128, 0), (20, 5, 16, 0), (3, 6, 8, 0), (19, 8, 100, 2)])
+@pytest.mark.parametrize("B,T,H,path", [(5, 9, 32, 0), (33, 6, 100, 0), (17, 7, 128, 0), (20, 5, 16, 0), (3, 6, 8, 0), (19, 8, 100, 2), (18, 5, 300, 0), (33, 4, 500, 0)])
 def test_bwd_multi_matches_oracle(device, B, T, H, path):
     """BPTT of both directions in one call (multi-CU clusters exchanging dz_t when path == 0) vs the oracle."""
     from mgr_amd import _capi
