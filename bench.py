@@ -78,6 +78,8 @@ def main():
         dev.call("mgr_tune", 2, 1)
     if args.scan_path:
         dev.call("mgr_tune", 0, args.scan_path)
+    if os.environ.get("MGR_GATHER_DELAY"):
+        dev.call("mgr_tune", 6, int(os.environ["MGR_GATHER_DELAY"]))
     if os.environ.get("MGR_SCAN_CFG"):   # experiment hook: "<cfg for H>=400>:<cfg for H<400>", 1-based indices into kCfgs
         a, b = os.environ["MGR_SCAN_CFG"].split(":")
         dev.call("mgr_tune", 4, int(a))

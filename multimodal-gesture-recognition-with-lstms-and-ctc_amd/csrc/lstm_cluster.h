@@ -29,6 +29,8 @@ struct ClusterLaunch {
   int njobs;
   unsigned* xcc;     // [grid] XCC id + 1 of every workgroup, published at kernel start
   int xcd_local;     // opt-in: clusters found on one XCD exchange through its L2 (plain stores + nt loads)
+  int gather_delay;  // 64-cycle sleeps between a workgroup's own publish and its first gather pass (a failed pass costs a
+                     // full fabric round trip, a short wait is cheaper)
   unsigned* status;  // [0] != 0 -> a bounded spin gave up
   ClusterJob job[MGR_MAX_SCAN_JOBS];
 };

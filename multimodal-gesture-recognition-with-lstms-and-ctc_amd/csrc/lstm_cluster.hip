@@ -43,7 +43,7 @@ constexpr unsigned POLL_LIMIT = 1u << 20;
 
 template <int KS, int TPW>
 __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int bg, int ug, int cl, unsigned* xcc, int xcd_local,
-                                            float* smem, unsigned* status) {
+                                            int gather_delay, float* smem, unsigned* status) {
   constexpr int H = 4 * KS, N = 4 * H, QN = (KS + 3) / 4, IMG = QN * 256;
   static_assert(QN <= 32, "gather sweep covers at most 32 image blocks (H <= 512)");
   const int tid = threadIdx.x, lane = tid & 63;
@@ -215,6 +215,7 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int bg, int ug
       // gather: wave w sweeps blocks w, w+nwv, w+2*nwv, ... of the exchange slot (up to 8 loads in flight per round) until
       // every word of a block shows this epoch's parity
       constexpr int NF = 8;  // loads in flight per wave and round
+      for (int d = 0; d < gather_delay; ++d) __builtin_amdgcn_s_sleep(1);  // see ClusterLaunch::gather_delay
       for (int base = 0; base < QN && !failed; base += NF * nwv) {
         u32x4 v[NF];
         unsigned pend = 0;
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(CL_WAVES * 64) void k_scan_cluster(ClusterLaunch L)
     const int bg = cl - jb.cls_cluster0;
     if (bg < 0 || bg >= jb.nbg) continue;
 #define CL_CASE(KS, TPW) \
-  if (jb.ks == KS && jb.tpw == TPW) return cluster_run<KS, TPW>(jb, bg, ug, cl, L.xcc, L.xcd_local, smem, L.status);
+  if (jb.ks == KS && jb.tpw == TPW) return cluster_run<KS, TPW>(jb, bg, ug, cl, L.xcc, L.xcd_local, L.gather_delay, smem, L.status);
     CL_FOREACH(CL_CASE)
 #undef CL_CASE
     return;
