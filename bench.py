@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--maxlen", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--show-plan", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the next step's frozen-encoder pass")
     ap.add_argument("--scan-path", type=int, default=0, help="0 auto, 3/4 clusters of 4/8 tiles, 5 paired batch groups")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-T", type=int, default=400)
@@ -104,12 +105,16 @@ def main():
     eng._upload_labels(labels, il, ll)
     dev.sync()
 
-    def step():
-        eng.enqueue_train_step(None, None, None, None, rand=None, apply_update=True, upload=False)
+    def step(prefetch):
+        # frozen encoders: the encoder pass of the NEXT step runs concurrently with this step's fusion / CTC / BPTT /
+        # Adam (Engine.can_pipeline).  Never across the timing boundary: the last warm-up and the last timed step do
+        # not prefetch, so exactly K complete steps - K encoder passes, K fusion passes - lie inside the timed region.
+        eng.enqueue_train_step(None, None, None, None, rand=None, apply_update=True, upload=False,
+                               prefetch_next=prefetch and not args.no_pipeline)
         return float(eng.loss_mean.download()[0])
 
-    for _ in range(args.warmup):
-        loss = step()
+    for i in range(args.warmup):
+        loss = step(i + 1 < args.warmup)
     dev.prof_enable((1 << 10) - 1)
     dev.prof_reset()
     if comm:
@@ -117,8 +122,8 @@ def main():
     dev.sync()
     t0 = time.perf_counter()
     losses = []
-    for _ in range(args.steps):
-        losses.append(step())
+    for i in range(args.steps):
+        losses.append(step(i + 1 < args.steps))
     dev.sync()
     if comm:
         comm.barrier()

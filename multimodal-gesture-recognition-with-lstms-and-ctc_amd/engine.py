@@ -150,6 +150,13 @@ class Engine:
                         self.Y2[s["name"]] = dev.empty((B, T, 2 * Hs[1]))
                     self.dY1[s["name"]] = dev.empty((B, T, 2 * Hs[0]))
         self.FEAT = dev.empty((B, T, W))
+        self._feat_ring = [self.FEAT]
+        if train and self.can_pipeline:
+            self._feat_ring.append(dev.empty((B, T, W)))   # second FEAT buffer for cross-step pipelining
+        self._feat_idx = 0
+        self._prefetched = None
+        self._prefetched_for = None
+        self._masks = {}
         any_tr_stream = any(s["trainable"] for s in sp.streams)
         if sp.fusion:
             Hf = sp.fusion["H"]
@@ -251,9 +258,9 @@ class Engine:
     def _seed(self, slot):
         return (self.seed * 1000003 + self.rng_step * 131 + slot) & 0xFFFFFFFFFFFFFFFF
 
-    def _upload_inputs(self, inputs, rand, train):
+    def _upload_inputs(self, inputs, rand, train, stream=0):
         dev = self.dev
-        dev.stream(0)
+        dev.stream(stream)
         for s in self.spec.streams:
             x = np.asarray(inputs[s["name"]], dtype=np.float32)
             if x.shape != (self.B, self.T, s["F"]):
@@ -278,35 +285,39 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------ forward
     def _forward(self, train, rand):
+        """Encoders + fusion + head, all on stream 0 (predict / parity / non-pipelined training)."""
+        if self._prefetched is not None:   # a pipelined encoder pass is in flight: let it finish, then discard it
+            self.dev.wait(0, 5)
+            self._prefetched = None
+        self._enqueue_encoders(train, rand, self.FEAT, 0, self.rng_step)
+        self._enqueue_fusion_head(train, rand, self.FEAT, self.rng_step)
+        if train:
+            self.rng_step += 1
+
+    def _enqueue_encoders(self, train, rand, feat_buf, es, rng_step, hold_scans_for=None):
+        """Noise + every encoder depth (input-projection GEMMs, then all recurrences of the depth in one multi-scan
+        call), written into feat_buf.  Everything is enqueued on stream `es`."""
         sp, dev, B, T = self.spec, self.dev, self.B, self.T
         W = sp.concat_width
         save = train and not self.inference_only
+        saved_step, self.rng_step = self.rng_step, rng_step
         slot = 0
-        used_streams = []
-        self._masks = {}
         cols = {}
         col = 0
         for s in sp.streams:
             cols[s["name"]] = col
             col += sp.stream_width(s)
+        dev.stream(es)
         # GaussianNoise (K1) per stream
         for si, s in enumerate(sp.streams):
-            sa, sb = 1 + 2 * si, 2 + 2 * si
-            used_streams += [sa, sb]
             name = s["name"]
             X = self.Xin[name]
-            dev.stream(sa)
-            dev.wait(sa, 0)
             if train and rand is None and s["noise"] > 0:
                 # on device; the resident input stays pristine for the next step
                 dev.call("mgr_add_gaussian_noise", X, self.X[name], X.size, float(s["noise"]),
                          C.c_uint64(self._seed(900 + si)))
                 X = self.X[name]
             self._xcur[name] = X
-            dev.wait(sb, sa)
-        dev.stream(0)
-        for st in used_streams:
-            dev.wait(0, st)
         depth = max(len(s["layers"]) for s in sp.streams)
         for k in range(depth):
             jobs = []
@@ -314,7 +325,6 @@ class Engine:
                 nl = len(s["layers"])
                 if k >= nl:
                     continue
-                sa, sb = 1 + 2 * si, 2 + 2 * si
                 name = s["name"]
                 H = s["layers"][k]["H"]
                 last = k == nl - 1
@@ -324,10 +334,9 @@ class Engine:
                 else:
                     Hp = s["layers"][k - 1]["H"]
                     cur, ldcur, fin = self.Y1[name], 2 * Hp, 2 * Hp
-                for di, (dname, st) in enumerate((("fwd", sa), ("bwd", sb))):
+                for di, dname in enumerate(("fwd", "bwd")):
                     L = self.dirs["%s/l%d/%s" % (name, k, dname)]
-                    dev.stream(0)   # every projection GEMM fills the chip: one stream keeps their timings honest
-                    slot += 1
+                    slot += 1   # (every projection GEMM fills the chip: one stream keeps their timings honest)
                     mptr = self._prep_mask(L, train, rand, slot)
                     self._masks[(L.prefix, L.d)] = mptr
                     Z = self.Zbuf[name][di]
@@ -338,41 +347,48 @@ class Engine:
                     elif nl == 2 and s["residual"] and name in self.Y2 and save:
                         Y, ldy = self.Y2[name].view(di * H, (1,)), 2 * H
                     else:
-                        Y, ldy = self.FEAT.view(col + di * H, (1,)), W
+                        Y, ldy = feat_buf.view(col + di * H, (1,)), W
                         if nl == 2 and s["residual"]:
                             R, ldr = self.Y1[name].view(di * H, (1,)), 2 * H
                     keep = save and L.trainable
                     jobs.append(dict(Z=Z, Up=L.Up, Y=Y, ldy=ldy, R=R, ldr=ldr, gates=L.gates if keep else 0,
                                      cs=L.cs if keep else 0, B=B, T=T, H=H, reverse=L.reverse))
             # all recurrences of this depth in ONE call (one persistent multi-CU launch when H is large)
-            dev.stream(0)
-            self._scan_multi(jobs)
+            if hold_scans_for is not None and k >= 1:
+                # pipelined with another stream: a persistent cluster launch that starts while chip-filling GEMMs of the
+                # other stream are draining gets a lopsided workgroup placement for its whole life (measured 23 ms
+                # instead of 11 ms), so the deep scans wait for that stream's queued work first
+                dev.wait(es, hold_scans_for)
+            self._scan_multi(jobs, "_ws_multi")
         for si, s in enumerate(sp.streams):
             name = s["name"]
             if len(s["layers"]) == 2 and s["residual"] and name in self.Y2 and save:
                 H = s["layers"][-1]["H"]
-                dev.stream(0)
-                dev.call("mgr_add2d", self.Y1[name], 2 * H, self.Y2[name], 2 * H, self.FEAT.view(cols[name], (1,)), W,
+                dev.call("mgr_add2d", self.Y1[name], 2 * H, self.Y2[name], 2 * H, feat_buf.view(cols[name], (1,)), W,
                          B * T, 2 * H)
+        self.rng_step = saved_step
+
+    def _enqueue_fusion_head(self, train, rand, feat_buf, rng_step):
+        """Fusion BiLSTM (projection GEMMs + recurrences) and Dropout/Dense/softmax on stream 0."""
+        sp, dev, B, T = self.spec, self.dev, self.B, self.T
+        W = sp.concat_width
+        save = train and not self.inference_only
+        saved_step, self.rng_step = self.rng_step, rng_step
         dev.stream(0)
-        for st in used_streams:
-            dev.wait(0, st)
-        feat, ldf = self.FEAT, W
+        feat, ldf = feat_buf, W
+        self._featin = feat_buf
         if sp.fusion:
             Hf = sp.fusion["H"]
             jobs = []
-            for di, (dname, st) in enumerate((("fwd", 0), ("bwd", 0))):
+            for di, dname in enumerate(("fwd", "bwd")):
                 L = self.dirs["fusion/%s" % dname]
-                dev.stream(st)
-                slot += 1
-                mptr = self._prep_mask(L, train, rand, slot)
+                mptr = self._prep_mask(L, train, rand, 500 + di)
                 self._masks[(L.prefix, L.d)] = mptr
-                dev.call("mgr_lstm_input_proj", self.FEAT, W, mptr, L.Wp, L.bp, self.ZF[di], B, T, W, Hf)
+                dev.call("mgr_lstm_input_proj", feat_buf, W, mptr, L.Wp, L.bp, self.ZF[di], B, T, W, Hf)
                 jobs.append(dict(Z=self.ZF[di], Up=L.Up, Y=self.YF.view(di * Hf, (1,)), ldy=2 * Hf, R=0, ldr=0,
                                  gates=L.gates if save else 0, cs=L.cs if save else 0, B=B, T=T, H=Hf,
                                  reverse=L.reverse))
-            dev.stream(0)
-            self._scan_multi(jobs)
+            self._scan_multi(jobs, "_ws_multi_f")
             feat, ldf = self.YF, 2 * Hf
         # head
         D, Cn = sp.head_width, sp.num_classes
@@ -392,16 +408,18 @@ class Engine:
         dev.call("mgr_dense_softmax_fwd", feat, ldf, hm, p_head, C.c_uint64(self._head_seed),
                  self._wview("dense/W"), self._wview("dense/b"), self.P, B, T, D, Cn)
         self._feat = (feat, ldf)
-        if train:
-            self.rng_step += 1
+        self.rng_step = saved_step
 
-    def _scan_multi(self, jobs):
+    def _scan_multi(self, jobs, wsname):
+        """One multi-scan call on the current stream; `wsname` keeps the encoder and fusion workspaces apart (they may
+        be in flight at the same time when steps are pipelined)."""
         arr = _capi.make_scan_jobs(jobs)
         need = self.lib.mgr_lstm_scan_multi_ws_bytes(len(jobs), arr)
-        if getattr(self, "_ws_multi", None) is None or self._ws_multi.nbytes < need:
-            self._ws_multi = self.mem.bytes(need)
-        _capi.check(self.lib.mgr_lstm_scan_fwd_multi(self.dev.ctx, len(jobs), arr, self._ws_multi.ptr,
-                                                     self._ws_multi.nbytes))
+        ws = getattr(self, wsname, None)
+        if ws is None or ws.nbytes < need:
+            ws = self.mem.bytes(need)
+            setattr(self, wsname, ws)
+        _capi.check(self.lib.mgr_lstm_scan_fwd_multi(self.dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes))
 
     # ------------------------------------------------------------------------------------------ public
     def predict(self, inputs):
@@ -438,18 +456,52 @@ class Engine:
                       1.0, self.loss_b, 0, self.ws_ctc, self.ws_ctc.nbytes)
         return self.loss_b.download()
 
-    def train_step(self, inputs, labels, input_length, label_length, rand=None, apply_update=True):
-        """One optimizer step (Keras train_on_batch).  Returns the mean CTC loss of the local batch."""
-        self.enqueue_train_step(inputs, labels, input_length, label_length, rand, apply_update)
+    def train_step(self, inputs, labels, input_length, label_length, rand=None, apply_update=True, next_inputs=None):
+        """One optimizer step (Keras train_on_batch).  Returns the mean CTC loss of the local batch.
+        next_inputs (optional): the inputs of the FOLLOWING call; when the encoders are frozen their pass for that batch
+        is overlapped with this step's fusion / BPTT / Adam work (bit-identical results)."""
+        self.enqueue_train_step(inputs, labels, input_length, label_length, rand, apply_update,
+                                prefetch_next=next_inputs is not None, next_inputs=next_inputs)
         return float(self.loss_mean.download()[0])
 
+    @property
+    def can_pipeline(self):
+        """Frozen encoders do not depend on the weights the step updates, so the encoder pass of step n+1 may run
+        while step n's fusion layer / CTC / BPTT / Adam are in flight (the fusion config of the reference)."""
+        sp = self.spec
+        return bool(sp.fusion) and not any(s["trainable"] for s in sp.streams) and not self.inference_only
+
     def enqueue_train_step(self, inputs, labels, input_length, label_length, rand=None, apply_update=True,
-                           upload=True):
+                           upload=True, prefetch_next=False, next_inputs=None):
+        """Enqueue one training step.  With prefetch_next (device-RNG training of a network whose encoders are frozen)
+        the NEXT step's encoder pass is enqueued on a second stream into the other FEAT buffer right after this step's
+        fusion work, and this step consumes the encoder pass enqueued by the previous call."""
         sp, dev, B, T = self.spec, self.dev, self.B, self.T
+        ES = 5  # encoder stream when pipelining
+        pipelined = prefetch_next and rand is None and self.can_pipeline
+        have = getattr(self, "_prefetched", None)
+        if have is not None:
+            stale = rand is not None or not self.can_pipeline
+            if upload and self._prefetched_for is not None and inputs is not self._prefetched_for:
+                stale = True   # the caller did not come back with the batch it announced
+            if stale:
+                dev.wait(0, ES)
+                have = self._prefetched = None
+        if have is None:
+            if upload:
+                self._upload_inputs(inputs, rand, True)
+            cur = self._feat_ring[self._feat_idx]
+            self._enqueue_encoders(True, rand, cur, 0, self.rng_step)   # nothing prefetched: do it now, in line
+        else:
+            cur = have
+            dev.wait(0, ES)          # this step's encoder pass (enqueued by the previous call) must be complete
         if upload:
-            self._upload_inputs(inputs, rand, True)
             self._upload_labels(labels, input_length, label_length)
-        self._forward(True, rand)
+        self._prefetched = None
+        if pipelined:
+            dev.wait(ES, 0)          # the other FEAT buffer was last read by the previous step's fusion phase
+        self._enqueue_fusion_head(True, rand, cur, self.rng_step)
+        self.rng_step += 1
         Cn, D = sp.num_classes, sp.head_width
         dev.stream(0)
         dev.call("mgr_ctc_loss_grad", self.P, self.labels_d, self.ilen_d, self.llen_d, B, T, Cn, self.Lmax,
@@ -471,7 +523,7 @@ class Engine:
                  self.ws_dense.nbytes)
         if sp.fusion:
             Hf = sp.fusion["H"]
-            self._bilstm_backward("fusion", self.dYF, 2 * Hf, self.FEAT, W, W, self.YF, 2 * Hf,
+            self._bilstm_backward("fusion", self.dYF, 2 * Hf, self._featin, W, W, self.YF, 2 * Hf,
                                   self.dFEAT if any_tr_stream else None, W)
         if any_tr_stream:
             col = 0
@@ -483,6 +535,18 @@ class Engine:
         dev.stream(0)
         if apply_update:
             self.apply_gradients()
+        if pipelined:
+            # encoder pass of the NEXT step, into the other FEAT buffer, concurrent with everything enqueued above
+            # (stream ES was made to wait for the previous step's fusion phase before this step's was enqueued)
+            self._feat_idx ^= 1
+            nxt = self._feat_ring[self._feat_idx]
+            self._prefetched_for = next_inputs
+            if next_inputs is not None:
+                dev.stream(ES)
+                self._upload_inputs(next_inputs, None, True, stream=ES)
+            self._enqueue_encoders(True, None, nxt, ES, self.rng_step, hold_scans_for=0)
+            self._prefetched = nxt
+            dev.stream(0)
 
     def _bilstm_backward(self, prefix, dY, lddy, Xin, ldx, fin, Hbuf, ldh, dX, lddx):
         """BPTT + parameter grads of one Bidirectional layer; the two directions run on streams 0 and 1."""

@@ -380,13 +380,26 @@ class Model:
             return dict(zip(names, x))
         return {names[0]: x}
 
-    def train_on_batch(self, x, y=None, rand=None):
-        ins = self._split_inputs(x)
+    def train_on_batch(self, x, y=None, rand=None, next_x=None):
+        """next_x: the batch of the FOLLOWING call (fit_generator passes it): with frozen encoders the engine overlaps
+        that batch's encoder pass with this step's trainable part."""
+        ins = self._cached_split(x)
         first = next(iter(ins.values()))
         B, T = first.shape[0], first.shape[1]
         labels = np.asarray(x["the_labels"])
         e = self._ensure_engine(B, T, labels.shape[1])
-        return e.train_step(ins, labels, x["input_length"], x["label_length"], rand=rand)
+        nxt = self._cached_split(next_x) if next_x is not None else None
+        return e.train_step(ins, labels, x["input_length"], x["label_length"], rand=rand, next_inputs=nxt)
+
+    def _cached_split(self, x):
+        """_split_inputs with identity preserved across calls (the engine matches a prefetched batch by identity)."""
+        key = id(x)
+        c = getattr(self, "_split_cache", None)
+        if c is not None and c[0] == key:
+            return c[1]
+        ins = self._split_inputs(x)
+        self._split_cache = (key, ins)
+        return ins
 
     def test_on_batch(self, x, y=None, rand=None):
         ins = self._split_inputs(x)
@@ -427,9 +440,12 @@ class Model:
                 if hasattr(cb, "on_epoch_begin"):
                     cb.on_epoch_begin(epoch, {})
             losses = []
+            pending = next(generator) if steps_per_epoch > 0 else None
             for step in range(steps_per_epoch):
-                x, y = next(generator)
-                losses.append(self.train_on_batch(x, y))
+                x, y = pending
+                # fetch the next batch early (never across an epoch boundary: on_epoch_end reshuffles the file lists)
+                pending = next(generator) if step + 1 < steps_per_epoch else None
+                losses.append(self.train_on_batch(x, y, next_x=pending[0] if pending is not None else None))
             logs = {"loss": float(np.mean(losses)) if losses else float("nan")}
             if validation_data is not None and validation_steps:
                 vl = []
