@@ -40,6 +40,16 @@ def skeletal_spec(numfeats=20, nb_classes=22, h=300, layers=2):
         optimizer={"lr": 1e-4, "decay": 1e-5, "clipvalue": 0.5, "maxnorm": 3.0}, name="sk_ctc_lstm")
 
 
+def early_fusion_spec(numfeats_speech=39, numfeats_skeletal=20, nb_classes=22, h=500):
+    """early_fusion/early_multimodal.py:321-418: concat(noisy audio, noisy skeletal) -> 2x BiLSTM(500, .4) + add -> Dropout(.4)."""
+    return NetworkSpec(
+        streams=[{"name": "early_concat", "inputs": ["the_input_audio", "the_input_skeletal"],
+                  "F": numfeats_speech + numfeats_skeletal, "noise": 0.5, "residual": True, "trainable": True,
+                  "layers": [{"H": h, "dropout": 0.4, "name": "blstm_1"}, {"H": h, "dropout": 0.4, "name": "blstm_2"}]}],
+        fusion=None, head={"dropout": 0.4, "C": nb_classes, "dropout_name": "dropout_layer_1"},
+        optimizer={"lr": 1e-4, "decay": 1e-5, "clipvalue": 0.5, "maxnorm": 3.0}, name="early_multimodal")
+
+
 def baseline_config(key):
     """BASELINE.json configs[] as (spec, B, T, Lmax)."""
     if key == "A":   # audio plumbing: 2-layer BiLSTM(128), 21 labels + blank
@@ -52,6 +62,8 @@ def baseline_config(key):
         return skeletal_spec(20, 22, 300, 2), 32, 1000, 28
     if key == "F":   # fusion at the reference's sizes (the metric's config)
         return fusion_spec(), 64, 1900, 35
+    if key == "E":   # early fusion: same kernels with F = 59, H = 500
+        return early_fusion_spec(), 16, 1900, 28
     if key == "F128":
         return fusion_spec(h_audio=128, h_skeletal=128, h_fusion=128), 64, 1900, 35
     raise KeyError(key)

@@ -226,9 +226,12 @@ class Model:
         sp = self.spec
         L = []
         for s in sp.streams:
-            L.append(Layer(s["name"], "InputLayer", self))
+            for n in (s.get("inputs") or [s["name"]]):
+                L.append(Layer(n, "InputLayer", self))
         for s in sp.streams:
             L.append(Layer("gaussian_noise_" + s["name"], "GaussianNoise", self, config={"stddev": s["noise"]}))
+            if s.get("inputs"):
+                L.append(Layer(s["name"], "Concatenate", self))
         for s in sp.streams:
             for k, lay in enumerate(s["layers"]):
                 L.append(Layer(lay.get("name", "%s_blstm_%d" % (s["name"], k + 1)), "Bidirectional", self,
@@ -375,7 +378,9 @@ class Model:
     def _split_inputs(self, x):
         names = [s["name"] for s in self.spec.streams]
         if isinstance(x, dict):
-            return {n: x[n] for n in names}
+            # a stream may read several graph inputs concatenated on the feature axis (early fusion)
+            return {s["name"]: (np.concatenate([np.asarray(x[k]) for k in s["inputs"]], axis=2) if s.get("inputs")
+                                else x[s["name"]]) for s in self.spec.streams}
         if isinstance(x, (list, tuple)):
             return dict(zip(names, x))
         return {names[0]: x}

@@ -2,6 +2,7 @@
  A  audio plumbing  : 2-layer BiLSTM(128)+CTC, B=8,  T=200,  39-d, full size, loss + gradients + one Adam step vs oracle
  S  skeletal        : BiLSTM(128)+CTC,         B=32, T=1000, 22-d, full size, loss vs oracle (1e-4 relative)
  F  fusion (ref sizes 500/300/100) at B=4, T=96 (the fp64 oracle needs minutes at T=1900): loss + trainable grads
+ E  early fusion: 2x BiLSTM(500) on the 59-d concatenated input, all trainable, B=4, T=64
  D  decode          : beam=10 and thresholded best-path on T=1900 sequences, label sequences bit-exact vs the oracle
 """
 import numpy as np
@@ -69,6 +70,10 @@ def test_config_F_reference_sizes_short_T(device):
 
 def test_config_F_ragged_batch_not_multiple_of_16(device):
     _run_case(device, "F", B=19, T=40, seed=1)
+
+
+def test_config_E_early_fusion_short_T(device):
+    _run_case(device, "E", B=4, T=64)
 
 
 def test_config_D_decode_long_sequences(device):

@@ -71,3 +71,33 @@ def test_unimodal_builders(device, tmp_path, monkeypatch):
     sg = skel.DataGenerator(minibatch_size=2, numfeats=20, maxlen=40, val_split=0.2, nb_classes=22, synthetic_files=10)
     x, y = next(sg.next_train())
     assert np.isfinite(s.train_on_batch(x, y)) and np.isfinite(s.test_on_batch(x, y))
+
+
+def test_early_fusion_builder(device, tmp_path, monkeypatch):
+    """early_fusion/early_multimodal.py flow: two-input dict -> concatenated 59-d stream -> train / predict / decode."""
+    import mgr_amd  # noqa: F401
+    from mgr_amd import decoding, keras_like as K
+    from mgr_amd.early_fusion import early_multimodal as early
+    from mgr_amd.early_fusion.sequence_decoding import decode_batch
+    monkeypatch.chdir(tmp_path)
+    decoding._DEV[0] = device
+    maxlen = 40
+    m = early.build_net(maxlen=maxlen, device=device)
+    assert os.path.exists("early_multimodal.json")
+    assert [l.name for l in m.layers[:2]] == ["the_input_audio", "the_input_skeletal"]
+    assert sum(int(np.prod(sh)) for _, sh, _, _ in m.spec.weight_table()) == 2 * (59 + 500 + 1) * 2000 + 2 * (1000 + 500 + 1) * 2000 + 1000 * 22 + 22
+    g = early.DataGenerator(minibatch_size=2, numfeats_skeletal=20, numfeats_speech=39, maxlen=maxlen, val_split=0.2,
+                            nb_classes=22, synthetic_files=10)
+    g.store.lmax = 4
+    x, y = next(g.next_train())
+    l1 = m.train_on_batch(x, y)
+    l2 = m.train_on_batch(x, y)
+    assert np.isfinite(l1) and np.isfinite(l2)
+    m.save_weights("early_multimodal.h5")
+    K.set_learning_phase(0)
+    m2 = early.load_model(device=device)
+    p1, p2 = m.predict_on_batch(x), m2.predict_on_batch(x)
+    assert p1.shape == (2, maxlen, 22) and np.array_equal(p1, p2)
+    res = decode_batch(p1, [1, 228])
+    assert len(res) == 2 and open("final_ctc_recout.mlf").read().count(".rec") == 1   # 228 is on the ignore list
+    K.set_learning_phase(1)
