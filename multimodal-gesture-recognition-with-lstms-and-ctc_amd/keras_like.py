@@ -329,13 +329,25 @@ class Model:
         self.set_weights_dict(dict(zip(names, lst)))
 
     def save_weights(self, filepath, overwrite=True):
+        """``*.h5`` / ``*.hdf5``: an HDF5 file in the Keras 2.1.4 ``save_weights`` layout (keras_io / h5lite - no h5py);
+        any other name: a numpy ``.npz`` archive under exactly that name."""
         w = self.get_weights_dict()
+        if str(filepath).lower().endswith((".h5", ".hdf5")):
+            from .keras_io import save_keras_weights
+            save_keras_weights(filepath, self.spec, w)
+            return
         with open(filepath, "wb") as f:
             np.savez(f, **{k.replace("/", "__"): v for k, v in w.items()})
 
     def load_weights(self, filepath, by_name=False):
-        with np.load(filepath) as z:
-            w = {k.replace("__", "/"): z[k] for k in z.files}
+        """Reads a Keras HDF5 weights file (written by Keras itself or by save_weights above) or an ``.npz`` archive."""
+        from . import h5lite
+        if h5lite.is_hdf5(filepath):
+            from .keras_io import load_keras_weights
+            w = load_keras_weights(filepath, self.spec)
+        else:
+            with np.load(filepath) as z:
+                w = {k.replace("__", "/"): z[k] for k in z.files}
         if by_name:
             w = {k: v for k, v in w.items() if k in dict((n, 1) for n, _, _, _ in self.spec.weight_table())}
         self.set_weights_dict(w)
@@ -483,5 +495,11 @@ class Model:
 
 
 def model_from_json(text, device=0):
-    """keras.models.model_from_json for the JSON this package writes (Model.to_json)."""
+    """keras.models.model_from_json: accepts the JSON this package writes (Model.to_json) and the functional-API JSON
+    Keras 2.1.4 writes for the reference's networks (keras_io.spec_from_keras_json)."""
+    d = json.loads(text)
+    if d.get("class_name") == "Model":
+        from .keras_io import spec_from_keras_json
+        spec, _, _ = spec_from_keras_json(d)
+        return Model(spec, device=device)
     return Model(NetworkSpec.from_json(text), device=device)
