@@ -114,6 +114,9 @@ enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 8 };
 int mgr_tune(mgr_ctx* ctx, int key, int value);
 /* Diagnostic: out[b] = XCC (XCD) id the workgroup b of a (nblocks, threads, lds_bytes) launch ran on. */
 int mgr_probe_xcc(mgr_ctx* ctx, int nblocks, int threads, int lds_bytes, int32_t* out);
+/* Hold the current stream for ~us microseconds on the device (bounded; 0 <= us <= 100000).  Scheduling aid: lets a
+ * persistent multi-CU scan launched on another stream become resident before this stream's chip-filling GEMMs start. */
+int mgr_stream_delay(mgr_ctx* ctx, int us);
 /* BPTT: dY[b,t,0:H] (row stride lddy) is dLoss/dh_t from above; Y (stride ldy) is the layer's own output as
  * written by scan_fwd WITHOUT residual (needed only through gates/cs here).  Produces dZ [B,T,4H] packed. */
 int mgr_lstm_scan_bwd(mgr_ctx* ctx, const float* dY, int lddy, const float* gates, const float* cs,

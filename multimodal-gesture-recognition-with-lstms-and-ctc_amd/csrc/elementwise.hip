@@ -158,7 +158,27 @@ __global__ void k_probe_xcc(int32_t* out) {
 
 }  // namespace
 
+// Holds the stream for ~`us` microseconds (constant 100 MHz counter), bounded.  Used to order the PLACEMENT of two launches
+// that become ready at the same moment on different streams (a persistent cluster scan must be resident before chip-filling
+// GEMM waves arrive, see Engine.enqueue_train_step).
+__global__ void k_delay(int us) {
+  const unsigned long long t0 = wall_clock64();
+  const unsigned long long ticks = (unsigned long long)us * 100ull;
+  for (int i = 0; i < (1 << 22); ++i) {
+    if (wall_clock64() - t0 >= ticks) break;
+    __builtin_amdgcn_s_sleep(16);
+  }
+}
+
 extern "C" {
+
+int mgr_stream_delay(mgr_ctx* c, int us) {
+  MGR_REQUIRE(c && us >= 0 && us <= 100000, "bad argument");
+  if (us == 0) return 0;
+  hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, mgr_stream(c), us);
+  MGR_LAUNCH_CHECK();
+  return 0;
+}
 
 int mgr_probe_xcc(mgr_ctx* c, int nblocks, int threads, int lds_bytes, int32_t* out) {
   MGR_REQUIRE(c && out && nblocks > 0 && threads > 0, "bad argument");

@@ -7,6 +7,7 @@ Keras' ``train_on_batch`` / ``predict_on_batch`` do for the reference (multimoda
 multimodal_fusion/sequence_decoding.py:121); there is no CPU fallback.
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -156,6 +157,8 @@ class Engine:
         self._feat_idx = 0
         self._prefetched = None
         self._prefetched_for = None
+        self.defer_param_grads = os.environ.get("MGR_DEFER_TN", "1") != "0"
+        self.defer_delay_us = int(os.environ.get("MGR_DEFER_DELAY_US", "150"))
         self._masks = {}
         any_tr_stream = any(s["trainable"] for s in sp.streams)
         if sp.fusion:
@@ -294,7 +297,7 @@ class Engine:
         if train:
             self.rng_step += 1
 
-    def _enqueue_encoders(self, train, rand, feat_buf, es, rng_step, hold_scans_for=None):
+    def _enqueue_encoders(self, train, rand, feat_buf, es, rng_step, hold_scans_for=None, before_last_scan=None):
         """Noise + every encoder depth (input-projection GEMMs, then all recurrences of the depth in one multi-scan
         call), written into feat_buf.  Everything is enqueued on stream `es`."""
         sp, dev, B, T = self.spec, self.dev, self.B, self.T
@@ -359,6 +362,9 @@ class Engine:
                 # other stream are draining gets a lopsided workgroup placement for its whole life (measured 23 ms
                 # instead of 11 ms), so the deep scans wait for that stream's queued work first
                 dev.wait(es, hold_scans_for)
+            if before_last_scan is not None and k == depth - 1 and k >= 1:
+                before_last_scan()
+                dev.stream(es)
             self._scan_multi(jobs, "_ws_multi")
         for si, s in enumerate(sp.streams):
             name = s["name"]
@@ -521,10 +527,12 @@ class Engine:
         dev.call("mgr_dense_bwd", feat, ldf, hm, p_head, C.c_uint64(hseed), self.dLogits, self._wview("dense/W"),
                  self._gview("dense/W"), self._gview("dense/b"), dA, ldda, B, T, D, Cn, self.ws_dense,
                  self.ws_dense.nbytes)
+        deferred = None
         if sp.fusion:
             Hf = sp.fusion["H"]
-            self._bilstm_backward("fusion", self.dYF, 2 * Hf, self._featin, W, W, self.YF, 2 * Hf,
-                                  self.dFEAT if any_tr_stream else None, W)
+            deferred = self._bilstm_backward("fusion", self.dYF, 2 * Hf, self._featin, W, W, self.YF, 2 * Hf,
+                                             self.dFEAT if any_tr_stream else None, W,
+                                             defer_param_grads=pipelined and self.defer_param_grads)
         if any_tr_stream:
             col = 0
             for si, s in enumerate(sp.streams):
@@ -533,9 +541,17 @@ class Engine:
                     self._stream_backward(s, col)
                 col += wout
         dev.stream(0)
-        if apply_update:
-            self.apply_gradients()
-        if pipelined:
+
+        def finish():
+            dev.stream(0)
+            if deferred is not None:
+                deferred()
+            if apply_update:
+                self.apply_gradients()
+
+        if not pipelined:
+            finish()
+        else:
             # encoder pass of the NEXT step, into the other FEAT buffer, concurrent with everything enqueued above
             # (stream ES was made to wait for the previous step's fusion phase before this step's was enqueued)
             self._feat_idx ^= 1
@@ -544,12 +560,27 @@ class Engine:
             if next_inputs is not None:
                 dev.stream(ES)
                 self._upload_inputs(next_inputs, None, True, stream=ES)
-            self._enqueue_encoders(True, None, nxt, ES, self.rng_step, hold_scans_for=0)
+            if deferred is None:
+                finish()
+                self._enqueue_encoders(True, None, nxt, ES, self.rng_step, hold_scans_for=0)
+            else:
+                # the dW/dU GEMMs of THIS step and the optimizer are held back until the next step's deepest projection
+                # GEMMs are done and then run beside its deepest encoder scan: GEMM next to GEMM gains nothing, whereas a
+                # big scan leaves most of the MFMA issue slots free (tools/overlap_probe.py: scan x1.12, GEMM at 1/3 speed)
+                def under_last_scan():
+                    dev.wait(0, ES)
+                    dev.stream(0)
+                    # both streams become ready at the same instant; the scan's workgroups must be placed first (one per CU)
+                    # or they trickle in behind GEMM waves and the whole scan runs at half speed (measured 22.7 vs 11.4 ms)
+                    dev.call("mgr_stream_delay", self.defer_delay_us)
+                    finish()
+                self._enqueue_encoders(True, None, nxt, ES, self.rng_step, before_last_scan=under_last_scan)
             self._prefetched = nxt
             dev.stream(0)
 
-    def _bilstm_backward(self, prefix, dY, lddy, Xin, ldx, fin, Hbuf, ldh, dX, lddx):
-        """BPTT + parameter grads of one Bidirectional layer; the two directions run on streams 0 and 1."""
+    def _bilstm_backward(self, prefix, dY, lddy, Xin, ldx, fin, Hbuf, ldh, dX, lddx, defer_param_grads=False):
+        """BPTT + parameter grads of one Bidirectional layer (both directions in one persistent launch).
+        defer_param_grads: return the dW/dU/db GEMM launches as a closure instead of enqueuing them now."""
         dev, B, T = self.dev, self.B, self.T
         jobs = []
         for di, dname in enumerate(("fwd", "bwd")):
@@ -565,17 +596,21 @@ class Engine:
             self._ws_bwd_multi = self.mem.bytes(need)
         _capi.check(self.lib.mgr_lstm_scan_bwd_multi(dev.ctx, len(jobs), arr, self._ws_bwd_multi.ptr,
                                                      self._ws_bwd_multi.nbytes))
-        for di, dname in enumerate(("fwd", "bwd")):
-            L = self.dirs["%s/%s" % (prefix, dname)]
-            H = L.H
-            mptr = self._masks.get((L.prefix, L.d), 0)
-            dev.call("mgr_lstm_param_grads", Xin, ldx, mptr, Hbuf.view(di * H, (1,)), ldh, L.dZ, L.gWp, L.gUp, L.gbp,
-                     B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes)
+        def param_grads():
+            for di, dname in enumerate(("fwd", "bwd")):
+                L = self.dirs["%s/%s" % (prefix, dname)]
+                H = L.H
+                mptr = self._masks.get((L.prefix, L.d), 0)
+                dev.call("mgr_lstm_param_grads", Xin, ldx, mptr, Hbuf.view(di * H, (1,)), ldh, L.dZ, L.gWp, L.gUp,
+                         L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes)
+        if not defer_param_grads:
+            param_grads()
         if dX is not None:
             for di, dname in enumerate(("fwd", "bwd")):
                 L = self.dirs["%s/%s" % (prefix, dname)]
                 mptr = self._masks.get((L.prefix, L.d), 0)
                 dev.call("mgr_lstm_input_grad", L.dZ, L.Wp, mptr, dX, lddx, 1 if di == 1 else 0, B, T, fin, L.H)
+        return param_grads if defer_param_grads else None
 
     def _stream_backward(self, s, col):
         sp, dev, B, T = self.spec, self.dev, self.B, self.T
