@@ -42,8 +42,8 @@ def cpu_baseline(spec_dict, seed, T_cpu, B_cpu):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="F")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
     ap.add_argument("--maxlen", type=int, default=0)
@@ -111,7 +111,7 @@ def main():
         # not prefetch, so exactly K complete steps - K encoder passes, K fusion passes - lie inside the timed region.
         eng.enqueue_train_step(None, None, None, None, rand=None, apply_update=True, upload=False,
                                prefetch_next=prefetch and not args.no_pipeline)
-        return float(eng.loss_mean.download()[0])
+        return eng.read_loss()
 
     for i in range(args.warmup):
         loss = step(i + 1 < args.warmup)

@@ -468,7 +468,18 @@ class Engine:
         is overlapped with this step's fusion / BPTT / Adam work (bit-identical results)."""
         self.enqueue_train_step(inputs, labels, input_length, label_length, rand, apply_update,
                                 prefetch_next=next_inputs is not None, next_inputs=next_inputs)
-        return float(self.loss_mean.download()[0])
+        return self.read_loss()
+
+    LOSS_STREAM = 6
+
+    def read_loss(self):
+        """Mean CTC loss of the step enqueued last.  Read on its own stream, which only waits for the loss kernels - not
+        for the gradient GEMMs / optimizer queued behind them - so the host can enqueue the next step early."""
+        dev = self.dev
+        dev.stream(self.LOSS_STREAM)
+        v = float(self.loss_mean.download()[0])
+        dev.stream(0)
+        return v
 
     @property
     def can_pipeline(self):
@@ -514,6 +525,7 @@ class Engine:
                  int(sp.ctc["skip"]), Cn - 1, float(sp.ctc["eps"]), 1.0 / B, self.loss_b, self.dLogits,
                  self.ws_ctc, self.ws_ctc.nbytes)
         dev.call("mgr_mean", self.loss_b, B, self.loss_mean)
+        dev.wait(self.LOSS_STREAM, 0)
         feat, ldf = self._feat
         hm, p_head, hseed = self._head_args
         any_tr_stream = any(s["trainable"] for s in sp.streams)
