@@ -3,7 +3,7 @@
 TAG=${1:-r01}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
-cd $R && timeout 600 python bench.py --steps 5 --warmup 2 > gpurun_out/${TAG}_bench.log 2>&1
+cd $R && timeout 600 python bench.py > gpurun_out/${TAG}_bench.log 2>&1
 tail -1 gpurun_out/${TAG}_bench.log > gpurun_out/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/${TAG}_prof
