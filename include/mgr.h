@@ -194,6 +194,14 @@ int mgr_ctc_beam_search(mgr_ctx* ctx, const float* P, const int32_t* input_len, 
                         int blank, int beam, float eps, int merge_repeated, int32_t* out, int32_t* out_len,
                         double* logp, void* ws, size_t ws_bytes);
 
+/* ---- skeletal feature extraction (skeletal_network/skeletal_feature_extraction.py:24-215), fp64 like the original.
+ * joints[n_frames][12] = lhX lhY rhX rhY leX leY reX reY hipX hipY shcX shcY of the WHOLE frame table in file order;
+ * out[n_frames][23] = lh_v rh_v le_v re_v | lh_a rh_a le_a re_a | hands_d | lh,rh,le,re _hip_d | lh,rh,le,re _shc_d |
+ * lh_hip_ang rh_hip_ang lh_shc_ang rh_shc_ang lh_el_ang rh_el_ang.  Velocities / accelerations of rows 0..4 are 0. */
+#define MGR_SKELETAL_JOINT_COLS 12
+#define MGR_SKELETAL_FEATURE_COLS 23
+int mgr_skeletal_features(mgr_ctx* ctx, const double* joints, size_t n_frames, double* out);
+
 #ifdef __cplusplus
 }
 #endif

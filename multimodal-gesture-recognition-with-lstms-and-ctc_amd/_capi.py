@@ -48,6 +48,7 @@ SIGNATURES = {
     "mgr_tune": (i32, [vp, i32, i32]),
     "mgr_probe_xcc": (i32, [vp, i32, i32, i32, vp]),
     "mgr_stream_delay": (i32, [vp, i32]),
+    "mgr_skeletal_features": (i32, [vp, vp, sz, vp]),
     "mgr_lstm_scan_bwd_multi_ws_bytes": (sz, [i32, vp]),
     "mgr_lstm_scan_bwd_multi": (i32, [vp, i32, vp, vp, sz]),
     "mgr_lstm_scan_bwd": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz]),

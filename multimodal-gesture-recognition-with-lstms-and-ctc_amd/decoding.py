@@ -113,3 +113,31 @@ def label_error_rate(hyps, refs):
     num = sum(edit_distance(h, r) for h, r in zip(hyps, refs))
     den = sum(len(r) for r in refs)
     return num / max(1, den)
+
+
+def read_mlf(path):
+    """HTK master label file -> {sample name: [labels]} (the layout write_mlf produces: '"*/Sample00001.rec"' lines,
+    one label per line, '.' terminator).  '.lab' and '.rec' entries are keyed by the bare sample name."""
+    out, cur = {}, None
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if not line or line == "#!MLF!#":
+                continue
+            if line.startswith('"'):
+                name = line.strip('"').split("/")[-1]
+                cur = out.setdefault(name.rsplit(".", 1)[0], [])
+            elif line == ".":
+                cur = None
+            elif cur is not None:
+                cur.append(line.split()[-1] if len(line.split()) > 1 and line.split()[0].isdigit() else line.split()[0])
+    return out
+
+
+def score_mlf(ref_path, rec_path, ignore=("sil",)):
+    """Label error rate of a recognition MLF against a reference MLF, over the samples present in both
+    (HResults-style: (S + D + I) / N after removing the `ignore` labels).  Returns (ler, n_samples)."""
+    ref, rec = read_mlf(ref_path), read_mlf(rec_path)
+    names = sorted(set(ref) & set(rec))
+    strip = lambda seq: [x for x in seq if x not in ignore]
+    return label_error_rate([strip(rec[n]) for n in names], [strip(ref[n]) for n in names]), len(names)

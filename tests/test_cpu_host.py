@@ -175,3 +175,31 @@ def test_shard_batch():
     assert s1["a"].ravel().tolist() == [2, 3] and s1["b"].shape == (2, 2)
     with pytest.raises(ValueError):
         shard_batch(batch, 0, 3)
+
+
+def test_mlf_round_trip_and_scoring(tmp_path):
+    from mgr_amd import decoding
+    hyp = [["sil", "VA", "sil", "OK"], ["sil"], ["CP", "CV"]]
+    ref = [["VA", "OK"], ["FU"], ["CP", "sil", "CV"]]
+    decoding.write_mlf(str(tmp_path / "rec.mlf"), hyp, [1, 2, 3], [], "Sample%05d")
+    decoding.write_mlf(str(tmp_path / "ref.mlf"), ref, [1, 2, 3, ], [], "Sample%05d")
+    got = decoding.read_mlf(str(tmp_path / "rec.mlf"))
+    assert got == {"Sample00001": hyp[0], "Sample00002": hyp[1], "Sample00003": hyp[2]}
+    ler, n = decoding.score_mlf(str(tmp_path / "ref.mlf"), str(tmp_path / "rec.mlf"))
+    assert n == 3 and ler == pytest.approx(1 / 5)      # one deletion (FU) over 5 reference labels
+
+
+def test_skeletal_feature_oracle_properties():
+    """The CPU restatement of skeletal_feature_extraction.py: shift-over-whole-table and first-five-rows rules."""
+    from oracle import skeletal_ref as sr
+    rng = np.random.default_rng(0)
+    n = 40
+    J = {c: rng.uniform(0, 640, n) for c in sr.JOINT_COLS}
+    F = sr.extract_features(J)
+    assert list(F) == sr.FEATURE_COLS and all(v.shape == (n,) for v in F.values())
+    assert np.all(F['lh_v'][:5] == 0) and np.all(F['re_a'][:5] == 0)
+    assert F['lh_v'][7] == np.sqrt((J['lhX'][7] - J['lhX'][6]) ** 2 + (J['lhY'][7] - J['lhY'][6]) ** 2)
+    assert F['lh_a'][5] == F['lh_v'][5] and F['rh_a'][9] == F['rh_v'][9] - F['rh_v'][8]
+    assert F['lh_el_ang'][3] == np.arctan2(J['lhY'][3] - J['leY'][3], J['lhX'][3] - J['leX'][3])
+    assert F['re_shc_d'][0] == np.hypot(J['reX'][0] - J['shcX'][0], J['reY'][0] - J['shcY'][0]) or \
+        abs(F['re_shc_d'][0] - np.hypot(J['reX'][0] - J['shcX'][0], J['reY'][0] - J['shcY'][0])) < 1e-12
