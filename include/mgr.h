@@ -56,6 +56,7 @@ int mgr_sync(mgr_ctx* ctx);
 int mgr_stream_set(mgr_ctx* ctx, int idx);
 int mgr_stream_wait(mgr_ctx* ctx, int waiter, int waited); /* waiter waits for everything queued on waited */
 int mgr_event_record(mgr_ctx* ctx, int ev);               /* on the current stream */
+int mgr_stream_wait_event(mgr_ctx* ctx, int waiter, int ev); /* stream `waiter` waits for event ev as last recorded */
 int mgr_event_elapsed_ms(mgr_ctx* ctx, int ev0, int ev1, float* ms);
 /* Per-kernel-family device timing (HIP events around each launch, on the launch stream).
  * family ids: MGR_K_*.  mgr_prof_get syncs the device and returns accumulated launches / milliseconds. */

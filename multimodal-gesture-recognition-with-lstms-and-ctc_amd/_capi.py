@@ -32,6 +32,7 @@ SIGNATURES = {
     "mgr_stream_set": (i32, [vp, i32]),
     "mgr_stream_wait": (i32, [vp, i32, i32]),
     "mgr_event_record": (i32, [vp, i32]),
+    "mgr_stream_wait_event": (i32, [vp, i32, i32]),
     "mgr_event_elapsed_ms": (i32, [vp, i32, i32, C.POINTER(C.c_float)]),
     "mgr_prof_enable": (i32, [vp, i32]),
     "mgr_prof_get": (i32, [vp, i32, C.POINTER(i32), C.POINTER(C.c_float)]),
@@ -241,6 +242,9 @@ class Device:
 
     def record(self, ev):
         check(self.lib.mgr_event_record(self.ctx, ev))
+
+    def wait_event(self, waiter, ev):
+        check(self.lib.mgr_stream_wait_event(self.ctx, waiter, ev))
 
     def elapsed_ms(self, ev0, ev1):
         ms = C.c_float()

@@ -140,6 +140,13 @@ int mgr_stream_wait(mgr_ctx* c, int waiter, int waited) {
   return 0;
 }
 
+int mgr_stream_wait_event(mgr_ctx* c, int waiter, int ev) {
+  MGR_REQUIRE(c && ev >= 0 && ev < MGR_NUM_EVENTS, "bad event index");
+  MGR_REQUIRE(waiter >= 0 && waiter < MGR_NUM_STREAMS, "bad stream index");
+  MGR_HIP(hipStreamWaitEvent(c->streams[waiter], c->events[ev], 0));
+  return 0;
+}
+
 int mgr_event_record(mgr_ctx* c, int ev) {
   MGR_REQUIRE(c && ev >= 0 && ev < MGR_NUM_EVENTS, "bad event index");
   MGR_HIP(hipEventRecord(c->events[ev], mgr_stream(c)));

@@ -159,6 +159,8 @@ class Engine:
         self._prefetched_for = None
         self.defer_param_grads = os.environ.get("MGR_DEFER_TN", "1") != "0"
         self.defer_delay_us = int(os.environ.get("MGR_DEFER_DELAY_US", "150"))
+        # opt-in experiment (measured slower): start the next step's depth-1 scan before this step's fusion layer
+        self.early_encoders = os.environ.get("MGR_EARLY_ENC", "0") == "1"
         self._masks = {}
         any_tr_stream = any(s["trainable"] for s in sp.streams)
         if sp.fusion:
@@ -300,6 +302,24 @@ class Engine:
     def _enqueue_encoders(self, train, rand, feat_buf, es, rng_step, hold_scans_for=None, before_last_scan=None):
         """Noise + every encoder depth (input-projection GEMMs, then all recurrences of the depth in one multi-scan
         call), written into feat_buf.  Everything is enqueued on stream `es`."""
+        depth = max(len(s["layers"]) for s in self.spec.streams)
+        for tag, k in self._encoder_phases(train, rand, feat_buf, es, rng_step):
+            if tag != "projected":
+                continue
+            if hold_scans_for is not None and k >= 1:
+                # pipelined with another stream: a persistent cluster launch that starts while chip-filling GEMMs of the
+                # other stream are draining gets a lopsided workgroup placement for its whole life (measured 23 ms
+                # instead of 11 ms), so the deep scans wait for that stream's queued work first
+                self.dev.stream(es)
+                self.dev.wait(es, hold_scans_for)
+            if before_last_scan is not None and k == depth - 1 and k >= 1:
+                before_last_scan()
+
+    def _encoder_phases(self, train, rand, feat_buf, es, rng_step):
+        """Generator form of the encoder pass: yields ("projected", k) after the projection GEMMs of depth k are enqueued
+        (before its scan) and ("scanned", k) after its multi-scan launch, so that a caller can interleave work of another
+        stream at those points.  Re-selects stream `es` after every resume; self.rng_step is only switched to `rng_step`
+        while the generator body runs."""
         sp, dev, B, T = self.spec, self.dev, self.B, self.T
         W = sp.concat_width
         save = train and not self.inference_only
@@ -356,16 +376,16 @@ class Engine:
                     keep = save and L.trainable
                     jobs.append(dict(Z=Z, Up=L.Up, Y=Y, ldy=ldy, R=R, ldr=ldr, gates=L.gates if keep else 0,
                                      cs=L.cs if keep else 0, B=B, T=T, H=H, reverse=L.reverse))
+            self.rng_step = saved_step
+            yield ("projected", k)
+            saved_step, self.rng_step = self.rng_step, rng_step
+            dev.stream(es)
             # all recurrences of this depth in ONE call (one persistent multi-CU launch when H is large)
-            if hold_scans_for is not None and k >= 1:
-                # pipelined with another stream: a persistent cluster launch that starts while chip-filling GEMMs of the
-                # other stream are draining gets a lopsided workgroup placement for its whole life (measured 23 ms
-                # instead of 11 ms), so the deep scans wait for that stream's queued work first
-                dev.wait(es, hold_scans_for)
-            if before_last_scan is not None and k == depth - 1 and k >= 1:
-                before_last_scan()
-                dev.stream(es)
             self._scan_multi(jobs, "_ws_multi")
+            self.rng_step = saved_step
+            yield ("scanned", k)
+            saved_step, self.rng_step = self.rng_step, rng_step
+            dev.stream(es)
         for si, s in enumerate(sp.streams):
             name = s["name"]
             if len(s["layers"]) == 2 and s["residual"] and name in self.Y2 and save:
@@ -515,8 +535,33 @@ class Engine:
         if upload:
             self._upload_labels(labels, input_length, label_length)
         self._prefetched = None
+        depth = max(len(s_["layers"]) for s_ in sp.streams)
+        # early start: the next step's depth-1 projections and scan are enqueued BEFORE this step's fusion layer, whose
+        # projection GEMMs then run beside that scan instead of beside the depth-1 projection GEMMs
+        early = (pipelined and have is not None and sp.fusion is not None and self.defer_param_grads
+                 and self.early_encoders and depth >= 2)
+        phases = None
+        EV_PREV = 40
         if pipelined:
-            dev.wait(ES, 0)          # the other FEAT buffer was last read by the previous step's fusion phase
+            # the other FEAT buffer was last read by the previous step's fusion phase (its dW GEMMs, queued on stream 0)
+            if early:
+                dev.stream(0)
+                dev.record(EV_PREV)   # only the launch that WRITES that buffer (the deepest scan) has to wait for it
+            else:
+                dev.wait(ES, 0)
+        if early:
+            self._feat_idx ^= 1
+            nxt = self._feat_ring[self._feat_idx]
+            self._prefetched_for = next_inputs
+            if next_inputs is not None:
+                dev.stream(ES)
+                self._upload_inputs(next_inputs, None, True, stream=ES)
+            phases = self._encoder_phases(True, None, nxt, ES, self.rng_step + 1)
+            assert next(phases) == ("projected", 0)
+            dev.wait(0, ES)           # this step's fusion projections start when the next step's depth-1 ones are done
+            assert next(phases) == ("scanned", 0)
+            dev.stream(0)
+            dev.call("mgr_stream_delay", self.defer_delay_us)   # ... and after that scan's workgroups are resident
         self._enqueue_fusion_head(True, rand, cur, self.rng_step)
         self.rng_step += 1
         Cn, D = sp.num_classes, sp.head_width
@@ -561,8 +606,23 @@ class Engine:
             if apply_update:
                 self.apply_gradients()
 
+        def under_last_scan():
+            dev.wait(0, ES)
+            dev.stream(0)
+            # both streams become ready at the same instant; the scan's workgroups must be placed first (one per CU)
+            # or they trickle in behind GEMM waves and the whole scan runs at half speed (measured 22.7 vs 11.4 ms)
+            dev.call("mgr_stream_delay", self.defer_delay_us)
+            finish()
+
         if not pipelined:
             finish()
+        elif early:
+            for tag, k in phases:
+                if tag == "projected" and k == depth - 1:
+                    under_last_scan()
+                    dev.wait_event(ES, EV_PREV)
+            self._prefetched = nxt
+            dev.stream(0)
         else:
             # encoder pass of the NEXT step, into the other FEAT buffer, concurrent with everything enqueued above
             # (stream ES was made to wait for the previous step's fusion phase before this step's was enqueued)
@@ -579,13 +639,6 @@ class Engine:
                 # the dW/dU GEMMs of THIS step and the optimizer are held back until the next step's deepest projection
                 # GEMMs are done and then run beside its deepest encoder scan: GEMM next to GEMM gains nothing, whereas a
                 # big scan leaves most of the MFMA issue slots free (tools/overlap_probe.py: scan x1.12, GEMM at 1/3 speed)
-                def under_last_scan():
-                    dev.wait(0, ES)
-                    dev.stream(0)
-                    # both streams become ready at the same instant; the scan's workgroups must be placed first (one per CU)
-                    # or they trickle in behind GEMM waves and the whole scan runs at half speed (measured 22.7 vs 11.4 ms)
-                    dev.call("mgr_stream_delay", self.defer_delay_us)
-                    finish()
                 self._enqueue_encoders(True, None, nxt, ES, self.rng_step, before_last_scan=under_last_scan)
             self._prefetched = nxt
             dev.stream(0)
