@@ -110,7 +110,8 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
 /* Tuning / test hooks.  key 0 (MGR_TUNE_SCAN_PATH): 0 auto, 1 force the L2-streaming fallback kernels,
  * 2 force one workgroup per batch group (no inter-CU exchange) where it fits, 3 force clusters with 4 tiles per
  * workgroup, 4 same with 8 tiles per workgroup.  key 1: !=0 makes scan_fwd check the give-up word synchronously.
- * key 2: print the scan plan.  key 3: opt into the XCD-local exchange path (measured slower; kept for study). */
+ * key 2: print the scan plan.  key 3: opt into the XCD-local exchange path (measured slower; kept for study).
+ * key 7: 1 = one-tile-per-wave clusters keep the LDS-image step instead of the K-split / register-direct gather step. */
 enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 8 };
 int mgr_tune(mgr_ctx* ctx, int key, int value);
 /* Diagnostic: out[b] = XCC (XCD) id the workgroup b of a (nblocks, threads, lds_bytes) launch ran on. */

@@ -274,6 +274,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     L.status = status;
     L.xcd_local = c->tune[3];
     L.gather_delay = c->tune[6];
+    L.ksplit = c->tune[7] == 0;   // tune key 7: 1 = keep the LDS-image step for one-tile-per-wave clusters
     if (c->tune[2]) {  // tune key 2: print the plan
       for (int i = 0; i < L.njobs; ++i)
         fprintf(stderr, "[mgr scan plan] job %d: H=%d ks=%d nw=%d tpw=%d pair=%d G=%d nbg=%d wg_begin=%d\n", i, L.job[i].H,

@@ -31,6 +31,7 @@ struct ClusterLaunch {
   int xcd_local;     // opt-in: clusters found on one XCD exchange through its L2 (plain stores + nt loads)
   int gather_delay;  // 64-cycle sleeps between a workgroup's own publish and its first gather pass (a failed pass costs a
                      // full fabric round trip, a short wait is cheaper)
+  int ksplit;        // one-tile-per-wave clusters use the K-split step (cluster_run_ks): register-direct gather
   unsigned* status;  // [0] != 0 -> a bounded spin gave up
   ClusterJob job[MGR_MAX_SCAN_JOBS];
 };

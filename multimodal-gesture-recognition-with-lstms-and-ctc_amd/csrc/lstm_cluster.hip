@@ -530,6 +530,266 @@ __device__ __forceinline__ void cluster_run2(const ClusterJob& jb, int wg, float
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K-split variant of the one-tile-per-wave cluster step (4 waves, 4 tiles = ONE 1 KiB image block per workgroup).
+// Instead of gathering the whole h_{t-1} image into LDS, joining at a barrier and then letting every wave run the full
+// K loop for its own tile, wave w here owns a QUARTER OF K for ALL FOUR tiles of the workgroup:
+//   * it polls only the image blocks of its K range and takes them STRAIGHT INTO REGISTERS as MFMA B operands (the
+//     block layout [kk][sample][r] is exactly the B fragment of four consecutive k-steps) - no LDS image, no B-operand
+//     ds_reads under the MFMAs, no barrier between gather and MFMA; blocks that have arrived are consumed at once,
+//     blocks still showing the previous epoch are polled again.  (A second register set, so that the re-poll is in
+//     flight under the MFMAs of the arrived blocks, does not fit: 128 weight + 64 polling registers spill at 256.)
+//   * the four partial sums per tile are exchanged through 12 KiB of LDS (double-buffered on the step parity: ONE
+//     barrier per step) and wave w finishes tile w: adds Z_t, runs the cell, publishes h_t (same data-is-the-flag
+//     parity words as cluster_run) and streams Y / gates / c out.
+// Exchange bytes per workgroup and step are unchanged (each wave fetches a distinct quarter of the image).
+template <int KS>
+__device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, int bg, int ug, float* smem, unsigned* status, int dbg_mode) {
+  constexpr int H = 4 * KS, N = 4 * H, QN = (KS + 3) / 4, IMG = QN * 256, NBW = (QN + 3) / 4;
+  static_assert(NBW <= 8, "at most 8 image blocks per wave (H <= 512)");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..3
+  const int j = lane & 15, uq = lane >> 4;
+  const int B = jb.B, T = jb.T, reverse = jb.reverse;
+  const int b = bg * 16 + j;
+  const bool bvalid = b < B;
+  const int bc = bvalid ? b : B - 1;
+  const float* __restrict__ Z = jb.Z;
+  const float* __restrict__ Up = jb.Up;
+
+  // K range of this wave: image blocks [qb, qb + nb)
+  const int qb = wave * NBW;
+  int nb = QN - qb;
+  nb = nb < 0 ? 0 : (nb > NBW ? NBW : nb);
+  nb = __builtin_amdgcn_readfirstlane(nb);
+
+  // U^T fragments of the workgroup's four tiles for this wave's k-steps (zero where tile or k-step does not exist)
+  float uf[4][NBW * 4];
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const int gt = ug * 4 + tt;
+#pragma unroll
+    for (int sl = 0; sl < NBW * 4; ++sl) {
+      const int s = qb * 4 + sl;
+      uf[tt][sl] = (gt < KS && s < KS) ? Up[(size_t)(4 * s + uq) * N + gt * 16 + j] : 0.f;
+    }
+  }
+  // the tile this wave finishes
+  const int tile = ug * 4 + wave;
+  const bool tvalid = tile < KS;  // wave-uniform
+  const int tl = tvalid ? tile : 0;
+  const int unit = tl * 4 + uq;
+
+  float* red = smem;  // [2][src wave][tile][lane] f32x4
+  float* xb = jb.xbuf + (size_t)bg * 2 * IMG;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, 2 * IMG * 4, 0x00020000);
+
+  float c = 0.f;
+  f32x4 zr0 = {0.f, 0.f, 0.f, 0.f}, zr1 = zr0, zr2 = zr0;
+  auto loadz = [&](f32x4& z, int step) {
+    if (step < T && tvalid) {
+      const int t = reverse ? T - 1 - step : step;
+      z = *reinterpret_cast<const f32x4*>(Z + ((size_t)bc * T + t) * N + (tl * 4 + uq) * 4);
+    }
+  };
+  loadz(zr0, 0);
+  loadz(zr1, 1);
+  bool failed = false;
+#ifdef MGR_ABLATE
+  const int ab = dbg_mode >= 200 ? dbg_mode - 200 : 0;   // bit flags, see tools/ablate_ks.py
+#endif
+#ifdef MGR_STAMP
+  unsigned long long ks_wait = 0, ks_mfma = 0, ks_red = 0, ks_cell = 0, ks_rounds = 0, ks_total = 0, ks_pre = 0, ks_t0 = 0;
+#define KSTAMP(x) unsigned long long x = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define KSTAMP(x)
+#endif
+
+  // ---- gather: the image blocks of this wave's K range go straight into registers.
+  // The loads are issued from inline asm, so hipcc does not know that the registers have loads pending and inserts no
+  // s_waitcnt in front of their readers; instead the wave POLLS THE REGISTERS: they are preset to a pattern no h word can
+  // have (quiet-NaN exponent, wrong epoch parity) and an empty asm with "+v" constraints makes every iteration re-read
+  // them.  A word that still shows the preset has not landed; a landed word with the previous epoch's parity means the
+  // producer was late and the block is fetched again.  Nothing here waits on vmcnt, so the wave's own write-through
+  // stores (whose acknowledgement takes longer than a load round trip) are never waited for.
+  auto hidden_load = [&](u32x4& dst, const char* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(dst) : "v"(p) : "memory");
+  };
+  auto touch = [&](u32x4 (&v)[NBW]) {
+    if constexpr (NBW == 8)
+      asm volatile("s_sleep 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])::"memory");
+    else if constexpr (NBW == 5)
+      asm volatile("s_sleep 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4])::"memory");
+    else if constexpr (NBW == 2)
+      asm volatile("s_sleep 1" : "+v"(v[0]), "+v"(v[1])::"memory");
+    else
+      static_assert(NBW == 8 || NBW == 5 || NBW == 2, "add a touch() arm for this block count");
+  };
+  auto mfmas = [&](const u32x4 (&v)[NBW], f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+      const float hv[4] = {__uint_as_float(v[i].x), __uint_as_float(v[i].y), __uint_as_float(v[i].z), __uint_as_float(v[i].w)};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)   // k-steps / blocks that do not exist carry zero weights
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[tt][i * 4 + r], hv[r], acc[tt], 0, 0, 0);
+      }
+    }
+  };
+
+  auto do_step = [&](int step, f32x4& zuse, f32x4& zload) {
+    const int t = reverse ? T - 1 - step : step;
+#ifdef MGR_STAMP
+    {
+      KSTAMP(b0);
+      if (step > 0) ks_total += b0 - ks_t0;
+      ks_t0 = b0;
+    }
+#endif
+#ifdef MGR_ABLATE
+    if (!(ab & 32))
+#endif
+    loadz(zload, step + 2);
+    f32x4 acc[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef MGR_ABLATE
+    if (step > 0 && nb > 0 && !failed && !(ab & 4)) {
+#else
+    if (step > 0 && nb > 0 && !failed) {
+#endif
+      const int slot = (step - 1) & 1;
+      const unsigned par = ((((unsigned)(step - 1)) >> 1) & 1u) ^ 1u;
+      const unsigned bad = 0x7FC00000u | (par ^ 1u);   // never a real h word (|h| < 1): bit 30 set, wrong parity
+      const char* gp[NBW];
+#pragma unroll
+      for (int i = 0; i < NBW; ++i) {
+        const int q = (i < nb) ? qb + i : QN - 1;        // unused slots re-read a valid block (their weights are zero)
+        gp[i] = reinterpret_cast<const char*>(xb) + ((size_t)slot * IMG + q * 256 + lane * 4) * 4;
+      }
+      u32x4 v[NBW];
+      unsigned rounds = 0, spins = 0;
+      bool issue = true;
+      for (;;) {
+        if (issue) {
+#pragma unroll
+          for (int i = 0; i < NBW; ++i) v[i] = (u32x4){bad, bad, bad, bad};
+#pragma unroll
+          for (int i = 0; i < NBW; ++i) hidden_load(v[i], gp[i]);
+          issue = false;
+          spins = 0;
+        }
+        touch(v);
+        unsigned a_and = v[0].x, a_or = v[0].x;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+          a_and &= v[i].x & v[i].y & v[i].z & v[i].w;
+          a_or |= v[i].x | v[i].y | v[i].z | v[i].w;
+        }
+        const bool lane_fresh = par ? (a_and & 1u) != 0u : (a_or & 1u) == 0u;
+#ifdef MGR_ABLATE
+        if ((ab & 1) && __all(((a_or >> 30) & 1u) == 0u)) break;   // timing ablation: take whatever landed
+#endif
+        if (__all(lane_fresh)) break;                 // every word shows this epoch (hence has landed)
+        if (__all(((a_or >> 30) & 1u) == 0u)) {       // everything landed, something was still the previous epoch
+          issue = true;
+          ++rounds;
+        } else if (++spins > 4096u) {                 // a load cannot take this long: drain and start over
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+          issue = true;
+          ++rounds;
+        }
+        if (issue) {
+          if ((rounds & 63u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) failed = true;
+          if (rounds > POLL_LIMIT) {
+            failed = true;
+            if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (failed) break;
+        }
+      }
+#ifdef MGR_ABLATE
+      if (!(ab & 2))
+#endif
+      mfmas(v, acc);
+      // keep the polling registers allocated until here, then make sure no re-issued load is still in flight before this
+      // wave publishes (a producer may overwrite the slot only after it has seen that publish)
+      touch(v);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    // the four partial sums of every tile meet in LDS (all four go through it: selecting "my own" accumulator by the
+    // run-time wave id would force the accumulators into scratch memory)
+    float* rbuf = red + (step & 1) * (16 * 64 * 4);
+    KSTAMP(r0);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(rbuf + ((tt * 4 + wave) * 64 + lane) * 4) = acc[tt];
+    __syncthreads();
+    KSTAMP(r1);
+    if (!tvalid) {
+      // padding tile of the last workgroup: its image words are still written every step (value 0, current parity), so
+      // that consumers can test whole blocks without knowing which words exist
+      if (step + 1 < T) {
+        const unsigned par0 = (((unsigned)step >> 1) & 1u) ^ 1u;
+        const int idx0 = (((tile >> 2) * 4 + uq) * 16 + j) * 4 + (tile & 3);
+        __builtin_amdgcn_raw_buffer_store_b32(par0, rs, ((step & 1) * IMG + idx0) * 4, 0, 16);
+      }
+    } else {
+      f32x4 tot = zuse;
+      const float* mine = rbuf + (wave * 4 * 64 + lane) * 4;   // [tile = wave][src][lane]
+#pragma unroll
+      for (int src = 0; src < 4; ++src) tot += *reinterpret_cast<const f32x4*>(mine + src * 64 * 4);
+      float4 g4;
+      float h = mgr_cell_fwd(tot[0], tot[1], tot[2], tot[3], c, g4);
+      const unsigned par = (((unsigned)step >> 1) & 1u) ^ 1u;
+      const unsigned hbits = (__float_as_uint(h) & ~1u) | par;  // epoch parity rides in the mantissa LSB
+      h = __uint_as_float(hbits);
+#ifdef MGR_ABLATE
+      if (step + 1 < T && !(ab & 8)) {
+#else
+      if (step + 1 < T) {
+#endif
+        // unit k = 4*tile + uq -> image [q = tile>>2][kk = uq][j][r = tile&3]
+        const int idx = (((tile >> 2) * 4 + uq) * 16 + j) * 4 + (tile & 3);
+        __builtin_amdgcn_raw_buffer_store_b32(hbits, rs, ((step & 1) * IMG + idx) * 4, 0, 16);  // sc1 write-through
+      }
+#ifdef MGR_ABLATE
+      if (bvalid && !(ab & 16)) {
+#else
+      if (bvalid) {
+#endif
+        size_t row = (size_t)b * T + t;
+        float yo = h;
+        if (jb.R) yo += jb.R[row * jb.ldr + unit];
+        jb.Y[row * jb.ldy + unit] = yo;
+        if (jb.G) *reinterpret_cast<float4*>(jb.G + (row * H + unit) * 4) = g4;
+        if (jb.Cs) jb.Cs[row * H + unit] = c;
+      }
+    }
+#ifdef MGR_STAMP
+    {
+      KSTAMP(r2);
+      ks_red += r1 - r0;
+      ks_cell += r2 - r1;
+    }
+#endif
+  };
+
+  for (int s0 = 0; s0 < T; s0 += 3) {
+    do_step(s0, zr0, zr2);
+    if (s0 + 1 < T) do_step(s0 + 1, zr1, zr0);
+    if (s0 + 2 < T) do_step(s0 + 2, zr2, zr1);
+  }
+#ifdef MGR_STAMP
+  if (lane == 0 && ug == 0 && bg < 2 && jb.cls_cluster0 == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(status + 16) + (bg * 8 + wave) * 8;
+    dbg[0] = ks_mfma; dbg[1] = ks_cell; dbg[2] = ks_wait; dbg[3] = ks_red; dbg[4] = ks_rounds; dbg[5] = ks_total; dbg[6] = ks_pre;
+  }
+#endif
+}
+
+#define CLKS_FOREACH(X) X(125) X(75) X(25)
+
 #define CL2_FOREACH(X) X(125) X(75) X(32) X(25) X(8)
 
 #define CL_FOREACH(X) \
@@ -554,6 +814,25 @@ __global__ __launch_bounds__(CL_WAVES * 64) void k_scan_cluster(ClusterLaunch L)
   if (jb.ks == KS && jb.tpw == TPW) return cluster_run<KS, TPW>(jb, bg, ug, cl, L.xcc, L.xcd_local, L.gather_delay, smem, L.status);
     CL_FOREACH(CL_CASE)
 #undef CL_CASE
+    return;
+  }
+}
+
+// K-split step: every job of the launch is a one-tile-per-wave, 4-wave cluster with an exchange (two workgroups per CU)
+__global__ __launch_bounds__(256, 2) void k_scan_cluster_ks(ClusterLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int bid = blockIdx.x;
+  for (int k = 0; k < L.njobs; ++k) {
+    const ClusterJob& jb = L.job[k];
+    const int w = bid - jb.cls_begin;
+    if (w < 0 || w >= jb.cls_nclusters * jb.G_) continue;
+    const int cl = w / jb.G_, ug = w % jb.G_;   // members of a cluster are contiguous workgroup ids
+    const int bg = cl - jb.cls_cluster0;
+    if (bg < 0 || bg >= jb.nbg) continue;
+#define CLKS_CASE(KS) \
+  if (jb.ks == KS) return cluster_run_ks<KS>(jb, bg, ug, smem, L.status, L.gather_delay);
+    CLKS_FOREACH(CLKS_CASE)
+#undef CLKS_CASE
     return;
   }
 }
@@ -605,6 +884,7 @@ int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool a
     size_t need = (L.job[i].pair == 2 ? 4 : 2) * img;
     lds = need > lds ? need : lds;
   }
+
   int per_cu = 1;
   if (any_exchange) {
     // co-residency of every spinning workgroup is what makes the in-launch hand-off deadlock-free.  4-wave workgroups
@@ -621,11 +901,26 @@ int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool a
   if (!attr_set) {
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_ks), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
+  }
+  bool ks_all = L.ksplit && any_exchange && !L.xcd_local && waves == 4;
+  for (int i = 0; i < L.njobs && ks_all; ++i) {
+    const ClusterJob& j = L.job[i];
+    bool inst = false;
+#define CLKS_CASE(KS) \
+  if (j.ks == KS) inst = true;
+    CLKS_FOREACH(CLKS_CASE)
+#undef CLKS_CASE
+    ks_all = inst && j.G_ > 1 && j.tpw == 1 && j.nw == 4 && j.pair != 2;
   }
   bool pair = L.njobs > 0 && L.job[0].pair == 2;
   for (int i = 0; i < L.njobs; ++i) MGR_REQUIRE((L.job[i].pair == 2) == pair, "paired and unpaired jobs cannot share a launch");
-  if (pair)
+  if (ks_all) {
+    // partial-sum exchange only (no h image); the size still keeps at most two of these workgroups on a CU
+    size_t lds_ks = 2 * 16 * 64 * 4 * sizeof(float);
+    hipLaunchKernelGGL(k_scan_cluster_ks, dim3(total_wgs), dim3(256), lds_ks, mgr_stream(c), L);
+  } else if (pair)
     hipLaunchKernelGGL(k_scan_cluster2, dim3(total_wgs), dim3(512), lds, mgr_stream(c), L);
   else
     hipLaunchKernelGGL(k_scan_cluster, dim3(total_wgs), dim3(waves * 64), lds, mgr_stream(c), L);

@@ -97,7 +97,8 @@ def test_early_fusion_builder(device, tmp_path, monkeypatch):
     K.set_learning_phase(0)
     m2 = early.load_model(device=device)
     p1, p2 = m.predict_on_batch(x), m2.predict_on_batch(x)
-    assert p1.shape == (2, maxlen, 22) and np.array_equal(p1, p2)
+    # (training and inference engines may run different scan kernels: same arithmetic, different summation order)
+    assert p1.shape == (2, maxlen, 22) and np.allclose(p1, p2, rtol=0, atol=1e-6)
     res = decode_batch(p1, [1, 228])
     assert len(res) == 2 and open("final_ctc_recout.mlf").read().count(".rec") == 1   # 228 is on the ignore list
     K.set_learning_phase(1)

@@ -281,6 +281,42 @@ def test_cluster_scan_matches_oracle(device, B, T, H, path):
         dev.call("mgr_tune", 1, 0)
 
 
+@pytest.mark.parametrize("H,B,T", [(100, 17, 40), (300, 33, 25), (500, 64, 30)])
+def test_cluster_step_variants_agree(device, H, B, T):
+    """One-tile-per-wave clusters: the K-split / register-polling step (default) and the LDS-image step (mgr_tune key 7)
+    compute the same recurrence; both against the oracle, over enough steps to cycle the epoch parity many times."""
+    from mgr_amd import _capi
+    dev = device
+    rng = np.random.default_rng(H)
+    F = 5
+    f32 = np.float32
+    x, W, U, b, _ = _lstm_case(rng, B, T, F, H, 0.0)
+    U = U * (0.1 if H >= 300 else 1.0)
+    got = {}
+    y_ref, _ = kr.lstm_forward(x, W, U, b, None, False)
+    Wp, Up, bp = dev.empty((F, 4 * H)), dev.empty((H, 4 * H)), dev.empty((4 * H,))
+    dev.call("mgr_lstm_pack", dev.array(W.astype(f32)), Wp, F, H, 0)
+    dev.call("mgr_lstm_pack", dev.array(U.astype(f32)), Up, H, H, 0)
+    dev.call("mgr_lstm_pack", dev.array(b.astype(f32)), bp, 1, H, 0)
+    Z = dev.empty((B, T, 4 * H))
+    dev.call("mgr_lstm_input_proj", dev.array(x.astype(f32)), F, 0, Wp, bp, Z, B, T, F, H)
+    ws = dev.bytes(dev.lib.mgr_lstm_scan_ws_bytes(B, T, H))
+    dev.call("mgr_tune", 0, 3)
+    dev.call("mgr_tune", 1, 1)
+    try:
+        for variant in (0, 1):
+            dev.call("mgr_tune", 7, variant)
+            Y = dev.zeros((B, T, H))
+            dev.call("mgr_lstm_scan_fwd", Z, Up, Y, H, 0, 0, 0, 0, B, T, H, 0, ws, ws.nbytes)
+            got[variant] = Y.download()
+            assert rel_err(got[variant], y_ref) < 3e-5, variant
+        assert rel_err(got[0], got[1]) < 1e-5
+    finally:
+        dev.call("mgr_tune", 7, 0)
+        dev.call("mgr_tune", 0, 0)
+        dev.call("mgr_tune", 1, 0)
+
+
 @pytest.mark.parametrize("path", [1, 2, 3])
 def test_scan_paths_agree(device, path):
     """fallback (1), single-CU (2) and 4-tile clusters (3) give the same recurrence (tolerance: fp32 summation order)."""

@@ -41,12 +41,12 @@ for hs in ((500, 300), (500,), (300,)):
     raw = ws.download().view(np.uint64)
     dbg = raw[8:8 + 16 * 8].reshape(16, 8)
     print("jobs H=%s: %.3f ms (%.2f us/step, stamped build) status=%d" % (hs, ms, ms * 1e3 / T, raw[0] & 0xFFFFFFFF))
-    print("   wave      mfma  compute  gather  barrier  passes/step   (s_memtime ticks per step)")
+    print("   wave      mfma  compute  gather  barrier  passes/step   (cycles per step; K-split kernel: mfma, cell+stores, poll wait, reduce+barrier, rounds)")
     for w in range(16):
         m = dbg[w]
         if m[1] == 0:
             continue
-        print("   bg%d.w%d %7.0f %7.0f %7.0f %7.0f   %.2f" % (w // 8, w % 8, m[0] / T, m[1] / T, m[2] / T, m[3] / T, m[4] / T))
+        print("   bg%d.w%d %7.0f %7.0f %7.0f %7.0f   %.2f   total %7.0f pre %6.0f" % (w // 8, w % 8, m[0] / T, m[1] / T, m[2] / T, m[3] / T, m[4] / T, m[5] / T, m[6] / T))
     for a in keep + [ws]:
         a.free()
 os.environ.pop("MGR_CXXFLAGS")
