@@ -166,7 +166,7 @@ def main():
         if not args.no_parity:
             parity = loss_parity(spec, dev)
         cpu = None
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:   # the CPU leg is reported at N=1 only (torchrun also pins OMP_NUM_THREADS=1)
             v, sec, _ = cpu_baseline(spec.to_dict(), 7, args.cpu_T, args.cpu_B)
             cpu = {"value": round(v, 2), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                    "sample": "one full train step of the same network, B=%d T=%d, numpy/OpenBLAS fp32 oracle, %.1f s"
