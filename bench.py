@@ -171,7 +171,8 @@ def main():
             cpu = {"value": round(v, 2), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                    "sample": "one full train step of the same network, B=%d T=%d, numpy/OpenBLAS fp32 oracle, %.1f s"
                              % (args.cpu_B, args.cpu_T, sec)}
-        out = {"metric": "train frames/sec, fusion BiLSTM+CTC", "value": round(value, 1), "unit": "frames/s",
+        out = {"metric": "train frames/sec, fusion BiLSTM+CTC" if args.config == "F" else "train frames/sec, config " + args.config,
+               "value": round(value, 1), "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "BASELINE configs[2]: multimodal_fusion fusion BiLSTM+CTC train step "

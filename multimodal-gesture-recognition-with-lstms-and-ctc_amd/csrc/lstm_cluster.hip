@@ -788,7 +788,7 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, int bg, int
 #endif
 }
 
-#define CLKS_FOREACH(X) X(125) X(75) X(25)
+#define CLKS_FOREACH(X) X(125) X(75) X(32) X(25)
 
 #define CL2_FOREACH(X) X(125) X(75) X(32) X(25) X(8)
 
