@@ -114,6 +114,10 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
  * key 7: 1 = one-tile-per-wave clusters keep the LDS-image step instead of the K-split / register-direct gather step. */
 enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 8 };
 int mgr_tune(mgr_ctx* ctx, int key, int value);
+/* Fails (and reports through mgr_last_error) if any persistent multi-CU scan launched on this context ever gave up on a
+ * bounded spin (a deadlocked or lost peer): such a launch returns promptly but its outputs are garbage.  Ordered on the
+ * current stream; cheap (one 4-byte read back) - call it where results are consumed, e.g. with the loss. */
+int mgr_scan_status(mgr_ctx* ctx, unsigned* out);
 /* Diagnostic: out[b] = XCC (XCD) id the workgroup b of a (nblocks, threads, lds_bytes) launch ran on. */
 int mgr_probe_xcc(mgr_ctx* ctx, int nblocks, int threads, int lds_bytes, int32_t* out);
 /* Hold the current stream for ~us microseconds on the device (bounded; 0 <= us <= 100000).  Scheduling aid: lets a

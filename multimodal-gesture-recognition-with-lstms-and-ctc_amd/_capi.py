@@ -49,6 +49,7 @@ SIGNATURES = {
     "mgr_tune": (i32, [vp, i32, i32]),
     "mgr_probe_xcc": (i32, [vp, i32, i32, i32, vp]),
     "mgr_stream_delay": (i32, [vp, i32]),
+    "mgr_scan_status": (i32, [vp, vp]),
     "mgr_skeletal_features": (i32, [vp, vp, sz, vp]),
     "mgr_lstm_scan_bwd_multi_ws_bytes": (sz, [i32, vp]),
     "mgr_lstm_scan_bwd_multi": (i32, [vp, i32, vp, vp, sz]),

@@ -29,6 +29,7 @@ struct mgr_ctx {
   float prof_ms[MGR_K_COUNT];
   int prof_launches[MGR_K_COUNT];
   int tune[MGR_TUNE_COUNT];
+  unsigned* sticky_status;  // device word: give-up code of any persistent scan launch since the last mgr_scan_status
 };
 
 int mgr_fail(int code, const char* fmt, ...);

@@ -43,6 +43,8 @@ int mgr_ctx_create(int device, mgr_ctx** out) {
   for (int i = 0; i < MGR_NUM_STREAMS; ++i) MGR_HIP(hipStreamCreateWithFlags(&c->streams[i], hipStreamNonBlocking));
   for (int i = 0; i < MGR_NUM_EVENTS; ++i) MGR_HIP(hipEventCreate(&c->events[i]));
   for (int i = 0; i < 64; ++i) MGR_HIP(hipEventCreateWithFlags(&c->xev[i], hipEventDisableTiming));
+  MGR_HIP(hipMalloc(&c->sticky_status, 256));
+  MGR_HIP(hipMemset(c->sticky_status, 0, 256));
   *out = c;
   return 0;
 }
@@ -54,6 +56,7 @@ int mgr_ctx_destroy(mgr_ctx* c) {
   for (int i = 0; i < MGR_NUM_STREAMS; ++i) hipStreamDestroy(c->streams[i]);
   for (int i = 0; i < MGR_NUM_EVENTS; ++i) hipEventDestroy(c->events[i]);
   for (int i = 0; i < 64; ++i) hipEventDestroy(c->xev[i]);
+  if (c->sticky_status) hipFree(c->sticky_status);
   for (int f = 0; f < MGR_K_COUNT; ++f) {
     for (int i = 0; i < c->prof_cap[f]; ++i) {
       hipEventDestroy(c->prof_pairs[f][i].a);
@@ -144,6 +147,15 @@ int mgr_stream_wait_event(mgr_ctx* c, int waiter, int ev) {
   MGR_REQUIRE(c && ev >= 0 && ev < MGR_NUM_EVENTS, "bad event index");
   MGR_REQUIRE(waiter >= 0 && waiter < MGR_NUM_STREAMS, "bad stream index");
   MGR_HIP(hipStreamWaitEvent(c->streams[waiter], c->events[ev], 0));
+  return 0;
+}
+
+int mgr_scan_status(mgr_ctx* c, unsigned* out) {
+  MGR_REQUIRE(c && out, "null argument");
+  // on the CURRENT stream: the caller decides what it is ordered after
+  MGR_HIP(hipMemcpyAsync(out, c->sticky_status, sizeof(unsigned), hipMemcpyDeviceToHost, mgr_stream(c)));
+  MGR_HIP(hipStreamSynchronize(mgr_stream(c)));
+  MGR_REQUIRE(*out == 0, "a persistent scan gave up on a bounded spin (code %u): its outputs are invalid", *out);
   return 0;
 }
 

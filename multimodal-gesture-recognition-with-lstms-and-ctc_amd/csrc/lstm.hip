@@ -272,6 +272,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
       w += mgr_align_up((size_t)P.nbg[i] * 2 * img * sizeof(float), 256);
     }
     L.status = status;
+    L.sticky = c->sticky_status;
     L.xcd_local = c->tune[3];
     L.gather_delay = c->tune[6];
     L.ksplit = c->tune[7] == 0;   // tune key 7: 1 = keep the LDS-image step for one-tile-per-wave clusters
@@ -330,6 +331,7 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
   ClusterBwdLaunch L;
   memset(&L, 0, sizeof(L));
   L.status = status;
+  L.sticky = c->sticky_status;
   L.xcc = reinterpret_cast<unsigned*>(base + 2048);
   L.xcd_local = c->tune[3];
   int total = 0;

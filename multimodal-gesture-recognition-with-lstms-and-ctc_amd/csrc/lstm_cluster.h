@@ -32,7 +32,8 @@ struct ClusterLaunch {
   int gather_delay;  // 64-cycle sleeps between a workgroup's own publish and its first gather pass (a failed pass costs a
                      // full fabric round trip, a short wait is cheaper)
   int ksplit;        // one-tile-per-wave clusters use the K-split step (cluster_run_ks): register-direct gather
-  unsigned* status;  // [0] != 0 -> a bounded spin gave up
+  unsigned* status;  // [0] != 0 -> a bounded spin gave up (zeroed ahead of every launch)
+  unsigned* sticky;  // context-wide word, never cleared by a launch: any give-up leaves its code here (mgr_scan_status)
   ClusterJob job[MGR_MAX_SCAN_JOBS];
 };
 
@@ -58,6 +59,7 @@ struct ClusterBwdLaunch {
   unsigned* xcc;
   int xcd_local;
   unsigned* status;
+  unsigned* sticky;
   ClusterBwdJob job[MGR_MAX_SCAN_JOBS];
 };
 bool mgr_cluster_bwd_supported(int H);
@@ -65,6 +67,14 @@ size_t mgr_cluster_bwd_img_floats(int H);
 int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs);
 
 #ifdef __HIPCC__
+// last thing a workgroup of a cluster kernel does: copy a give-up code of this launch into the context's sticky word
+__device__ __forceinline__ void mgr_cluster_exit(unsigned* status, unsigned* sticky) {
+  if (threadIdx.x == 0 && sticky) {
+    unsigned st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (st != 0) __hip_atomic_store(sticky, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ---- device helpers shared by the forward and backward cluster kernels -------------------------------------------
 // Publish this workgroup's XCC (XCD) id, then learn whether every member of its cluster sits on the same XCD.  Each
 // wave does this for itself (no LDS), the result is wave-uniform.  If true, the cluster may exchange through its

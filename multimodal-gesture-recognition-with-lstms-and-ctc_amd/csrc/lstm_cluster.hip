@@ -811,7 +811,7 @@ __global__ __launch_bounds__(CL_WAVES * 64) void k_scan_cluster(ClusterLaunch L)
     const int bg = cl - jb.cls_cluster0;
     if (bg < 0 || bg >= jb.nbg) continue;
 #define CL_CASE(KS, TPW) \
-  if (jb.ks == KS && jb.tpw == TPW) return cluster_run<KS, TPW>(jb, bg, ug, cl, L.xcc, L.xcd_local, L.gather_delay, smem, L.status);
+  if (jb.ks == KS && jb.tpw == TPW) { cluster_run<KS, TPW>(jb, bg, ug, cl, L.xcc, L.xcd_local, L.gather_delay, smem, L.status); return mgr_cluster_exit(L.status, L.sticky); }
     CL_FOREACH(CL_CASE)
 #undef CL_CASE
     return;
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(256, 2) void k_scan_cluster_ks(ClusterLaunch L) {
     const int bg = cl - jb.cls_cluster0;
     if (bg < 0 || bg >= jb.nbg) continue;
 #define CLKS_CASE(KS) \
-  if (jb.ks == KS) return cluster_run_ks<KS>(jb, bg, ug, smem, L.status, L.gather_delay);
+  if (jb.ks == KS) { cluster_run_ks<KS>(jb, bg, ug, smem, L.status, L.gather_delay); return mgr_cluster_exit(L.status, L.sticky); }
     CLKS_FOREACH(CLKS_CASE)
 #undef CLKS_CASE
     return;
@@ -848,7 +848,7 @@ __global__ __launch_bounds__(512) void k_scan_cluster2(ClusterLaunch L) {
   const int wg = bid - jb.wg_begin;
   if (wg >= jb.G_ * ((jb.nbg + 1) / 2)) return;
 #define CL2_CASE(KS) \
-  if (jb.ks == KS) return cluster_run2<KS>(jb, wg, smem, L.status);
+  if (jb.ks == KS) { cluster_run2<KS>(jb, wg, smem, L.status); return mgr_cluster_exit(L.status, L.sticky); }
   CL2_FOREACH(CL2_CASE)
 #undef CL2_CASE
 }

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(BW_WAVES * 64) void k_scan_cluster_bwd(ClusterBwdLa
     const int bg = cl - jb.cls_cluster0;
     if (bg < 0 || bg >= jb.nbg) continue;
 #define BW_CASE(HH) \
-  if (jb.H == HH) return cluster_bwd_run<HH>(jb, bg, ug, cl, L.xcc, L.xcd_local, smem, L.status);
+  if (jb.H == HH) { cluster_bwd_run<HH>(jb, bg, ug, cl, L.xcc, L.xcd_local, smem, L.status); return mgr_cluster_exit(L.status, L.sticky); }
     BW_FOREACH(BW_CASE)
 #undef BW_CASE
     return;

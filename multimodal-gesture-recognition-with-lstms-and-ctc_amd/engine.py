@@ -448,17 +448,25 @@ class Engine:
         _capi.check(self.lib.mgr_lstm_scan_fwd_multi(self.dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes))
 
     # ------------------------------------------------------------------------------------------ public
+    def _check_scans(self):
+        st = C.c_uint(0)
+        self.dev.call("mgr_scan_status", C.byref(st))   # raises if a persistent scan gave up on a bounded spin
+
     def predict(self, inputs):
         """Softmax output (B,T,C) with learning phase 0 (sequence_decoding.py:81)."""
         self._upload_inputs(inputs, None, False)
         self._forward(False, None)
-        return self.P.download()
+        P = self.P.download()
+        self._check_scans()
+        return P
 
     def forward_train_phase(self, inputs, rand=None):
         """Softmax output with learning phase 1 (dropout / noise active) - no gradient."""
         self._upload_inputs(inputs, rand, True)
         self._forward(True, rand)
-        return self.P.download()
+        P = self.P.download()
+        self._check_scans()
+        return P
 
     def _upload_labels(self, labels, input_length, label_length):
         lab = np.asarray(labels)
@@ -498,7 +506,11 @@ class Engine:
         dev = self.dev
         dev.stream(self.LOSS_STREAM)
         v = float(self.loss_mean.download()[0])
-        dev.stream(0)
+        st = C.c_uint(0)
+        try:
+            dev.call("mgr_scan_status", C.byref(st))   # raises if a persistent scan ever gave up: results would be garbage
+        finally:
+            dev.stream(0)
         return v
 
     @property

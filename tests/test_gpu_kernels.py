@@ -311,6 +311,10 @@ def test_cluster_step_variants_agree(device, H, B, T):
             got[variant] = Y.download()
             assert rel_err(got[variant], y_ref) < 3e-5, variant
         assert rel_err(got[0], got[1]) < 1e-5
+        import ctypes
+        st = ctypes.c_uint(7)
+        dev.call("mgr_scan_status", ctypes.byref(st))     # no persistent scan of this context ever gave up
+        assert st.value == 0
     finally:
         dev.call("mgr_tune", 7, 0)
         dev.call("mgr_tune", 0, 0)
