@@ -157,8 +157,16 @@ def main():
         if dom in flops_family and fam[dom]["ms"] > 0:
             fl = flops_family[dom] * B * T * args.steps
             ach = fl / (fam[dom]["ms"] * 1e-3) / 1e12
+            # HBM bytes per launch of that family from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+            # their own runs, tools/profile_round.sh + summarize_profile.py); null when no such pass is on file
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if args.config == "F" and os.path.exists(tpath):
+                with open(tpath) as fh:
+                    traffic = json.load(fh).get("bytes_per_launch", {}).get(dom)
+                traffic = round(traffic) if traffic else None
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 5), "traffic": None,
+                    "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 5), "traffic": traffic,
                     "avg_launch_ms": round(fam[dom]["ms"] / max(1, fam[dom]["launches"]), 4)}
         whole = spec.flops_per_frame() * value / 1e12
         # ---- parity: same weights / batch / injected randomness on a short-T slice vs the fp64 oracle ----

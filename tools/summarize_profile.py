@@ -56,6 +56,21 @@ for k in sorted(f, key=lambda k: -f[k]["FETCH_SIZE"]):
         continue
     out.append("| %s | %d | %.1f | %.1f |" % (k, fc[k], 2 * f[k]["FETCH_SIZE"] / fc[k] / 1024,
                                            w[k]["WRITE_SIZE"] / max(1, wc[k]) / 1024))
+# per-family HBM bytes per launch for bench.py's roofline.traffic (read + write, FETCH_SIZE x2-corrected, KB -> bytes)
+FAMILY = {"k_scan_cluster_ks": "scan_fwd", "k_scan_cluster": "scan_fwd", "k_scan_cluster2": "scan_fwd", "k_scan_simple": "scan_fwd",
+          "k_scan_fwd_mfma": "scan_fwd", "k_scan_cluster_bwd": "scan_bwd", "k_scan_bwd_mfma": "scan_bwd", "k_gemm_nn": "gemm_nn",
+          "k_gemm_tn": "gemm_tn", "k_gemm_nt": "gemm_nt"}
+fam_bytes, fam_n = collections.defaultdict(float), collections.Counter()
+for k in f:
+    fam = FAMILY.get(k)
+    if fam and fc[k]:
+        fam_bytes[fam] += (2 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"]) * 1024.0
+        fam_n[fam] += fc[k]
+if fam_n:
+    import json
+    json.dump({"tag": tag, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1",
+               "bytes_per_launch": {k: fam_bytes[k] / fam_n[k] for k in fam_n}},
+              open("profiles/pmc_traffic.json", "w"), indent=1)
 s, sc = pmc("SQ_VALU_MFMA_BUSY_CYCLES")
 out.append("\n## SQ counters per kernel (sums over launches)\n")
 out.append("| kernel | launches | MFMA busy / (1024 SIMD x GUI_ACTIVE/8) | WAIT_INST_ANY/WAVE_CYCLES | WAIT_ANY/WAVE_CYCLES | ACTIVE/WAVE_CYCLES | LDS bank conflict cycles |\n|---|---|---|---|---|---|---|")
