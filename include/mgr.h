@@ -50,6 +50,11 @@ int mgr_free(mgr_ctx* ctx, void* dptr);
 int mgr_memset(mgr_ctx* ctx, void* d, int byte, size_t n);
 /* Keras feeds numpy arrays through feed_dict (multimodal_fusion/multimodal.py:264); these are that copy. */
 int mgr_h2d(mgr_ctx* ctx, void* d, const void* h, size_t n);
+/* Pinned host memory + a copy that does NOT synchronise: the host returns at once and the copy is ordered on the current
+ * stream.  (mgr_h2d on pageable memory blocks the host, and on this runtime for as long as OTHER streams have work queued.) */
+int mgr_host_alloc(mgr_ctx* ctx, size_t bytes, void** out);
+int mgr_host_free(mgr_ctx* ctx, void* p);
+int mgr_h2d_async(mgr_ctx* ctx, void* d, const void* h_pinned, size_t n);
 int mgr_d2h(mgr_ctx* ctx, void* h, const void* d, size_t n);
 int mgr_d2d(mgr_ctx* ctx, void* dst, const void* src, size_t n);
 int mgr_sync(mgr_ctx* ctx);

@@ -49,6 +49,9 @@ SIGNATURES = {
     "mgr_tune": (i32, [vp, i32, i32]),
     "mgr_probe_xcc": (i32, [vp, i32, i32, i32, vp]),
     "mgr_stream_delay": (i32, [vp, i32]),
+    "mgr_host_alloc": (i32, [vp, sz, C.POINTER(vp)]),
+    "mgr_host_free": (i32, [vp, vp]),
+    "mgr_h2d_async": (i32, [vp, vp, vp, sz]),
     "mgr_scan_status": (i32, [vp, vp]),
     "mgr_skeletal_features": (i32, [vp, vp, sz, vp]),
     "mgr_lstm_scan_bwd_multi_ws_bytes": (sz, [i32, vp]),
@@ -128,6 +131,10 @@ def load_library(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
+    # The HIP runtime multiplexes streams onto 4 hardware queues by default; a context here has 8 streams, and two logically
+    # independent streams that share a hardware queue serialise (measured: the host->device batch copy queued behind a whole
+    # training step and took the encoder stream with it, 51 instead of 42 ms/step).  Must be set before the runtime starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if not os.path.exists(LIB_PATH) and build_if_missing:
         from . import _build
         _build.build(verbose=False)
@@ -208,6 +215,7 @@ class Device:
         self.hbm_bytes = hbm.value
         self.name = name.value.decode()
         self._arrays = []
+        self._pinned = []
 
     # -- memory ------------------------------------------------------------------------------------
     def empty(self, shape, dtype=np.float32):
@@ -219,6 +227,19 @@ class Device:
         a = DeviceArray(self, p.value, shape, dtype)
         self._arrays.append(a)
         return a
+
+    def pinned(self, shape, dtype=np.float32):
+        """Page-locked host array (numpy view) for mgr_h2d_async; freed with the Device."""
+        n = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        p = vp()
+        check(self.lib.mgr_host_alloc(self.ctx, max(n, 16), C.byref(p)))
+        self._pinned.append(p.value)
+        buf = (C.c_char * n).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def h2d_async(self, darr, host_pinned):
+        """Enqueue a copy from a pinned() array on the current stream; does not block the host."""
+        check(self.lib.mgr_h2d_async(self.ctx, darr.ptr, host_pinned.ctypes.data, host_pinned.nbytes))
 
     def zeros(self, shape, dtype=np.float32):
         return self.empty(shape, dtype).zero()
@@ -274,6 +295,9 @@ class Device:
             for a in self._arrays:
                 a.free()
             self._arrays = []
+            for p in self._pinned:
+                self.lib.mgr_host_free(self.ctx, p)
+            self._pinned = []
             self.lib.mgr_ctx_destroy(self.ctx)
             self.ctx = None
 

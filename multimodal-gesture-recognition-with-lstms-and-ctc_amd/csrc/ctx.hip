@@ -106,6 +106,26 @@ int mgr_h2d(mgr_ctx* c, void* d, const void* h, size_t n) {
   return 0;
 }
 
+int mgr_host_alloc(mgr_ctx* c, size_t bytes, void** out) {
+  MGR_REQUIRE(c && out && bytes > 0, "bad argument");
+  MGR_HIP(hipSetDevice(c->device));
+  MGR_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return 0;
+}
+
+int mgr_host_free(mgr_ctx* c, void* p) {
+  MGR_REQUIRE(c, "null ctx");
+  if (p) MGR_HIP(hipHostFree(p));
+  return 0;
+}
+
+int mgr_h2d_async(mgr_ctx* c, void* d, const void* h_pinned, size_t n) {
+  MGR_REQUIRE(c && d && h_pinned, "null argument");
+  // h_pinned must come from mgr_host_alloc and stay untouched until the stream has passed this copy
+  MGR_HIP(hipMemcpyAsync(d, h_pinned, n, hipMemcpyHostToDevice, mgr_stream(c)));
+  return 0;
+}
+
 int mgr_d2h(mgr_ctx* c, void* h, const void* d, size_t n) {
   MGR_REQUIRE(c && d && h, "null argument");
   MGR_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, mgr_stream(c)));

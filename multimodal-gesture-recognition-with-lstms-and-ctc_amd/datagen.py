@@ -42,6 +42,7 @@ class SyntheticStore:
         self.seed = seed
         self.lmin, self.lmax = lmin, lmax
         self.empty_every = empty_every    # every k-th file has an empty label row (exercises the blank substitution)
+        self._cache, self._cache_bytes, self.cache_limit_bytes = {}, 0, 2 << 30
 
     def file_ids(self):
         return list(self.ids)
@@ -54,9 +55,16 @@ class SyntheticStore:
         return int(r.integers(int(np.ceil(0.6 * self.maxlen)), self.maxlen + 1))
 
     def features(self, file_id, modality):
-        F, scale = self.feats[modality]
-        r = self._rng(file_id, 1 + sorted(self.feats).index(modality))
-        return (r.standard_normal((self.length(file_id), F)) * scale).astype(np.float32)
+        key = (int(file_id), modality)
+        hit = self._cache.get(key)
+        if hit is None:
+            F, scale = self.feats[modality]
+            r = self._rng(file_id, 1 + sorted(self.feats).index(modality))
+            hit = (r.standard_normal((self.length(file_id), F)) * scale).astype(np.float32)
+            if self._cache_bytes + hit.nbytes <= self.cache_limit_bytes:   # a real store keeps its files in memory too
+                self._cache[key] = hit
+                self._cache_bytes += hit.nbytes
+        return hit
 
     def labels(self, file_id):
         if self.empty_every and int(file_id) % self.empty_every == 0:
@@ -164,7 +172,10 @@ class BaseDataGenerator(Callback):
         file_list, index = (self.train_list, self.train_index) if train else (self.val_list, self.val_index)
         batch = file_list[index:index + self.minibatch_size]
         size = len(batch)
-        X = {key: np.ones([size, self.maxlen, getattr(self, attr)]) for key, _, attr in self.streams}
+        # (np.ones of the reference, :178-186; rows are fully overwritten below unless the file has no label row, so the
+        # buffers come from a small ring instead of 57 MB of fresh pages per call - a batch stays valid until
+        # BATCH_RING further batches have been drawn)
+        X = {key: self._batch_buffer(key, (size, self.maxlen, getattr(self, attr))) for key, _, attr in self.streams}
         labels = np.ones([size, self.absolute_max_sequence_len])
         input_length = np.zeros([size, 1])
         label_length = np.zeros([size, 1])
@@ -173,6 +184,8 @@ class BaseDataGenerator(Callback):
             lab_seq = self.expand_labels(np.asarray(lab_seq, np.float32))
             if lab_seq.shape[0] == 0:
                 # no label row: the inputs stay all-ones and the target is the single blank label
+                for key, _, _ in self.streams:
+                    X[key][i, :, :] = 1.0
                 row = -np.ones(self.absolute_max_sequence_len)
                 row[0] = self.blank_label[0]
                 labels[i, :] = row
@@ -181,7 +194,11 @@ class BaseDataGenerator(Callback):
                 for key, modality, attr in self.streams:
                     feats = np.asarray(self.store.features(fid, modality))
                     if feats.ndim == 2 and feats.shape[1] == getattr(self, attr):
-                        X[key][i, :, :] = pad_post(feats, self.maxlen)
+                        n = min(self.maxlen, feats.shape[0])     # pad_sequences(padding='post', truncating='post')
+                        X[key][i, :n, :] = feats[:n]
+                        X[key][i, n:, :] = 0.0
+                    else:
+                        X[key][i, :, :] = 1.0
                 label_length[i] = min(lab_seq.shape[0], self.absolute_max_sequence_len)
                 row = -np.ones(self.absolute_max_sequence_len)
                 n = int(label_length[i, 0])
@@ -194,6 +211,22 @@ class BaseDataGenerator(Callback):
         inputs['label_length'] = label_length
         outputs = {'ctc': np.zeros([size])}
         return (inputs, outputs)
+
+    BATCH_RING = 4
+
+    def _batch_buffer(self, key, shape):
+        ring = self.__dict__.setdefault("_batch_ring", {})
+        slot = ring.setdefault(key, {"i": 0, "bufs": []})
+        bufs = slot["bufs"]
+        if len(bufs) < self.BATCH_RING or bufs[slot["i"] % self.BATCH_RING].shape != tuple(shape):
+            buf = np.empty(shape, np.float64)
+            if len(bufs) < self.BATCH_RING:
+                bufs.append(buf)
+            else:
+                bufs[slot["i"] % self.BATCH_RING] = buf
+        buf = bufs[slot["i"] % self.BATCH_RING] if len(bufs) == self.BATCH_RING else bufs[-1]
+        slot["i"] += 1
+        return buf
 
     def next_train(self):
         while 1:

@@ -40,6 +40,9 @@ class _Arena:
     def bytes(self, nbytes):
         return self._keep(self.dev.bytes(nbytes))
 
+    def pinned(self, shape, dtype=np.float32):
+        return self.dev.pinned(shape, dtype)   # (tiny; released with the Device)
+
     def free_all(self):
         dead = set(id(a) for a in self.arrays)
         for a in self.arrays:
@@ -134,12 +137,22 @@ class Engine:
         self.Y2 = {}
         self.dY1 = {}
         self.Zbuf = {}
-        self.Xin = {}
         self._xcur = {}
+        # host batches arrive through a dedicated copy stream into two alternating input / label buffer sets, so an upload
+        # never has to wait for (or stall the host behind) whatever the compute streams still have queued
+        self._xin_ring = [{}, {}]
+        self._xin_slot = 0
+        self._xin_pin = None
+        self._xin_user = [-1, -1]      # id of the last step that reads input set 0 / 1 (see _upload_inputs)
+        self._lab_user = [-1, -1]
+        self._step_id = 0              # training steps enqueued so far
+        self._synced_step = -1         # the host has seen the loss of this step (everything before its CTC is complete)
         for s in sp.streams:
-            self.Xin[s["name"]] = dev.empty((B, T, s["F"]))
+            for ring in self._xin_ring:
+                ring[s["name"]] = dev.empty((B, T, s["F"]))
             if s["noise"] > 0:
                 self.X[s["name"]] = dev.empty((B, T, s["F"]))
+            self.Xin = self._xin_ring[0]
             Hs = [lay["H"] for lay in s["layers"]]
             zf = dev.empty((B, T, 4 * max(Hs)))
             zb = dev.empty((B, T, 4 * max(Hs)))
@@ -178,9 +191,13 @@ class Engine:
             self.dLogits = dev.empty((B, T, Cn))
             self.loss_b = dev.empty((B,))
             self.loss_mean = dev.empty((4,))
-            self.labels_d = dev.empty((B, self.Lmax), np.int32)
-            self.ilen_d = dev.empty((B,), np.int32)
-            self.llen_d = dev.empty((B,), np.int32)
+            self._lab_ring = [(dev.empty((B, self.Lmax), np.int32), dev.empty((B,), np.int32), dev.empty((B,), np.int32))
+                              for _ in range(2)]
+            self._lab_slot = 0
+            self.labels_d, self.ilen_d, self.llen_d = self._lab_ring[0]
+            # page-locked staging for the (tiny) label arrays: their copies are enqueued without blocking the host
+            self._lab_pin = [(dev.pinned((B, self.Lmax), np.int32), dev.pinned((B,), np.int32), dev.pinned((B,), np.int32))
+                             for _ in range(2)]
             self.ws_ctc = dev.bytes(self.lib.mgr_ctc_ws_bytes(B, T, Cn, self.Lmax))
             self.ws_dense = dev.bytes(self.lib.mgr_dense_bwd_ws_bytes(B, T, D, Cn))
         self.dev.sync()
@@ -263,17 +280,40 @@ class Engine:
     def _seed(self, slot):
         return (self.seed * 1000003 + self.rng_step * 131 + slot) & 0xFFFFFFFFFFFFFFFF
 
+    COPY_STREAM = 7
+    EV_IN = (41, 42)     # last reader of input buffer set 0 / 1
+    EV_LAB = (43, 44)    # last reader of label buffer set 0 / 1
+
     def _upload_inputs(self, inputs, rand, train, stream=0):
+        """Host batch -> the input buffer set that is NOT the one read last, on the copy stream; `stream` (where the
+        encoder pass that reads it will be enqueued) waits for the copies."""
         dev = self.dev
-        dev.stream(stream)
+        slot = self._xin_slot ^ 1
+        dev.stream(self.COPY_STREAM)
+        # the set was last read by step _xin_user[slot]; once the host has read a loss at or after that step the readers
+        # are known to be complete (stream order) and no device-side wait is needed.  (Measured: hipStreamWaitEvent on an
+        # event recorded long ago resolves against that stream's CURRENT tail on this runtime, which stalls the copy - and
+        # the host behind it - for a whole step.)
+        if self._xin_user[slot] > self._synced_step:
+            dev.wait_event(self.COPY_STREAM, self.EV_IN[slot])
+        if self._xin_pin is None:   # page-locked staging, allocated at the first host batch (resident-input runs never need it)
+            self._xin_pin = [{s["name"]: dev.pinned((self.B, self.T, s["F"]), np.float32) for s in self.spec.streams}
+                             for _ in range(2)]
         for s in self.spec.streams:
-            x = np.asarray(inputs[s["name"]], dtype=np.float32)
+            x = np.asarray(inputs[s["name"]])
             if x.shape != (self.B, self.T, s["F"]):
                 raise ValueError("input %s: expected %s got %s" % (s["name"], (self.B, self.T, s["F"]), x.shape))
+            stage = self._xin_pin[slot][s["name"]]
+            np.copyto(stage, x, casting="unsafe")          # float64 batch -> float32 staging in one pass
             nz = rand.get(s["name"] + "/noise") if rand else None
             if train and nz is not None:
-                x = x + np.asarray(nz, dtype=np.float32)
-            self.Xin[s["name"]].upload(x)
+                stage += np.asarray(nz, dtype=np.float32)
+            dev.h2d_async(self._xin_ring[slot][s["name"]], stage)   # the host does not wait for the copy
+        dev.wait(stream, self.COPY_STREAM)
+        self._xin_slot = slot
+        self._xin_user[slot] = 1 << 60     # set by the step that consumes it (enqueue_train_step)
+        self.Xin = self._xin_ring[slot]
+        dev.stream(stream)
 
     def _prep_mask(self, L, train, rand, slot):
         """Returns the device pointer (or 0) of the [4,B,fin] input-dropout mask for this pass."""
@@ -376,6 +416,8 @@ class Engine:
                     keep = save and L.trainable
                     jobs.append(dict(Z=Z, Up=L.Up, Y=Y, ldy=ldy, R=R, ldr=ldr, gates=L.gates if keep else 0,
                                      cs=L.cs if keep else 0, B=B, T=T, H=H, reverse=L.reverse))
+            if k == 0:
+                dev.record(self.EV_IN[self._xin_slot])   # the inputs have been read (noise kernel / depth-1 projections)
             self.rng_step = saved_step
             yield ("projected", k)
             saved_step, self.rng_step = self.rng_step, rng_step
@@ -475,9 +517,24 @@ class Engine:
             if lab.shape[1] > self.Lmax:
                 raise ValueError("label rows longer (%d) than Lmax=%d" % (lab.shape[1], self.Lmax))
             lab = np.concatenate([lab, -np.ones((self.B, self.Lmax - lab.shape[1]), np.int32)], axis=1)
-        self.labels_d.upload(lab)
-        self.ilen_d.upload(np.asarray(input_length).reshape(self.B).astype(np.int32))
-        self.llen_d.upload(np.asarray(label_length).reshape(self.B).astype(np.int32))
+        dev = self.dev
+        slot = self._lab_slot ^ 1
+        dev.stream(self.COPY_STREAM)
+        if self._lab_user[slot] > self._synced_step:       # see _upload_inputs
+            dev.wait_event(self.COPY_STREAM, self.EV_LAB[slot])
+        labels_d, ilen_d, llen_d = self._lab_ring[slot]
+        plab, pil, pll = self._lab_pin[slot]    # (the staging set is reused together with the device set: same ordering)
+        plab[...] = lab
+        pil[...] = np.asarray(input_length).reshape(self.B)
+        pll[...] = np.asarray(label_length).reshape(self.B)
+        dev.h2d_async(labels_d, plab)
+        dev.h2d_async(ilen_d, pil)
+        dev.h2d_async(llen_d, pll)
+        dev.wait(0, self.COPY_STREAM)          # the CTC kernel runs on stream 0
+        self._lab_slot = slot
+        self._lab_user[slot] = 1 << 60
+        self.labels_d, self.ilen_d, self.llen_d = labels_d, ilen_d, llen_d
+        dev.stream(0)
 
     def loss_on_batch(self, inputs, labels, input_length, label_length, rand=None, train_phase=True):
         """Per-sample CTC loss (validation inside fit_generator: learning phase stays 1, multimodal.py:66)."""
@@ -506,6 +563,7 @@ class Engine:
         dev = self.dev
         dev.stream(self.LOSS_STREAM)
         v = float(self.loss_mean.download()[0])
+        self._synced_step = self._step_id - 1
         st = C.c_uint(0)
         try:
             dev.call("mgr_scan_status", C.byref(st))   # raises if a persistent scan ever gave up: results would be garbage
@@ -568,6 +626,7 @@ class Engine:
             if next_inputs is not None:
                 dev.stream(ES)
                 self._upload_inputs(next_inputs, None, True, stream=ES)
+                self._xin_user[self._xin_slot] = self._step_id + 1
             phases = self._encoder_phases(True, None, nxt, ES, self.rng_step + 1)
             assert next(phases) == ("projected", 0)
             dev.wait(0, ES)           # this step's fusion projections start when the next step's depth-1 ones are done
@@ -582,7 +641,14 @@ class Engine:
                  int(sp.ctc["skip"]), Cn - 1, float(sp.ctc["eps"]), 1.0 / B, self.loss_b, self.dLogits,
                  self.ws_ctc, self.ws_ctc.nbytes)
         dev.call("mgr_mean", self.loss_b, B, self.loss_mean)
+        dev.record(self.EV_LAB[self._lab_slot])
         dev.wait(self.LOSS_STREAM, 0)
+        this_step = self._step_id
+        self._step_id += 1
+        self._lab_user[self._lab_slot] = this_step
+        if have is None:   # this step's own inputs (a prefetched set was tagged when it was uploaded)
+            # trainable first layers read them again in their dW GEMMs, which only the NEXT step's loss read-back covers
+            self._xin_user[self._xin_slot] = this_step + (1 if any(s_["trainable"] for s_ in sp.streams) else 0)
         feat, ldf = self._feat
         hm, p_head, hseed = self._head_args
         any_tr_stream = any(s["trainable"] for s in sp.streams)
@@ -610,6 +676,8 @@ class Engine:
                     self._stream_backward(s, col)
                 col += wout
         dev.stream(0)
+        if any_tr_stream:
+            dev.record(self.EV_IN[self._xin_slot])   # trainable first layers read the inputs again in their dW GEMMs
 
         def finish():
             dev.stream(0)
@@ -644,6 +712,7 @@ class Engine:
             if next_inputs is not None:
                 dev.stream(ES)
                 self._upload_inputs(next_inputs, None, True, stream=ES)
+                self._xin_user[self._xin_slot] = self._step_id   # (already advanced: the step that will consume it)
             if deferred is None:
                 finish()
                 self._enqueue_encoders(True, None, nxt, ES, self.rng_step, hold_scans_for=0)
