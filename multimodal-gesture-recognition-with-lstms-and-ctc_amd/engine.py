@@ -291,9 +291,7 @@ class Engine:
         slot = self._xin_slot ^ 1
         dev.stream(self.COPY_STREAM)
         # the set was last read by step _xin_user[slot]; once the host has read a loss at or after that step the readers
-        # are known to be complete (stream order) and no device-side wait is needed.  (Measured: hipStreamWaitEvent on an
-        # event recorded long ago resolves against that stream's CURRENT tail on this runtime, which stalls the copy - and
-        # the host behind it - for a whole step.)
+        # are known to be complete (stream order) and no device-side wait is needed; otherwise wait for the readers' event
         if self._xin_user[slot] > self._synced_step:
             dev.wait_event(self.COPY_STREAM, self.EV_IN[slot])
         if self._xin_pin is None:   # page-locked staging, allocated at the first host batch (resident-input runs never need it)
