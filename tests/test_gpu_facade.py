@@ -102,3 +102,36 @@ def test_early_fusion_builder(device, tmp_path, monkeypatch):
     res = decode_batch(p1, [1, 228])
     assert len(res) == 2 and open("final_ctc_recout.mlf").read().count(".rec") == 1   # 228 is on the ignore list
     K.set_learning_phase(1)
+
+
+def test_fit_generator_prefetch_equals_plain_loop(device):
+    """fit_generator hands the engine the NEXT batch so that its frozen-encoder pass overlaps the current step; losses and
+    weights must be identical to feeding the same batches one at a time."""
+    import mgr_amd  # noqa: F401
+    from mgr_amd import keras_like as K
+    from mgr_amd.configs import fusion_spec
+    from mgr_amd.keras_like import Adam, Model
+    from mgr_amd.multimodal_fusion.data_generator import DataGenerator
+    K.set_learning_phase(1)
+    mb, maxlen, steps = 4, 40, 6
+
+    def make():
+        gen = DataGenerator(minibatch_size=mb, numfeats_skeletal=20, numfeats_speech=39, maxlen=maxlen, dataset='train',
+                            val_split=0.0, nb_classes=22, synthetic_files=mb * steps)
+        gen.store.lmax = 5
+        m = Model(fusion_spec(h_audio=32, h_skeletal=16, h_fusion=8), device=device, seed=11)
+        m.compile(loss={'ctc': lambda a, b: b}, optimizer=Adam(lr=1e-3, clipvalue=0.5, decay=1e-5))
+        return gen, m
+
+    gen_a, a = make()
+    hist = a.fit_generator(generator=gen_a.next_train(), steps_per_epoch=steps, epochs=1, verbose=0)
+    gen_b, b = make()
+    g = gen_b.next_train()
+    losses = []
+    for _ in range(steps):
+        x, y = next(g)
+        losses.append(b.train_on_batch(x, y))
+    assert abs(hist.history["loss"][0] - float(np.mean(losses))) < 1e-6
+    wa, wb = a.get_weights_dict(), b.get_weights_dict()
+    for k in wa:
+        assert np.array_equal(wa[k], wb[k]), k
