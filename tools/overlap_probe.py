@@ -23,7 +23,7 @@ def main():
     B, T = 64, int(os.environ.get("PROBE_T", 1900))
     rng = np.random.default_rng(0)
     jobs, keep = [], []
-    for H in (500, 300):
+    for H in [int(h) for h in os.environ.get("PROBE_HS", "500,300").split(",")]:
         for rev in (0, 1):
             Z = dev.array((rng.standard_normal((B, T, 4 * H)) * 0.5).astype(np.float32))
             Up = dev.array((rng.standard_normal((H, 4 * H)) * 0.05).astype(np.float32))
@@ -69,6 +69,22 @@ def main():
         dev.sync()
         return (dev.elapsed_ms(0, 1) if fn_a else None, dev.elapsed_ms(2, 3) if fn_b else None)
 
+    def timed_gemm_first(delay_us):
+        # GEMMs are already resident when the scan arrives (the placement case the schedule avoids with mgr_stream_delay)
+        dev.sync()
+        dev.stream(2)
+        dev.record(2)
+        gemms()
+        dev.record(3)
+        dev.stream(1)
+        dev.call("mgr_stream_delay", delay_us)
+        dev.record(0)
+        scan()
+        dev.record(1)
+        dev.stream(0)
+        dev.sync()
+        return dev.elapsed_ms(0, 1), dev.elapsed_ms(2, 3)
+
     timed(scan, gemms)
     a, _ = timed(scan)
     _, g = timed(None, gemms)
@@ -78,6 +94,9 @@ def main():
     print("gemms alone (x%d)  : %7.2f ms  %6.1f TF" % (ngemm, g, fl / g / 1e9))
     print("concurrent        : scan %7.2f ms (x%.2f)   gemms %7.2f ms (x%.2f)" % (a2, a2 / a, g2, g2 / g))
     print("serial sum %.2f ms, concurrent wall ~%.2f ms" % (a + g, max(a2, g2)))
+    for d in (500, 2000):
+        a3, g3 = timed_gemm_first(d)
+        print("GEMMs first, scan %4d us later: scan %7.2f ms (x%.2f)   gemms %7.2f ms (x%.2f)" % (d, a3, a3 / a, g3, g3 / g))
 
 
 if __name__ == "__main__":
