@@ -1,7 +1,7 @@
 """-m gpu: the BASELINE.json configs that are parity cases rather than bench lines.
  A  audio plumbing  : 2-layer BiLSTM(128)+CTC, B=8,  T=200,  39-d, full size, loss + gradients + one Adam step vs oracle
  S  skeletal        : BiLSTM(128)+CTC,         B=32, T=1000, 22-d, full size, loss vs oracle (1e-4 relative)
- F  fusion (ref sizes 500/300/100) at B=4, T=96 (the fp64 oracle needs minutes at T=1900): loss + trainable grads
+ F  fusion (ref sizes 500/300/100) at B=4, T=96 and at the full T=1900 with B=2: loss + trainable grads
  E  early fusion: 2x BiLSTM(500) on the 59-d concatenated input, all trainable, B=4, T=64
  D  decode          : beam=10 and thresholded best-path on T=1900 sequences, label sequences bit-exact vs the oracle
 """
@@ -66,6 +66,12 @@ def test_config_S_short_T_strong_weights(device):
 
 def test_config_F_reference_sizes_short_T(device):
     _run_case(device, "F", B=4, T=96)
+
+
+def test_config_F_reference_sizes_full_T(device):
+    """The metric's own sequence length: T = 1900 through 500/300/100-unit BiLSTMs and the CTC, B = 2, loss and softmax
+    and trainable gradients against the fp64 oracle (recipe weights: with doubled weights a 1900-step recurrence is chaotic, see config S)."""
+    _run_case(device, "F", B=2, T=1900, lmin=8, lmax=20, check_grads=True, wscale=1.0)
 
 
 def test_config_F_ragged_batch_not_multiple_of_16(device):
