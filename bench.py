@@ -171,8 +171,8 @@ def main():
         whole = spec.flops_per_frame() * value / 1e12
         # ---- parity: same weights / batch / injected randomness on a short-T slice vs the fp64 oracle ----
         parity = None
-        if not args.no_parity:
-            parity = loss_parity(spec, dev)
+        if not args.no_parity and world == 1:
+            parity = loss_parity(spec, dev, T)
         cpu = None
         if not args.no_cpu and world == 1:   # the CPU leg is reported at N=1 only (torchrun also pins OMP_NUM_THREADS=1)
             v, sec, _ = cpu_baseline(spec.to_dict(), 7, args.cpu_T, args.cpu_B)
@@ -200,12 +200,13 @@ def main():
     return out
 
 
-def loss_parity(spec, dev):
-    """CTC-loss delta vs the fp64 oracle on identical inputs (short-T slice so the CPU side takes seconds)."""
+def loss_parity(spec, dev, T_full):
+    """CTC-loss delta vs the fp64 oracle on identical inputs: same network, the config's full sequence length, two
+    sequences (the fp64 CPU side then takes a few seconds)."""
     from mgr_amd.engine import Engine
     from mgr_amd.synthetic import synthetic_arrays, synthetic_weights
     from oracle import network_ref as nr
-    B, T, Lmax = 4, 64, 35
+    B, T, Lmax = 2, T_full, 35
     eng = Engine(spec, B, T, Lmax, device=dev, seed=5)
     w = synthetic_weights(spec, 99)
     eng.set_weights(w)
@@ -217,7 +218,7 @@ def loss_parity(spec, dev):
     ref, _, _, _ = nr.loss_and_grads(sd, w64, xs, labels, il, ll, rand)
     eng.enqueue_train_step(xs, labels, il, ll, rand=rand, apply_update=False)
     got = float(eng.loss_mean.download()[0])
-    return {"gpu": got, "oracle_fp64": ref, "rel_delta": abs(got - ref) / abs(ref), "shape": "B=4,T=64"}
+    return {"gpu": got, "oracle_fp64": ref, "rel_delta": abs(got - ref) / abs(ref), "shape": "B=%d,T=%d" % (B, T)}
 
 
 if __name__ == "__main__":
