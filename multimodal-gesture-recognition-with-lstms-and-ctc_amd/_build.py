@@ -53,6 +53,8 @@ def build(force=False, verbose=True, jobs=4):
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > newest:
             continue
         cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if s in ISA_CHECKED:
+            cmd.append("--save-temps=obj")   # keeps the device assembly next to the object for check_hidden_loads()
         if verbose:
             print("[mgr build]", " ".join(cmd), file=sys.stderr)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -71,7 +73,66 @@ def build(force=False, verbose=True, jobs=4):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stdout.decode(errors="replace"))
+    check_hidden_loads(objdir)
     return LIB
+
+
+ISA_CHECKED = {"lstm_cluster.hip": ["k_scan_cluster_ks"]}
+
+
+def _regs(tok):
+    """'v[16:19]' / 'v7' -> set of VGPR indices (empty for anything else)."""
+    import re
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def check_hidden_loads(objdir):
+    """The K-split scan step issues its gather loads from inline asm and polls the destination REGISTERS (csrc/
+    lstm_cluster.hip, cluster_run_ks).  That only works if hipcc keeps each polled variable in the registers the load
+    writes: a compiler-inserted copy taken while the load is in flight freezes a stale value (seen once, in an
+    experimental BPTT variant: the workgroup then spins until its bounded give-up).  This check reads the device assembly
+    kept by --save-temps and fails the build if any move / spill instruction reads those registers."""
+    import re
+    for src, kernels in ISA_CHECKED.items():
+        stem = src.replace(".hip", "")
+        cands = [f for f in os.listdir(objdir) if f.startswith(stem) and f.endswith(".s") and "amdgcn" in f]
+        if not cands:
+            continue   # the object was up to date and no assembly of this build exists: nothing new to check
+        text = open(os.path.join(objdir, cands[0])).read().split("\n")
+        for kname in kernels:
+            start = next((i for i, l in enumerate(text) if re.match(r"^_Z\w*%s\w*:" % kname, l)), None)
+            if start is None:
+                raise RuntimeError("ISA check: kernel %s not found in %s" % (kname, cands[0]))
+            end = next(i for i in range(start, len(text)) if "s_endpgm" in text[i])
+            body = [l.split(";")[0].strip() for l in text[start:end]]
+            # a polling window runs from a group's first hidden load to the first MFMA that consumes the data
+            polled, nloads = set(), 0
+            for l in body:
+                if not l or " " not in l:
+                    continue
+                mnem, rest = l.split(None, 1)
+                ops = [o.strip() for o in rest.split(",")]
+                if mnem == "global_load_dwordx4" and " sc1" in l:
+                    polled |= _regs(ops[0])
+                    nloads += 1
+                    continue
+                if mnem.startswith("v_mfma"):
+                    polled = set()
+                    continue
+                if not polled:
+                    continue
+                if mnem.startswith(("v_mov", "v_accvgpr", "v_swap", "v_cndmask", "v_perm")) and any(_regs(o) & polled for o in ops[1:]):
+                    raise RuntimeError("ISA check (%s): '%s' copies a register that a hidden gather load writes while it may still "
+                                       "be in flight; the polling loop would watch a stale copy.  Restructure cluster_run_ks "
+                                       "(register pressure?)" % (kname, l))
+                if mnem.startswith("scratch_store") and any(_regs(o) & polled for o in ops):
+                    raise RuntimeError("ISA check (%s): '%s' spills a polled register" % (kname, l))
+            if nloads == 0:
+                raise RuntimeError("ISA check: no hidden gather loads found in %s" % kname)
 
 
 if __name__ == "__main__":

@@ -40,6 +40,7 @@ namespace {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int CL_WAVES = 8;
 constexpr unsigned POLL_LIMIT = 1u << 20;
+constexpr unsigned KS_ROUND_LIMIT = 1u << 16;   // K-split step: ~0.1 s of re-polling a late producer, ~1 s of lost loads
 
 template <int KS, int TPW>
 __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int bg, int ug, int cl, unsigned* xcc, int xcd_local,
@@ -695,14 +696,14 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, int bg, int
         if (__all(((a_or >> 30) & 1u) == 0u)) {       // everything landed, something was still the previous epoch
           issue = true;
           ++rounds;
-        } else if (++spins > 4096u) {                 // a load cannot take this long: drain and start over
+        } else if (++spins > 4096u) {                 // a load cannot take this long (~1 ms): drain and start over
           __builtin_amdgcn_s_waitcnt(0x0F70);
           issue = true;
-          ++rounds;
+          rounds += 64;                               // (so that this path, too, gives up after about a second)
         }
         if (issue) {
           if ((rounds & 63u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) failed = true;
-          if (rounds > POLL_LIMIT) {
+          if (rounds > KS_ROUND_LIMIT) {
             failed = true;
             if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }

@@ -203,3 +203,31 @@ def test_skeletal_feature_oracle_properties():
     assert F['lh_el_ang'][3] == np.arctan2(J['lhY'][3] - J['leY'][3], J['lhX'][3] - J['leX'][3])
     assert F['re_shc_d'][0] == np.hypot(J['reX'][0] - J['shcX'][0], J['reY'][0] - J['shcY'][0]) or \
         abs(F['re_shc_d'][0] - np.hypot(J['reX'][0] - J['shcX'][0], J['reY'][0] - J['shcY'][0])) < 1e-12
+
+
+def test_hidden_load_isa_check():
+    """The build keeps the device assembly of lstm_cluster.hip and verifies that no compiler-inserted copy reads a register
+    while a hidden gather load may still be writing it (see _build.check_hidden_loads).  Positive case: the shipped kernel;
+    negative control: a hand-made snippet with exactly the copy that once froze a polling loop."""
+    import tempfile
+    from mgr_amd import _build
+    objdir = os.path.join(os.path.dirname(_build.__file__), "build")
+    if any(f.endswith(".s") and "amdgcn" in f for f in os.listdir(objdir)):
+        _build.check_hidden_loads(objdir)
+    bad = """
+_ZN12_GLOBAL__N_117k_scan_cluster_ksE13ClusterLaunch:
+\tv_mov_b32_e32 v9, v54
+\tglobal_load_dwordx4 v[54:57], v[102:103], off sc1
+\ts_nop 0
+\tv_mov_b64_e32 v[50:51], v[54:55]
+\tv_mfma_f32_16x16x4_f32 v[0:3], v50, v4, v[0:3]
+\ts_endpgm
+"""
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "lstm_cluster-hip-amdgcn-amd-amdhsa-gfx950.s"), "w") as f:
+            f.write(bad)
+        with pytest.raises(RuntimeError, match="copies a register"):
+            _build.check_hidden_loads(d)
+        with open(os.path.join(d, "lstm_cluster-hip-amdgcn-amd-amdhsa-gfx950.s"), "w") as f:
+            f.write(bad.replace("\tv_mov_b64_e32 v[50:51], v[54:55]\n", "").replace("v50, v4", "v54, v4"))
+        _build.check_hidden_loads(d)     # the copy BEFORE the load and the MFMA consuming the loaded register are fine
