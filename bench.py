@@ -9,7 +9,7 @@ train frames/sec (+ CTC-loss delta vs the fp64 oracle), fusion BiLSTM+CTC, B=64 
 One JSON line on rank 0.  Inputs are synthetic and resident in HBM before the timed region; a step is one
 full training step (frozen encoders fwd, fusion BiLSTM fwd/bwd, CTC, Adam) with device-side noise/dropout
 RNG and one loss read-back, exactly K of them between barrier+sync pairs; value = all ranks' frames / max time.
-torch is used only for the multi-process rendezvous (gloo store) - never for compute.
+The multi-process rendezvous (RCCL unique id) is a plain TCP exchange on MASTER_ADDR:MASTER_PORT+101; torch is not imported.
 """
 import argparse
 import json
@@ -74,7 +74,8 @@ def main():
         B = args.batch
     if args.maxlen:
         T = args.maxlen
-    dev = _capi.Device(local_rank)
+    # (MGR_DEVICE_OVERRIDE: debugging aid to run several ranks on one GPU where the communication library permits it)
+    dev = _capi.Device(int(os.environ.get("MGR_DEVICE_OVERRIDE", local_rank)))
     if args.show_plan:
         dev.call("mgr_tune", 2, 1)
     if args.scan_path:
@@ -87,16 +88,14 @@ def main():
         dev.call("mgr_tune", 5, int(b))
 
     comm = None
+    if world == 1 and os.environ.get("MGR_FORCE_COMM"):
+        # debugging aid: a 1-rank RCCL communicator, so that the all-reduce / barrier code path runs on a single GPU
+        comm = RcclComm(dev, 0, 1, lambda uid: uid)
     if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("gloo")
-
-        def bootstrap(uid):
-            obj = [uid]
-            dist.broadcast_object_list(obj, src=0)
-            return obj[0]
-
-        comm = RcclComm(dev, rank, world, bootstrap)
+        # rendezvous over the launcher's MASTER_ADDR / MASTER_PORT (+101); importing torch here would pull the wheel's own
+        # HIP / HSA / RCCL copies into the process next to the ROCm installation's
+        from mgr_amd.parallel import tcp_bootstrap
+        comm = RcclComm(dev, rank, world, tcp_bootstrap(rank, world))
 
     eng = Engine(spec, B, T, Lmax, device=dev, seed=1000 + rank, comm=comm, world=world)
     eng.set_weights(synthetic_weights(spec, 20131900 + 3))
@@ -193,10 +192,8 @@ def main():
                "speedup_vs_cpu": round(value / cpu["value"], 1) if cpu else None}
         print(json.dumps(out))
     if comm:
+        comm.barrier()   # nobody tears its communicator down while a peer is still in a collective
         comm.close()
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
     return out
 
 

@@ -2,6 +2,7 @@
 // loads (and single-GPU paths work) on hosts without it.  One process per GPU; the unique id is created by
 // rank 0 and distributed by the host (any out-of-band channel).
 #include <dlfcn.h>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -27,10 +28,16 @@ Rccl g_rccl;
 
 int rccl_load() {
   if (g_rccl.lib) return 0;
-  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  // The ROCm installation's RCCL by ABSOLUTE path first: a process that has imported PyTorch already holds the wheel's own
+  // librccl.so (built against the wheel's bundled HIP / HSA runtimes), and a bare dlopen("librccl.so") returns THAT one -
+  // whose HSA wrapper is not the initialised runtime ("pfn_hsa_system_get_info failed with 4107 ... no ROCm-capable
+  // device is detected", seen under torch.distributed.run).  RTLD_LOCAL: its symbols are only reached through dlsym here.
+  const char* env = getenv("MGR_RCCL_PATH");
+  const char* names[] = {env ? env : "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so",
+                         "librccl.so.1", "librccl.so"};
   void* h = nullptr;
   for (const char* n : names) {
-    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     if (h) break;
   }
   if (!h) return mgr_fail(-3, "cannot dlopen librccl.so: %s", dlerror());

@@ -784,7 +784,7 @@ class Engine:
         dev, o = self.dev, self.spec.optimizer
         dev.stream(0)
         gscale = 1.0
-        if self.comm is not None and self.world > 1:
+        if self.comm is not None:   # (a 1-rank communicator is legal: the reduction is then the identity)
             self.comm.allreduce_sum(self.grads, self.n_train)
             gscale = 1.0 / self.world
         k = self.iterations

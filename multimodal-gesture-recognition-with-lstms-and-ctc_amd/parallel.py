@@ -68,3 +68,46 @@ def data_parallel_update(local_grads, allreduce_sum, world):
     returns the gradient every replica feeds to clip+Adam:  (sum over ranks of local mean-grads) / world."""
     total = allreduce_sum(np.asarray(local_grads))
     return total / float(world)
+
+
+def tcp_bootstrap(rank, world, addr=None, port=None, timeout=120.0):
+    """bootstrap(uid) callable for RcclComm that needs nothing but the launcher's MASTER_ADDR / MASTER_PORT: rank 0 serves the
+    128-byte unique id on MASTER_PORT + 101 (the launcher's own store owns MASTER_PORT), every other rank fetches it.
+    No torch import: a PyTorch wheel brings its own HIP / HSA / RCCL copies into the process."""
+    import os
+    import socket
+    import time
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(port or int(os.environ.get("MASTER_PORT", "29500")) + 101)
+
+    def bootstrap(uid):
+        deadline = time.time() + timeout
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr if addr not in ("localhost",) else "127.0.0.1", port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            for _ in range(world - 1):
+                c, _ = srv.accept()
+                c.sendall(uid)
+                c.close()
+            srv.close()
+            return uid
+        while True:
+            try:
+                c = socket.create_connection((addr, port), timeout=5.0)
+                break
+            except OSError:
+                if time.time() > deadline:
+                    raise RuntimeError("rank %d: no unique id from rank 0 at %s:%d" % (rank, addr, port))
+                time.sleep(0.1)
+        buf = b""
+        while len(buf) < 128:
+            chunk = c.recv(128 - len(buf))
+            if not chunk:
+                raise RuntimeError("rank %d: connection closed while receiving the unique id" % rank)
+            buf += chunk
+        c.close()
+        return buf
+    return bootstrap

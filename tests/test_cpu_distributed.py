@@ -98,3 +98,30 @@ def test_two_rank_gloo_equals_single_process(tmp_path):
         kk = k.replace("/", "__")
         assert np.array_equal(r0[kk], r1[kk]), k           # replicas stay bit-identical
         assert np.allclose(r0[kk], v, rtol=1e-10, atol=1e-14), k
+
+
+def _tcp_rank(rank, world, port, q):
+    from mgr_amd.parallel import tcp_bootstrap
+    boot = tcp_bootstrap(rank, world, addr="127.0.0.1", port=port, timeout=30.0)
+    uid = bytes(range(128)) if rank == 0 else None
+    q.put((rank, boot(uid)))
+
+
+def test_tcp_bootstrap_distributes_the_unique_id():
+    """The RCCL unique id travels from rank 0 to every other rank over a plain TCP exchange (no torch in the ranks)."""
+    import multiprocessing as mp
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    procs = [ctx.Process(target=_tcp_rank, args=(r, world, port, q)) for r in (2, 1, 0)]   # clients may start first
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in range(world))
+    for p in procs:
+        p.join(30)
+    assert all(got[r] == bytes(range(128)) for r in range(world))
