@@ -74,6 +74,10 @@ def build(force=False, verbose=True, jobs=4):
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stdout.decode(errors="replace"))
     check_hidden_loads(objdir)
+    # --save-temps leaves bitcode / preprocessed sources behind; only the device assembly is of further use
+    for f in os.listdir(objdir):
+        if f.endswith((".bc", ".hipi", ".hipfb", ".out", ".cui")) or (f.endswith(".s") and "amdgcn" not in f):
+            os.remove(os.path.join(objdir, f))
     return LIB
 
 
