@@ -101,9 +101,11 @@ def check_hidden_loads(objdir):
     experimental BPTT variant: the workgroup then spins until its bounded give-up).  This check reads the device assembly
     kept by --save-temps and fails the build if any move / spill instruction reads those registers."""
     import re
+    if os.environ.get("MGR_SKIP_ISA_CHECK"):   # diagnostic builds only (extra code may legitimately copy the registers)
+        return
     for src, kernels in ISA_CHECKED.items():
         stem = src.replace(".hip", "")
-        cands = [f for f in os.listdir(objdir) if f.startswith(stem) and f.endswith(".s") and "amdgcn" in f]
+        cands = [f for f in os.listdir(objdir) if f.startswith(stem + "-hip-amdgcn") and f.endswith(".s")]
         if not cands:
             continue   # the object was up to date and no assembly of this build exists: nothing new to check
         text = open(os.path.join(objdir, cands[0])).read().split("\n")
