@@ -116,8 +116,9 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
  * 2 force one workgroup per batch group (no inter-CU exchange) where it fits, 3 force clusters with 4 tiles per
  * workgroup, 4 same with 8 tiles per workgroup.  key 1: !=0 makes scan_fwd check the give-up word synchronously.
  * key 2: print the scan plan.  key 3: opt into the XCD-local exchange path (measured slower; kept for study).
- * key 7: 1 = one-tile-per-wave clusters keep the LDS-image step instead of the K-split / register-direct gather step. */
-enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 8 };
+ * key 7: 1 = one-tile-per-wave clusters keep the LDS-image step instead of the K-split / register-direct gather step.
+ * key 8: 1 = the multi-CU BPTT keeps its 4-wave kernel instead of the split-role (4 compute + 4 gather waves) one. */
+enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 12 };
 int mgr_tune(mgr_ctx* ctx, int key, int value);
 /* Fails (and reports through mgr_last_error) if any persistent multi-CU scan launched on this context ever gave up on a
  * bounded spin (a deadlocked or lost peer): such a launch returns promptly but its outputs are garbage.  Ordered on the

@@ -24,7 +24,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned POLL_LIMIT = 1u << 20;
 constexpr int BW_WAVES = 4;
 
-template <int H>
+// SPLIT = false: 4 waves, each gathers its share of the incoming partial tiles AND computes / stores its outgoing ones.
+// SPLIT = true : 8 waves, one workgroup per CU.  Waves 0-3 only compute and store, waves 4-7 only gather: a gather wave
+//   never stores, so the s_waitcnt in front of its gathered data no longer covers write-through stores (on gfx9 stores and
+//   loads share vmcnt; the acknowledgement of a wave's 8 x 16-byte stores per step was 2.7 of 7.8 us at H = 500), and the
+//   compute waves never wait on vmcnt for the exchange at all.  Plain compiler-managed loads - no register polling.
+template <int H, bool SPLIT>
 __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg, int ug, int cl, unsigned* xcc, int xcd_local,
                                                 float* smem, unsigned* status) {
   constexpr int N = 4 * H;
@@ -34,14 +39,17 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
   (void)xcd_local;
   (void)cl;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool gatherer = SPLIT ? wave_id >= BW_WAVES : true;    // runs step 1 (gather)
+  const bool computer = SPLIT ? wave_id < BW_WAVES : true;     // runs steps 2 and 3 (cell backward, MFMAs, stores)
+  const int wave = SPLIT ? (wave_id & (BW_WAVES - 1)) : wave_id;   // role-local wave index 0..3
   const int j = lane & 15, uq = lane >> 4;
   const int B = jb.B, T = jb.T, reverse = jb.reverse;
   const int b = bg * 16 + j;
   const bool bvalid = b < B;
   const int bc = bvalid ? b : B - 1;
   float* dzi = smem;                 // [4 blocks][4 gates][16 samples][4] own dz image: k-step s = own unit s, kk = gate
-  float* red = smem + 4 * 256;       // [4 waves][64 lanes][4] per-wave partial sums of the tiles addressed to this workgroup
+  float* red = smem + 4 * 256;       // [4 waves (+1: own tile, SPLIT)][64 lanes][4] partial sums of the tiles addressed to this workgroup
 
   // A fragments: tile m (units 16m..16m+15) x this workgroup's 64 gate columns: k-step s (own unit s), kk = gate
   //   A[i = lane&15][kk = lane>>4] = Up[unit 16m+i][4*(16*ug + s) + kk]
@@ -53,10 +61,10 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int su = ug * 16 + s;
-      uf[i][s] = (m < GT && ur < H && su < H) ? jb.Up[(size_t)ur * N + 4 * su + uq] : 0.f;
+      uf[i][s] = (computer && m < GT && ur < H && su < H) ? jb.Up[(size_t)ur * N + 4 * su + uq] : 0.f;
     }
   }
-  for (int i = tid; i < 4 * 256; i += BW_WAVES * 64) dzi[i] = 0.f;
+  for (int i = tid; i < 4 * 256; i += (int)blockDim.x) dzi[i] = 0.f;
 
   // cell backward ownership: unit = 16*ug + 4*uq + wave (row 4*(lane>>4)+reg of the reduced tile, reg = wave), sample j
   const int unit = ug * 16 + uq * 4 + wave;
@@ -74,7 +82,7 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
   r0.dy = r0.c = r1.dy = r1.c = r2.dy = r2.c = 0.f;
   r0.g = r1.g = r2.g = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load = [&](Saved& sv, int k) {
-    if (uvalid && k < T) {
+    if (computer && uvalid && k < T) {
       const int n = T - 1 - k;
       const int t = reverse ? T - 1 - n : n;
       const size_t row = (size_t)bc * T + t;
@@ -99,7 +107,7 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
     float dhr = 0.f;
     if (k > 0) {
       f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-      if (GT > 1) {
+      if (GT > 1 && gatherer) {
         const int slot = (k - 1) & 1;
         const unsigned par = (((unsigned)(k - 1) >> 1) & 1u) ^ 1u;
         u32x4 v[TPW];
@@ -138,7 +146,7 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
           const int src = wave + BW_WAVES * i;
           if (src < GT) {
             if (src == ug) {
-              sum += own_tile;
+              if (!SPLIT) sum += own_tile;   // (SPLIT: the own tile lives in a compute wave and goes through red[4])
             } else {
               sum[0] += __uint_as_float(v[i].x);
               sum[1] += __uint_as_float(v[i].y);
@@ -147,24 +155,30 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
             }
           }
         }
-      } else {
-        if (wave == 0) sum = own_tile;
+      } else if (GT <= 1) {
+        if (wave == 0 && computer) sum = own_tile;
       }
-      *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = sum;
+      if (SPLIT && GT > 1) {
+        if (gatherer) *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = sum;
+        if (computer && wave == (ug & (BW_WAVES - 1))) *reinterpret_cast<f32x4*>(red + (4 * 64 + lane) * 4) = own_tile;
+      } else if (computer) {
+        *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = sum;
+      }
       __syncthreads();
       dhr = red[(0 * 64 + lane) * 4 + wave] + red[(1 * 64 + lane) * 4 + wave] + red[(2 * 64 + lane) * 4 + wave] +
             red[(3 * 64 + lane) * 4 + wave];
+      if (SPLIT && GT > 1) dhr += red[(4 * 64 + lane) * 4 + wave];
     }
     // ---- 2. cell backward for (unit, sample); own dz slice -> global dZ and the LDS B-operand image
     float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (uvalid) {
+    if (computer && uvalid) {
       const float dh = use.dy + dhr;
       const float cp = has_prev ? prev.c : 0.f;
       dz = mgr_cell_bwd(dh, use.g, use.c, cp, dcc);
       if (bvalid) *reinterpret_cast<float4*>(jb.dZ + ((size_t)b * T + t) * N + unit * 4) = dz;
     }
     if (!has_prev) return;  // the first forward step has no predecessor: nothing to send (workgroup-uniform)
-    {
+    if (computer) {
       // own unit index s = 4*uq + wave -> image [q = s>>2 = uq][kk = gate][j][r = s&3 = wave]
       float* p = dzi + ((uq * 4) * 16 + j) * 4 + wave;
       p[0 * 64] = dz.x;
@@ -174,7 +188,7 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
     }
     __syncthreads();
     // ---- 3. partial sums for every tile of 16 units from this workgroup's 64 gate columns; send tile m to workgroup m
-    {
+    if (computer) {
       const int slot = k & 1;
       const unsigned par = (((unsigned)k >> 1) & 1u) ^ 1u;
       f32x4 dv[4];
@@ -220,8 +234,8 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
 
 #define BW_FOREACH(X) X(8) X(16) X(32) X(64) X(100) X(128) X(300) X(500)
 
-__global__ __launch_bounds__(BW_WAVES * 64) void k_scan_cluster_bwd(ClusterBwdLaunch L) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+template <bool SPLIT>
+__device__ __forceinline__ void scan_cluster_bwd_body(const ClusterBwdLaunch& L, float* smem) {
   const int bid = blockIdx.x;
   for (int k = 0; k < L.njobs; ++k) {
     const ClusterBwdJob& jb = L.job[k];
@@ -234,11 +248,22 @@ __global__ __launch_bounds__(BW_WAVES * 64) void k_scan_cluster_bwd(ClusterBwdLa
     const int bg = cl - jb.cls_cluster0;
     if (bg < 0 || bg >= jb.nbg) continue;
 #define BW_CASE(HH) \
-  if (jb.H == HH) { cluster_bwd_run<HH>(jb, bg, ug, cl, L.xcc, L.xcd_local, smem, L.status); return mgr_cluster_exit(L.status, L.sticky); }
+  if (jb.H == HH) { cluster_bwd_run<HH, SPLIT>(jb, bg, ug, cl, L.xcc, L.xcd_local, smem, L.status); return mgr_cluster_exit(L.status, L.sticky); }
     BW_FOREACH(BW_CASE)
 #undef BW_CASE
     return;
   }
+}
+
+__global__ __launch_bounds__(BW_WAVES * 64) void k_scan_cluster_bwd(ClusterBwdLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  scan_cluster_bwd_body<false>(L, smem);
+}
+
+// split roles: 4 compute + 4 gather waves, one workgroup per CU
+__global__ __launch_bounds__(2 * BW_WAVES * 64) void k_scan_cluster_bwd_split(ClusterBwdLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  scan_cluster_bwd_body<true>(L, smem);
 }
 
 }  // namespace
@@ -260,15 +285,27 @@ bool mgr_cluster_bwd_supported(int H) {
 int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs) {
   int maxH = 0;
   for (int i = 0; i < L.njobs; ++i) maxH = L.job[i].H > maxH ? L.job[i].H : maxH;
-  (void)maxH;
-  size_t lds = (size_t)(4 * 256 + 4 * 64 * 4) * sizeof(float);
   MGR_REQUIRE(total_wgs <= 2 * c->cu_count, "cluster BPTT needs %d co-resident workgroups", total_wgs);
   static bool attr_set = false;
   if (!attr_set) {
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_scan_cluster_bwd, dim3(total_wgs), dim3(BW_WAVES * 64), lds, mgr_stream(c), L);
+  // split roles (8 waves, > 80 KiB of LDS requested so that exactly one workgroup sits on a CU) whenever the launch fits one
+  // workgroup per CU and has an exchange at all; tune key 8 = 1 keeps the 4-wave kernel
+  // ... and the layers are wide: at H = 100 (7 workgroups per cluster, two 16-byte stores per lane and step) the store
+  // acknowledgement is 0.35 of 2.2 us and the 8-wave workgroups cost config F 0.7 % end to end, at H = 300 / 500 they
+  // save a third of the step (E: 60 -> 48 ms/step, S_ref 24 -> 21)
+  bool exchange = false;
+  for (int i = 0; i < L.njobs; ++i) exchange = exchange || L.job[i].G_ > 1;
+  if (exchange && maxH >= 200 && total_wgs <= c->cu_count && c->tune[8] != 1) {
+    size_t lds = 84 * 1024;
+    hipLaunchKernelGGL(k_scan_cluster_bwd_split, dim3(total_wgs), dim3(2 * BW_WAVES * 64), lds, mgr_stream(c), L);
+  } else {
+    size_t lds = (size_t)(4 * 256 + 5 * 64 * 4) * sizeof(float);
+    hipLaunchKernelGGL(k_scan_cluster_bwd, dim3(total_wgs), dim3(BW_WAVES * 64), lds, mgr_stream(c), L);
+  }
   MGR_LAUNCH_CHECK();
   return 0;
 }
