@@ -80,8 +80,8 @@ def main():
         dev.call("mgr_tune", 2, 1)
     if args.scan_path:
         dev.call("mgr_tune", 0, args.scan_path)
-    if os.environ.get("MGR_BWD_SPLIT") == "0":   # experiment hook: 4-wave BPTT cluster kernel instead of the split-role one
-        dev.call("mgr_tune", 8, 1)
+    if os.environ.get("MGR_BWD_SPLIT") in ("0", "2"):   # experiment hook: 0 = always the 4-wave BPTT cluster kernel, 2 = always split roles
+        dev.call("mgr_tune", 8, 1 if os.environ["MGR_BWD_SPLIT"] == "0" else 2)
     if os.environ.get("MGR_GATHER_DELAY"):
         dev.call("mgr_tune", 6, int(os.environ["MGR_GATHER_DELAY"]))
     if os.environ.get("MGR_SCAN_CFG"):   # experiment hook: "<cfg for H>=400>:<cfg for H<400>", 1-based indices into kCfgs

@@ -299,7 +299,7 @@ int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs)
   // save a third of the step (E: 60 -> 48 ms/step, S_ref 24 -> 21)
   bool exchange = false;
   for (int i = 0; i < L.njobs; ++i) exchange = exchange || L.job[i].G_ > 1;
-  if (exchange && maxH >= 200 && total_wgs <= c->cu_count && c->tune[8] != 1) {
+  if (exchange && (maxH >= 200 || c->tune[8] == 2) && total_wgs <= c->cu_count && c->tune[8] != 1) {   // (key 8 = 2 forces it)
     size_t lds = 84 * 1024;
     hipLaunchKernelGGL(k_scan_cluster_bwd_split, dim3(total_wgs), dim3(2 * BW_WAVES * 64), lds, mgr_stream(c), L);
   } else {
