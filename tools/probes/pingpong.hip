@@ -65,9 +65,13 @@ void run(const char* name, int* flags, long long* out, int* xcc, int partner) {
   else printf("  %-34s partner=%2d xcc=(%d,%d): one-way %7.1f ns\n", name, partner, x[0], x[1], t * 10.0 / (2.0 * (iters - 8)));
 }
 
-int main() {
+int main(int argc, char** argv) {
   int* flags; long long* out; int* xcc;
-  CHECK(hipMalloc(&flags, 1024)); CHECK(hipMalloc(&out, 64)); CHECK(hipMalloc(&xcc, 64));
+  const int kind = argc > 1 ? atoi(argv[1]) : 0;   // 0 hipMalloc, 1 uncached device memory, 2 fine-grained device memory
+  if (kind == 1) { CHECK(hipExtMallocWithFlags((void**)&flags, 1024, hipDeviceMallocUncached)); printf("exchange words in UNCACHED device memory\n"); }
+  else if (kind == 2) { CHECK(hipExtMallocWithFlags((void**)&flags, 1024, hipDeviceMallocFinegrained)); printf("exchange words in FINE-GRAINED device memory\n"); }
+  else { CHECK(hipMalloc(&flags, 1024)); printf("exchange words in hipMalloc memory\n"); }
+  CHECK(hipMalloc(&out, 64)); CHECK(hipMalloc(&xcc, 64));
   // aux bits: 1 = sc0, 2 = nt, 16 = sc1
   for (int partner : {8, 1}) {
     printf("%s pair:\n", partner == 8 ? "same-XCD (expected)" : "cross-XCD (expected)");
