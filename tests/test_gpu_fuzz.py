@@ -1,0 +1,77 @@
+"""-m gpu: randomised multi-job scan launches against the oracle (forward cluster kernels: K-split step, LDS-image step,
+and their mixes; BPTT cluster kernels incl. the split-role one).  MGR_FUZZ_CASES raises the number of cases (default 8)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import keras_ref as kr
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _lstm_weights(rng, F, H, scale_u):
+    W = rng.uniform(-0.3, 0.3, (F, 4 * H))
+    U = rng.standard_normal((H, 4 * H)) * scale_u
+    b = rng.uniform(-0.2, 0.2, (4 * H,))
+    return W, U, b
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("MGR_FUZZ_CASES", "8"))))
+def test_random_multi_job_scans(device, case):
+    from mgr_amd import _capi
+    dev = device
+    rng = np.random.default_rng(9000 + case)
+    f32 = np.float32
+    njobs = int(rng.integers(1, 5))
+    T = int(rng.integers(3, 120))
+    B = int(rng.integers(1, 70))
+    jobs, bjobs, refs, outs, keep = [], [], [], [], []
+    for _ in range(njobs):
+        H = int(rng.choice([100, 300, 500, 128, 32]))
+        F = int(rng.integers(3, 9))
+        reverse = int(rng.integers(0, 2))
+        W, U, b = _lstm_weights(rng, F, H, 0.6 / np.sqrt(H))
+        x = rng.standard_normal((B, T, F))
+        y_ref, cache = kr.lstm_forward(x, W, U, b, None, bool(reverse))
+        dY = rng.standard_normal((B, T, H)) * 0.1
+        Wp, Up, bp = dev.empty((F, 4 * H)), dev.empty((H, 4 * H)), dev.empty((4 * H,))
+        dev.call("mgr_lstm_pack", dev.array(W.astype(f32)), Wp, F, H, 0)
+        dev.call("mgr_lstm_pack", dev.array(U.astype(f32)), Up, H, H, 0)
+        dev.call("mgr_lstm_pack", dev.array(b.astype(f32)), bp, 1, H, 0)
+        Z = dev.empty((B, T, 4 * H))
+        dev.call("mgr_lstm_input_proj", dev.array(x.astype(f32)), F, 0, Wp, bp, Z, B, T, F, H)
+        Y, G, Cs = dev.empty((B, T, H)), dev.empty((B, T, H, 4)), dev.empty((B, T, H))
+        jobs.append(dict(Z=Z, Up=Up, Y=Y, ldy=H, R=0, ldr=0, gates=G, cs=Cs, B=B, T=T, H=H, reverse=reverse))
+        dZ = dev.zeros((B, T, 4 * H))
+        bjobs.append(dict(dY=dev.array(dY.astype(f32)), gates=G, cs=Cs, Up=Up, dZ=dZ, lddy=H, B=B, T=T, H=H, reverse=reverse))
+        refs.append((y_ref, cache, dY, W, U))
+        outs.append((Y, G, Cs, dZ, Z))
+        keep += [Wp, Up, bp]
+    dev.call("mgr_tune", 1, 1)   # synchronous give-up check
+    try:
+        arr = _capi.make_scan_jobs(jobs)
+        ws = dev.bytes(dev.lib.mgr_lstm_scan_multi_ws_bytes(njobs, arr))
+        _capi.check(dev.lib.mgr_lstm_scan_fwd_multi(dev.ctx, njobs, arr, ws.ptr, ws.nbytes))
+        for (Y, G, Cs, _, _), (y_ref, cache, _, _, _) in zip(outs, refs):
+            assert rel_err(Y.download(), y_ref) < 5e-5
+            assert rel_err(Cs.download(), cache["c"]) < 5e-5
+        barr = _capi.make_scan_bwd_jobs(bjobs)
+        bws = dev.bytes(dev.lib.mgr_lstm_scan_bwd_multi_ws_bytes(njobs, barr))
+        _capi.check(dev.lib.mgr_lstm_scan_bwd_multi(dev.ctx, njobs, barr, bws.ptr, bws.nbytes))
+        # BPTT check through its consequence: dU = sum_t h_{t-1}^T dz_t against the oracle's dU
+        for (Y, G, Cs, dZ, _), (y_ref, cache, dY, W, U), j in zip(outs, refs, bjobs):
+            _, _, dU_ref, _ = kr.lstm_backward(dY, cache, need_dx=False)
+            H = j["H"]
+            dz = dZ.download().reshape(B, T, H, 4).transpose(0, 1, 3, 2).reshape(B, T, 4 * H)   # packed -> Keras gate-major
+            h = Y.download()
+            hp = np.zeros_like(h)
+            if j["reverse"]:
+                hp[:, :-1] = h[:, 1:]
+            else:
+                hp[:, 1:] = h[:, :-1]
+            dU = np.einsum("bth,btg->hg", hp.astype(np.float64), dz.astype(np.float64))
+            assert rel_err(dU, dU_ref) < 5e-4
+    finally:
+        dev.call("mgr_tune", 1, 0)
