@@ -91,7 +91,9 @@ void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
       if (G > 1) exch = true;
       int nbg = (j.B + 15) / 16;
       if (f.pair == 2 && (G == 1 || nbg < 2)) feas = false;  // pairing only pays when there is a hand-off to hide
-      total += G * ((nbg + f.pair - 1) / f.pair);
+      // (classes of jobs are laid out on workgroup ranges rounded up to a multiple of 8 - the XCD count - at launch; count
+      // every job rounded up so that a plan accepted here always passes the launcher's co-residency check)
+      total += (G * ((nbg + f.pair - 1) / f.pair) + 7) / 8 * 8;
       if (f.pair == 2) anypair = true;
       // per-step estimate in cycles: MFMA chain per SIMD (+15% issue overhead) + cell update + exchange / barrier
       int tiles_here = std::min(tiles, ks);
