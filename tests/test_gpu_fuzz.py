@@ -75,3 +75,47 @@ def test_random_multi_job_scans(device, case):
             assert rel_err(dU, dU_ref) < 5e-4
     finally:
         dev.call("mgr_tune", 1, 0)
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("MGR_FUZZ_NETS", "6"))))
+def test_random_networks(device, case):
+    """Random members of the reference's network family (1-2 streams of 1-2 BiLSTM layers, optional fusion BiLSTM, frozen or
+    trainable encoders) at random sizes: loss, softmax and every trainable gradient against the fp64 oracle."""
+    import mgr_amd  # noqa: F401
+    from mgr_amd.engine import Engine
+    from mgr_amd.spec import NetworkSpec
+    from mgr_amd.synthetic import synthetic_arrays, synthetic_weights
+    from oracle import network_ref as nr
+    rng = np.random.default_rng(7000 + case)
+    hs = [8, 16, 32, 64, 100, 128, 300]
+    nstreams = int(rng.integers(1, 3))
+    use_fusion = bool(rng.integers(0, 2)) or nstreams == 2
+    streams = []
+    for si in range(nstreams):
+        nl = int(rng.integers(1, 3))
+        H = int(rng.choice(hs))
+        streams.append({"name": "in%d" % si, "F": int(rng.integers(3, 12)), "noise": float(rng.choice([0.0, 0.5])),
+                        "residual": nl == 2, "trainable": bool(rng.integers(0, 2)) or not use_fusion,
+                        "layers": [{"H": H, "dropout": float(rng.choice([0.0, 0.4])), "name": "l%d_%d" % (si, k)} for k in range(nl)]})
+    fusion = {"H": int(rng.choice([8, 16, 32, 100])), "dropout": 0.5, "name": "fus"} if use_fusion else None
+    C = int(rng.integers(5, 23))
+    spec = NetworkSpec(streams, fusion, {"dropout": float(rng.choice([0.0, 0.5])), "C": C})
+    B, T = int(rng.integers(1, 40)), int(rng.integers(12, 70))
+    Lmax = 8
+    eng = Engine(spec, B, T, Lmax, device=device, seed=case)
+    w = synthetic_weights(spec, 500 + case)
+    eng.set_weights(w)
+    xs, labels, il, ll = synthetic_arrays(spec, B, T, Lmax, 600 + case, lmin=1, lmax=4)
+    sd = spec.to_dict()
+    rand = nr.draw_rand(sd, B, T, np.random.default_rng(700 + case))
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    ref_loss, ref_lb, ref_g, ref_P = nr.loss_and_grads(sd, w64, xs, labels, il, ll, rand)
+    eng.enqueue_train_step(xs, labels, il, ll, rand=rand, apply_update=False)
+    loss = eng.read_loss()
+    assert abs(loss - ref_loss) <= 1e-4 * abs(ref_loss), (loss, ref_loss, sd)
+    assert rel_err(eng.P.download(), ref_P) < 2e-4
+    g = eng.get_grads()
+    assert set(g) == set(ref_g)
+    for k in ref_g:
+        assert rel_err(g[k], ref_g[k]) < 2e-3, (k, rel_err(g[k], ref_g[k]), sd)
+    eng.close()
