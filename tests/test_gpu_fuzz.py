@@ -119,3 +119,52 @@ def test_random_networks(device, case):
     for k in ref_g:
         assert rel_err(g[k], ref_g[k]) < 2e-3, (k, rel_err(g[k], ref_g[k]), sd)
     eng.close()
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("MGR_FUZZ_SEQS", "4"))))
+def test_random_operation_sequences_pipelined_equals_plain(device, case):
+    """Random interleavings of training steps (with and without an announced next batch), validation losses and
+    predictions on a pipelined engine give exactly the numbers of an engine that never overlaps anything: exercises the
+    two-stream schedule, the copy stream and the alternating input / label / FEAT buffers."""
+    import mgr_amd  # noqa: F401
+    from mgr_amd.configs import fusion_spec
+    from mgr_amd.engine import Engine
+    from mgr_amd.synthetic import synthetic_arrays, synthetic_weights
+    rng = np.random.default_rng(3000 + case)
+    big = case % 4 == 3     # every fourth sequence at the reference's layer sizes (multi-CU cluster kernels, deferral)
+    spec = fusion_spec() if big else fusion_spec(h_audio=32, h_skeletal=16, h_fusion=8)
+    B, T, Lmax = int(rng.integers(2, 20)), int(rng.integers(20, 60)), 6
+    w = synthetic_weights(spec, 40 + case)
+    batches = [synthetic_arrays(spec, B, T, Lmax, 900 + 10 * case + i, lmin=1, lmax=4) for i in range(6)]
+    ops = []
+    for _ in range(14):
+        r = rng.random()
+        ops.append(("train", int(rng.integers(0, 6)), bool(rng.integers(0, 2))) if r < 0.6 else
+                   (("val" if r < 0.8 else "predict"), int(rng.integers(0, 6)), False))
+
+    def run(pipelined):
+        eng = Engine(spec, B, T, Lmax, device=device, seed=77)
+        eng.set_weights(w)
+        out = []
+        for i, (op, bi, announce) in enumerate(ops):
+            xs, labels, il, ll = batches[bi]
+            if op == "train":
+                nxt = None
+                if pipelined and announce and i + 1 < len(ops):
+                    # usually the batch that really comes next; sometimes a wrong announcement (or one followed by a
+                    # validation / prediction call), which the engine has to notice and discard
+                    nxt = batches[ops[i + 1][1]][0] if (i + case) % 5 else batches[(ops[i + 1][1] + 1) % 6][0]
+                out.append(eng.train_step(xs, labels, il, ll, next_inputs=nxt))
+            elif op == "val":
+                out.append(float(np.sum(eng.loss_on_batch(xs, labels, il, ll, train_phase=False))))
+            else:
+                out.append(float(eng.predict(xs).sum()))
+        weights = eng.get_weights()
+        eng.close()
+        return out, weights
+
+    a, wa = run(True)
+    b, wb = run(False)
+    assert a == b, (ops, a, b)
+    for k in wa:
+        assert np.array_equal(wa[k], wb[k]), k
