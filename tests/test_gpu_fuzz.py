@@ -168,3 +168,72 @@ def test_random_operation_sequences_pipelined_equals_plain(device, case):
     assert a == b, (ops, a, b)
     for k in wa:
         assert np.array_equal(wa[k], wb[k]), k
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("MGR_FUZZ_GEMMS", "6"))))
+def test_random_gemm_shapes(device, case):
+    """The three MFMA GEMM entry points at random (ragged) shapes, strides, alignments and masks against numpy fp64:
+    packed column j*4+g holds gate g of unit j; the Keras per-gate input-dropout mask multiplies X per (gate, sample, feature)."""
+    dev = device
+    rng = np.random.default_rng(5000 + case)
+    f32 = np.float32
+    B, T = int(rng.integers(1, 9)), int(rng.integers(1, 300))
+    F, H = int(rng.integers(1, 200)), int(rng.integers(1, 80))
+    N = 4 * H
+    ldx = F + int(rng.choice([0, 0, 1, 3, 4, 8]))           # ldx not a multiple of 4 -> the unaligned (scalar) loaders
+    use_mask = bool(rng.integers(0, 2))
+    Xh = np.zeros((B, T, ldx), f32)
+    Xh[:, :, :F] = rng.standard_normal((B, T, F))
+    Wp = (rng.standard_normal((F, N)) * 0.2).astype(f32)
+    bp = rng.standard_normal(N).astype(f32)
+    mask = ((rng.random((4, B, F)) > 0.4) * 1.6).astype(f32) if use_mask else None
+    X64 = Xh[:, :, :F].astype(np.float64)
+    gate = np.arange(N) % 4
+
+    def masked_x(g):   # (B,T,F) seen by gate g
+        return X64 * mask[g][:, None, :].astype(np.float64) if use_mask else X64
+
+    dX_ = dev.array(Xh)
+    dW_, db_ = dev.array(Wp), dev.array(bp)
+    dM = dev.array(mask) if use_mask else 0
+    # nn
+    Z = dev.empty((B, T, N))
+    dev.call("mgr_lstm_input_proj", dX_, ldx, dM, dW_, db_, Z, B, T, F, H)
+    Zref = np.empty((B, T, N))
+    for g in range(4):
+        Zref[:, :, gate == g] = masked_x(g) @ Wp[:, gate == g].astype(np.float64) + bp[gate == g]
+    assert rel_err(Z.download(), Zref) < 2e-5
+    # tn (dW, dU, db) with a time-shifted h
+    reverse = int(rng.integers(0, 2))
+    ldh = H + int(rng.choice([0, 4, 5]))
+    Hh = np.zeros((B, T, ldh), f32)
+    Hh[:, :, :H] = rng.standard_normal((B, T, H))
+    dZ = (rng.standard_normal((B, T, N)) * 0.3).astype(f32)
+    gW, gU, gb = dev.empty((F, N)), dev.empty((H, N)), dev.empty((N,))
+    ws = dev.bytes(dev.lib.mgr_lstm_param_grads_ws_bytes(B, T, F, H))
+    dev.call("mgr_lstm_param_grads", dX_, ldx, dM, dev.array(Hh), ldh, dev.array(dZ), gW, gU, gb, B, T, F, H, reverse, ws, ws.nbytes)
+    dZ64 = dZ.astype(np.float64)
+    gW_ref = np.empty((F, N))
+    for g in range(4):
+        gW_ref[:, gate == g] = np.einsum("btf,btn->fn", masked_x(g), dZ64[:, :, gate == g])
+    hprev = np.zeros((B, T, H))
+    h64 = Hh[:, :, :H].astype(np.float64)
+    if reverse:
+        hprev[:, :-1] = h64[:, 1:]
+    else:
+        hprev[:, 1:] = h64[:, :-1]
+    assert rel_err(gW.download(), gW_ref) < 5e-5
+    assert rel_err(gU.download(), np.einsum("bth,btn->hn", hprev, dZ64)) < 5e-5
+    assert rel_err(gb.download(), dZ64.sum((0, 1))) < 5e-5
+    # nt (dX), plain and accumulating
+    lddx = F + int(rng.choice([0, 2, 4]))
+    base = rng.standard_normal((B, T, lddx)).astype(f32)
+    dXo = dev.array(base)
+    dev.call("mgr_lstm_input_grad", dev.array(dZ), dW_, dM, dXo, lddx, 1, B, T, F, H)
+    ref = np.zeros((B, T, F))
+    for g in range(4):
+        part = dZ64[:, :, gate == g] @ Wp[:, gate == g].astype(np.float64).T
+        ref += part * mask[g][:, None, :] if use_mask else part
+    got = dXo.download()
+    assert rel_err(got[:, :, :F] - base[:, :, :F], ref) < 5e-5
+    assert np.array_equal(got[:, :, F:], base[:, :, F:])      # padding columns untouched
