@@ -237,3 +237,35 @@ def test_random_gemm_shapes(device, case):
     got = dXo.download()
     assert rel_err(got[:, :, :F] - base[:, :, :F], ref) < 5e-5
     assert np.array_equal(got[:, :, F:], base[:, :, F:])      # padding columns untouched
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("MGR_FUZZ_CTC", "6"))))
+def test_random_ctc(device, case):
+    """CTC loss and logit gradient at random shapes: label rows with repeats, with the blank class itself as a target
+    (the reference's empty-label substitution, data_generator.py:228-238), per-sample input lengths, peaky or flat
+    posteriors; feasible alignments only (TF returns inf otherwise)."""
+    from tests.test_gpu_kernels import _run_ctc
+    rng = np.random.default_rng(1000 + case)
+    B, T = int(rng.integers(1, 12)), int(rng.integers(5, 260))
+    Cn = int(rng.integers(3, 50))
+    Lmax = int(rng.integers(1, 40))
+    z = rng.standard_normal((B, T, Cn)) * float(rng.choice([0.5, 2.0, 6.0]))
+    P = np.exp(z - z.max(-1, keepdims=True))
+    P = (P / P.sum(-1, keepdims=True)).astype(np.float32)
+    labels = -np.ones((B, Lmax))
+    ll = np.zeros(B, np.int64)
+    il = np.zeros(B, np.int64)
+    for b in range(B):
+        Tin = int(rng.integers(max(1, (T - 2) // 3), T - 1))          # frames after the skip
+        Lcap = max(1, min(Lmax, (Tin + 1) // 2))                      # room for the blanks between repeats
+        L = int(rng.integers(1, Lcap + 1))
+        seq = rng.integers(0, Cn, size=L) if rng.random() < 0.3 else rng.integers(0, Cn - 1, size=L)   # sometimes incl. the blank id
+        if rng.random() < 0.4 and L > 1:
+            seq[1] = seq[0]                                            # adjacent repeat
+        labels[b, :L] = seq
+        ll[b], il[b] = L, Tin
+    ref_loss, ref_dz = kr.ctc_loss_grad(P.astype(np.float64), labels, il, ll)
+    ok = np.isfinite(ref_loss)
+    loss, dz = _run_ctc(device, P, labels, il, ll)
+    assert np.allclose(loss[ok], ref_loss[ok], rtol=1e-4), (loss, ref_loss)
+    assert rel_err(dz[ok], ref_dz[ok]) < 1e-3
