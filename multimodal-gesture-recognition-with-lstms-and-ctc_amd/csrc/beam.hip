@@ -8,8 +8,10 @@
 //      an extension that reproduces the prefix of another live beam r2 (its trie parent is beam r and its last
 //      label is c) is merged into r2's stay candidate instead (stay term first, then the extension)
 //   3. the W best candidates by lse(p_blank, p_nonblank) - ties to the smaller idx, -inf dropped - are picked by W
-//      rounds of a wave-wide (score, idx) arg-max with lane shuffles; extensions allocate a trie node
-//      (parent, label) in the per-sequence node pool.
+//      rounds of a wave-wide (score, idx) arg-max with lane shuffles; extensions take their trie node (parent, label)
+//      from a per-sequence hash table, so that a prefix which fell out of the beam and is found again keeps its node
+//      id: "same node" is then exactly "same prefix", which the merge rule of step 2 relies on (a prefix p can die
+//      while p+c lives; when p comes back, p+c must still be recognised as its child).
 // The winner's prefix is read back through the parent links.  Scores are fp64 because fp32 scores near -5000 have
 // an ulp of 5e-4 and the beam cut would then depend on libm rounding; the CPU oracle uses the same formulas.
 #include "common.h"
@@ -39,14 +41,15 @@ __global__ __launch_bounds__(64) void k_beam(const float* __restrict__ P, const 
                                              int C, int skip, int blank, int W, float eps, int merge_repeated,
                                              int32_t* __restrict__ out, int32_t* __restrict__ out_len,
                                              double* __restrict__ logp, int32_t* __restrict__ node_parent,
-                                             int32_t* __restrict__ node_label, int nodes_per_seq) {
+                                             int32_t* __restrict__ node_label, int nodes_per_seq,
+                                             unsigned long long* __restrict__ table, int table_bits) {
   __shared__ double s_logy[MAXC];
   __shared__ double s_pb[MAXW], s_pnb[MAXW], s_tot[MAXW];
   __shared__ double s_npb[MAXW], s_npnb[MAXW];   // stay candidates (after merging)
-  __shared__ int s_node[MAXW], s_last[MAXW], s_len[MAXW];
+  __shared__ int s_node[MAXW], s_pnode[MAXW], s_last[MAXW], s_len[MAXW];
   __shared__ unsigned long long s_mmask[MAXW];   // classes whose extension of beam r was merged into another beam
   __shared__ double s_selb[MAXW], s_selnb[MAXW];
-  __shared__ int s_selnode[MAXW], s_sellast[MAXW], s_sellen[MAXW];
+  __shared__ int s_selnode[MAXW], s_selpnode[MAXW], s_sellast[MAXW], s_sellen[MAXW];
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
   const int To = T - skip;
@@ -54,6 +57,11 @@ __global__ __launch_bounds__(64) void k_beam(const float* __restrict__ P, const 
   Tp = Tp < 0 ? 0 : (Tp > To ? To : Tp);
   int32_t* par = node_parent + (size_t)b * nodes_per_seq;
   int32_t* lab = node_label + (size_t)b * nodes_per_seq;
+  // (parent, label) -> node: open addressing, one 64-bit word per entry = (key + 1) << 32 | node, 0 = empty
+  unsigned long long* tab = table + ((size_t)b << table_bits);
+  const unsigned tmask = (1u << table_bits) - 1u;
+  for (unsigned i = lane; i <= tmask; i += 64) tab[i] = 0ull;
+  __threadfence();
   int nb = 1;          // live beams
   int nnodes = 1;      // node 0 = empty prefix
   if (lane == 0) {
@@ -62,6 +70,7 @@ __global__ __launch_bounds__(64) void k_beam(const float* __restrict__ P, const 
     s_pb[0] = 0.0;
     s_pnb[0] = kNegInfD;
     s_node[0] = 0;
+    s_pnode[0] = -1;
     s_last[0] = -1;
     s_len[0] = 0;
   }
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(64) void k_beam(const float* __restrict__ P, const 
     __syncthreads();
     // ---- 2b. merge extensions that land on a live beam (lane = r2; at most one (r, c) per r2)
     if (lane < nb && s_len[lane] > 0) {
-      int pnode = par[s_node[lane]];
+      int pnode = s_pnode[lane];
       int c = s_last[lane];
       for (int r = 0; r < nb; ++r) {
         if (s_node[r] == pnode) {
@@ -152,16 +161,15 @@ __global__ __launch_bounds__(64) void k_beam(const float* __restrict__ P, const 
           s_selb[nsel] = s_npb[r];
           s_selnb[nsel] = s_npnb[r];
           s_selnode[nsel] = s_node[r];
+          s_selpnode[nsel] = s_pnode[r];
           s_sellast[nsel] = s_last[r];
           s_sellen[nsel] = s_len[r];
         } else {
           int c = slot - 1;
-          int nn = nnodes + nsel;  // provisional id; only extensions consume ids, gaps are harmless
-          par[nn] = s_node[r];
-          lab[nn] = c;
           s_selb[nsel] = kNegInfD;
           s_selnb[nsel] = ((s_len[r] > 0 && c == s_last[r]) ? s_pb[r] : s_tot[r]) + s_logy[c];
-          s_selnode[nsel] = nn;
+          s_selnode[nsel] = -1;  // resolved below, all selections in parallel
+          s_selpnode[nsel] = s_node[r];
           s_sellast[nsel] = c;
           s_sellen[nsel] = s_len[r] + 1;
         }
@@ -170,9 +178,36 @@ __global__ __launch_bounds__(64) void k_beam(const float* __restrict__ P, const 
     }
     __syncthreads();
     if (lane < nsel) {
+      int node = s_selnode[lane];
+      if (node < 0) {
+        // find-or-insert (parent, label); the selected extensions are distinct prefixes, hence distinct keys
+        const int pn = s_selpnode[lane], c = s_sellast[lane];
+        const unsigned key = (unsigned)pn * 64u + (unsigned)c + 1u;
+        const int fresh = nnodes + lane;  // only used if the prefix is new; gaps in the pool are harmless
+        unsigned h = (key * 0x9E3779B1u) >> (32 - table_bits);
+        for (;;) {
+          unsigned long long e = __hip_atomic_load(tab + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (e == 0ull) {
+            unsigned long long mine = ((unsigned long long)key << 32) | (unsigned)fresh;
+            if (atomicCAS(tab + h, 0ull, mine) == 0ull) {
+              par[fresh] = pn;
+              lab[fresh] = c;
+              node = fresh;
+              break;
+            }
+            continue;  // another lane took the slot: look at it again
+          }
+          if ((unsigned)(e >> 32) == key) {
+            node = (int)(unsigned)e;
+            break;
+          }
+          h = (h + 1u) & tmask;
+        }
+      }
       s_pb[lane] = s_selb[lane];
       s_pnb[lane] = s_selnb[lane];
-      s_node[lane] = s_selnode[lane];
+      s_node[lane] = node;
+      s_pnode[lane] = s_selpnode[lane];
       s_last[lane] = s_sellast[lane];
       s_len[lane] = s_sellen[lane];
     }
@@ -181,6 +216,7 @@ __global__ __launch_bounds__(64) void k_beam(const float* __restrict__ P, const 
     __syncthreads();
   }
   // ---- read the winner back
+  __threadfence();
   if (lane == 0) {
     int32_t* o = out + (size_t)b * To;
     int n = 0;
@@ -188,9 +224,9 @@ __global__ __launch_bounds__(64) void k_beam(const float* __restrict__ P, const 
       int len = s_len[0];
       int node = s_node[0];
       // write reversed into the tail, then compact forward
-      for (int i = len - 1; i >= 0; --i) {
-        o[i] = lab[node];
-        node = par[node];
+      for (int i = len - 1; i >= 0; --i) {  // (nodes were written by other lanes: read them past the L1)
+        o[i] = __hip_atomic_load(lab + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        node = __hip_atomic_load(par + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (merge_repeated) {
         for (int i = 0; i < len; ++i)
@@ -211,10 +247,16 @@ __global__ __launch_bounds__(64) void k_beam(const float* __restrict__ P, const 
 
 extern "C" {
 
+static int beam_table_bits(size_t nodes) {
+  int bits = 6;
+  while (((size_t)1 << bits) < 2 * nodes) ++bits;
+  return bits;
+}
+
 size_t mgr_ctc_beam_ws_bytes(int B, int T, int C, int beam) {
   (void)C;
   size_t nodes = (size_t)T * (beam > 0 ? beam : 1) + 2;
-  return mgr_align_up((size_t)B * nodes * sizeof(int32_t), 256) * 2;
+  return mgr_align_up((size_t)B * nodes * sizeof(int32_t), 256) * 2 + ((size_t)B << beam_table_bits(nodes)) * sizeof(unsigned long long);
 }
 
 int mgr_ctc_beam_search(mgr_ctx* c, const float* P, const int32_t* input_len, int B, int T, int C, int skip, int blank,
@@ -227,11 +269,14 @@ int mgr_ctc_beam_search(mgr_ctx* c, const float* P, const int32_t* input_len, in
   MGR_REQUIRE(blank >= 0 && blank < C, "blank out of range");
   MGR_REQUIRE(ws && ws_bytes >= mgr_ctc_beam_ws_bytes(B, T, C, beam), "workspace too small");
   int nodes = T * beam + 2;
+  MGR_REQUIRE((size_t)nodes < ((size_t)1 << 25), "T*beam too large for the prefix table");
   int32_t* parent = reinterpret_cast<int32_t*>(ws);
   int32_t* label = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + mgr_align_up((size_t)B * nodes * sizeof(int32_t), 256));
+  unsigned long long* table =
+      reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + 2 * mgr_align_up((size_t)B * nodes * sizeof(int32_t), 256));
   mgr_prof_begin(c, MGR_K_MISC);
   hipLaunchKernelGGL(k_beam, dim3(B), dim3(64), 0, mgr_stream(c), P, input_len, B, T, C, skip, blank, beam, eps,
-                     merge_repeated, out, out_len, logp, parent, label, nodes);
+                     merge_repeated, out, out_len, logp, parent, label, nodes, table, beam_table_bits(nodes));
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_MISC);
   return 0;

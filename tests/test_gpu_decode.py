@@ -75,6 +75,25 @@ def test_beam_search_golden_and_random(device):
         assert np.allclose(gs, rs, rtol=1e-12)
 
 
+def test_beam_search_prefix_reentering_the_beam(device):
+    """Few classes and a narrow beam: a prefix p drops out of the beam while p+c stays, and p is found again later.  The
+    extension p -> p+c must then still merge into the live beam p+c (the kernel keys trie nodes by (parent, label) so a
+    re-found prefix keeps its identity); a kernel that gave the re-found p a new node carried two copies of p+c and lost
+    probability mass - found by tests/test_gpu_fuzz.py::test_random_decode."""
+    from mgr_amd import decoding
+    for seed in (423, 7, 8, 9):
+        rng = np.random.default_rng(seed)
+        for (T, Cn, W) in [(9, 3, 3), (150, 5, 10), (400, 3, 4), (60, 4, 16)]:
+            z = rng.standard_normal((3, T, Cn)) * 1.5
+            P = np.exp(z - z.max(-1, keepdims=True))
+            P = (P / P.sum(-1, keepdims=True)).astype(np.float32)
+            il = np.array([T - 2, (T - 2) // 2, max(1, T // 3)])
+            ref, rs = kr.ctc_beam_search(P, il, beam_width=W, merge_repeated=False)
+            got, gs = decoding.beam_search_decode(P, il, beam_width=W, merge_repeated=False, dev=device)
+            assert got == ref, (seed, T, Cn, W)
+            assert np.allclose(gs, rs, rtol=1e-12)
+
+
 def test_ctc_lambda_func_dropin(device):
     from mgr_amd import decoding
     from mgr_amd.multimodal_fusion.losses import ctc_lambda_func

@@ -269,3 +269,32 @@ def test_random_ctc(device, case):
     loss, dz = _run_ctc(device, P, labels, il, ll)
     assert np.allclose(loss[ok], ref_loss[ok], rtol=1e-4), (loss, ref_loss)
     assert rel_err(dz[ok], ref_dz[ok]) < 1e-3
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("MGR_FUZZ_DECODE", "20"))))
+def test_random_decode(device, case):
+    """Thresholded best-path decode (with the reference's list.remove quirk) and CTC prefix beam search at random shapes,
+    thresholds, beam widths and posteriors from flat to peaky: label sequences identical to the oracle's."""
+    from mgr_amd import decoding
+    rng = np.random.default_rng(2000 + case)
+    N, T = int(rng.integers(1, 7)), int(rng.integers(4, 160))
+    Cn = int(rng.integers(2, 45))
+    z = rng.standard_normal((N, T, Cn)) * float(rng.choice([0.3, 1.5, 4.0]))
+    for n in range(N):   # runs of a dominant class, like a trained network's output
+        t = 0
+        while t < T:
+            run = int(rng.integers(1, 12))
+            z[n, t:t + run, int(rng.integers(0, Cn))] += rng.uniform(0, 6)
+            t += run
+    P = np.exp(z - z.max(-1, keepdims=True))
+    P = (P / P.sum(-1, keepdims=True)).astype(np.float32)
+    thr = float(rng.choice([0.3, 0.5, 0.75, 0.97]))
+    assert decoding.greedy_decode(P, thr, dev=device) == kr.greedy_decode_quirk(P, thr)
+    W = int(rng.choice([1, 2, 5, 10, 16]))
+    if W * (Cn + 1) <= 64 * 34:
+        il = rng.integers(1, T - 1, size=N)
+        mr = bool(rng.integers(0, 2))
+        ref, rs = kr.ctc_beam_search(P, il, beam_width=W, merge_repeated=mr)
+        got, gs = decoding.beam_search_decode(P, il, beam_width=W, merge_repeated=mr, dev=device)
+        assert got == ref, (N, T, Cn, W, mr)
+        assert np.allclose(gs, rs, rtol=1e-12)
