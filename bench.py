@@ -39,6 +39,32 @@ def cpu_baseline(spec_dict, seed, T_cpu, B_cpu):
     return B_cpu * T_cpu / dt, dt, float(loss)
 
 
+def _spawn_ranks(n):
+    """`python bench.py --gpus N` without torchrun: start N copies of this command, one rank per GPU, rendezvous on
+    127.0.0.1; rank 0's JSON line goes to stdout.  Returns the first non-zero exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable] + sys.argv, env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            if p.poll() is not None:
+                live.remove(p)
+                if p.returncode and not rc:   # one rank failed: the others would only wait for it
+                    rc = p.returncode
+                    for q in live:
+                        q.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,6 +87,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        # started without a launcher: be the launcher (one child per GPU; this process never touches the GPU)
+        sys.exit(_spawn_ranks(args.gpus))
 
     import mgr_amd  # noqa: F401
     from mgr_amd import _capi

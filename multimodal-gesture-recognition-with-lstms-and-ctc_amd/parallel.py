@@ -70,7 +70,7 @@ def data_parallel_update(local_grads, allreduce_sum, world):
     return total / float(world)
 
 
-def tcp_bootstrap(rank, world, addr=None, port=None, timeout=120.0):
+def tcp_bootstrap(rank, world, addr=None, port=None, timeout=600.0):
     """bootstrap(uid) callable for RcclComm that needs nothing but the launcher's MASTER_ADDR / MASTER_PORT: rank 0 serves the
     128-byte unique id on MASTER_PORT + 101 (the launcher's own store owns MASTER_PORT), every other rank fetches it.
     No torch import: a PyTorch wheel brings its own HIP / HSA / RCCL copies into the process."""
