@@ -89,6 +89,12 @@ int mgr_transpose(mgr_ctx* ctx, const float* src, float* dst, int rows, int cols
  * X has row stride ldx floats (>= F).  mask4 [4,B,F] may be NULL (no input dropout).  Z is [B,T,4H] packed order. */
 int mgr_lstm_input_proj(mgr_ctx* ctx, const float* X, int ldx, const float* mask4, const float* Wp,
                         const float* bp, float* Z, int B, int T, int F, int H);
+/* The same for BOTH directions of a Bidirectional layer (multimodal.py:159-168: two LSTMs over the same input, each with
+ * its own kernel, bias and dropout masks) as one GEMM over 8H columns when that saves column tiles (4H = 400: 7 instead
+ * of 2 x 4); otherwise it is two mgr_lstm_input_proj calls.  Results are identical to the two calls. */
+int mgr_lstm_input_proj_pair(mgr_ctx* ctx, const float* X, int ldx, const float* mask4_fwd, const float* Wp_fwd,
+                             const float* bp_fwd, float* Z_fwd, const float* mask4_rev, const float* Wp_rev,
+                             const float* bp_rev, float* Z_rev, int B, int T, int F, int H);
 /* Recurrence. reverse=1 walks t = T-1..0 and writes outputs at their original t (Bidirectional backward
  * sub-layer).  Y[b,t,0:H] with row stride ldy gets h_t (+ R[b,t,0:H] with stride ldr when R != NULL: the
  * residual add / concat fusion of multimodal.py:111,117,155).  gates [B,T,H,4] (i,f,g,o after activation) and

@@ -124,6 +124,26 @@ __device__ __forceinline__ void load_mc_fast(RegTile& r, const float* __restrict
   }
 }
 
+// Two-matrix view of the m-contiguous operand: columns [0, nd) come from base, columns [nd, 2 nd) from base2 (both with row
+// stride nd).  Used to run the two directions of a Bidirectional layer as ONE GEMM over N = 8H columns: for 4H = 400 that
+// is 7 column tiles instead of 2 x 4 (the fourth tile of a 400-column matrix is 12.5 % used).  nd is a multiple of 4.
+__device__ __forceinline__ void load_mc_fast2(RegTile& r, const float* __restrict__ base, const float* __restrict__ base2, int nd,
+                                              int m0, int k0, int tid, int kshift = 0) {
+#pragma unroll
+  for (int i = 0; i < LPT; ++i) {
+    int idx4 = tid + i * 256;
+    int k = idx4 >> 5, m4 = (idx4 & 31) * 4;
+    int gm = m0 + m4;
+    gm = gm + 3 < 2 * nd ? gm : 2 * nd - 4;
+    const float* src = gm >= nd ? base2 + (gm - nd) : base + gm;
+    float4 t = *reinterpret_cast<const float4*>(src + (ptrdiff_t)(k0 + k + kshift) * (ptrdiff_t)nd);
+    r.v[i * 4 + 0] = t.x;
+    r.v[i * 4 + 1] = t.y;
+    r.v[i * 4 + 2] = t.z;
+    r.v[i * 4 + 3] = t.w;
+  }
+}
+
 __device__ __forceinline__ void mma_stage(const float (*As)[LDS_LD], const float (*Bs)[LDS_LD], f32x16 (&acc)[2][2], int wr,
                                           int wc, int lane) {
   const int l31 = lane & 31, lh = lane >> 5;
@@ -233,6 +253,81 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(const float* __restrict__ X,
       for (int reg = 0; reg < 16; ++reg) {
         int r = r0 + ACC_ROW(wr, mt, reg, lane);
         if (r < T && col < N) Z[((size_t)b * T + r) * N + col] = acc[mt][nt][reg] + bias;
+      }
+    }
+}
+
+
+// nn over both directions of a Bidirectional layer: columns [0,Nd) -> (Wp, bp, mask4, Z), [Nd, 2Nd) -> (Wp2, bp2, mask4b, Z2).
+// Requires F % BK == 0 and 16-byte aligned rows (the host falls back to two k_gemm_nn launches otherwise).
+// grid: (ceil(2Nd/128), ceil(T/128), B)
+__global__ __launch_bounds__(256, 4) void k_gemm_nn2(const float* __restrict__ X, int ldx, const float* __restrict__ mask4,
+                                                  const float* __restrict__ mask4b, const float* __restrict__ Wp,
+                                                  const float* __restrict__ Wp2, const float* __restrict__ bp,
+                                                  const float* __restrict__ bp2, float* __restrict__ Z, float* __restrict__ Z2,
+                                                  int B, int T, int F, int Nd) {
+  __shared__ __attribute__((aligned(16))) float As2[NBUF][BK][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs2[NBUF][BK][LDS_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int n0 = blockIdx.x * BN, r0 = blockIdx.y * BM, b = blockIdx.z;
+  const float* Xb = X + (size_t)b * T * ldx;
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  RegTile ra, rb, rm;
+  const bool masked = mask4 != nullptr;
+  // this thread's B columns (4 gates of one unit) all belong to one direction
+  const float* mk = (n0 + (tid & 31) * 4 >= Nd) ? mask4b : mask4;
+  auto fetch_mask = [&](int k0) {
+    if (masked) {
+#pragma unroll
+      for (int i = 0; i < LPT; ++i) {
+        int k = k0 + ((tid + i * 256) >> 5);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rm.v[i * 4 + g] = mk[((size_t)g * B + b) * F + k];
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+    if (masked) {
+#pragma unroll
+      for (int e = 0; e < 4 * LPT; ++e) rb.v[e] *= rm.v[e];
+    }
+    store_kc(As2[buf], ra, tid);
+    store_mc(Bs2[buf], rb, tid);
+  };
+  const int nst = F / BK;
+  load_kc_fast(ra, Xb, (size_t)ldx, r0, 0, T, tid);
+  load_mc_fast2(rb, Wp, Wp2, Nd, n0, 0, tid);
+  fetch_mask(0);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kt = 0; kt < nst; ++kt) {
+    const bool more = kt + 1 < nst;
+    if (more) {
+      load_kc_fast(ra, Xb, (size_t)ldx, r0, (kt + 1) * BK, T, tid);
+      load_mc_fast2(rb, Wp, Wp2, Nd, n0, (kt + 1) * BK, tid);
+      fetch_mask((kt + 1) * BK);
+    }
+    mma_stage(As2[buf], Bs2[buf], acc, wr, wc, lane);
+    if (NBUF == 1) __syncthreads();
+    if (more) stash(buf ^ (NBUF - 1));
+    __syncthreads();
+    buf ^= (NBUF - 1);
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      int col = n0 + ACC_COL(wc, nt, lane);
+      const bool second = col >= Nd;
+      const int cd = second ? col - Nd : col;
+      float* Zd = second ? Z2 : Z;
+      float bias = (col < 2 * Nd) ? (second ? bp2 : bp)[cd] : 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        int r = r0 + ACC_ROW(wr, mt, reg, lane);
+        if (r < T && col < 2 * Nd) Zd[((size_t)b * T + r) * Nd + cd] = acc[mt][nt][reg] + bias;
       }
     }
 }
@@ -452,6 +547,29 @@ int mgr_lstm_input_proj(mgr_ctx* c, const float* X, int ldx, const float* mask4,
   dim3 grid((N + BN - 1) / BN, (T + BM - 1) / BM, B);
   mgr_prof_begin(c, MGR_K_GEMM_NN);
   hipLaunchKernelGGL(k_gemm_nn, grid, dim3(256), 0, mgr_stream(c), X, ldx, mask4, Wp, bp, Z, B, T, F, N, vecA);
+  MGR_LAUNCH_CHECK();
+  mgr_prof_end(c, MGR_K_GEMM_NN);
+  return 0;
+}
+
+int mgr_lstm_input_proj_pair(mgr_ctx* c, const float* X, int ldx, const float* mask4_fwd, const float* Wp_fwd,
+                             const float* bp_fwd, float* Z_fwd, const float* mask4_rev, const float* Wp_rev,
+                             const float* bp_rev, float* Z_rev, int B, int T, int F, int H) {
+  MGR_REQUIRE(c && X && Wp_fwd && bp_fwd && Z_fwd && Wp_rev && bp_rev && Z_rev, "null argument");
+  MGR_REQUIRE((mask4_fwd == nullptr) == (mask4_rev == nullptr), "both directions masked or neither");
+  MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0 && ldx >= F, "bad shape");
+  const int Nd = 4 * H;
+  const bool fast = (ldx % 4 == 0) && (F % BK == 0) && aligned16(X) && aligned16(Wp_fwd) && aligned16(Wp_rev);
+  // one launch pays when it saves column tiles; otherwise (or for shapes the fused kernel does not take) two plain ones
+  if (!fast || (2 * Nd + BN - 1) / BN >= 2 * ((Nd + BN - 1) / BN)) {
+    int r = mgr_lstm_input_proj(c, X, ldx, mask4_fwd, Wp_fwd, bp_fwd, Z_fwd, B, T, F, H);
+    if (r) return r;
+    return mgr_lstm_input_proj(c, X, ldx, mask4_rev, Wp_rev, bp_rev, Z_rev, B, T, F, H);
+  }
+  dim3 grid((2 * Nd + BN - 1) / BN, (T + BM - 1) / BM, B);
+  mgr_prof_begin(c, MGR_K_GEMM_NN);
+  hipLaunchKernelGGL(k_gemm_nn2, grid, dim3(256), 0, mgr_stream(c), X, ldx, mask4_fwd, mask4_rev, Wp_fwd, Wp_rev, bp_fwd, bp_rev,
+                     Z_fwd, Z_rev, B, T, F, Nd);
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_GEMM_NN);
   return 0;

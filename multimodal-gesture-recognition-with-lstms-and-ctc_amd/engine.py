@@ -395,13 +395,18 @@ class Engine:
                 else:
                     Hp = s["layers"][k - 1]["H"]
                     cur, ldcur, fin = self.Y1[name], 2 * Hp, 2 * Hp
+                pair = []
                 for di, dname in enumerate(("fwd", "bwd")):
                     L = self.dirs["%s/l%d/%s" % (name, k, dname)]
                     slot += 1   # (every projection GEMM fills the chip: one stream keeps their timings honest)
                     mptr = self._prep_mask(L, train, rand, slot)
                     self._masks[(L.prefix, L.d)] = mptr
+                    pair += [mptr, L.Wp, L.bp, self.Zbuf[name][di]]
+                # both directions read the same input: one call (one GEMM where that saves column tiles)
+                dev.call("mgr_lstm_input_proj_pair", cur, ldcur, *pair, B, T, fin, H)
+                for di, dname in enumerate(("fwd", "bwd")):
+                    L = self.dirs["%s/l%d/%s" % (name, k, dname)]
                     Z = self.Zbuf[name][di]
-                    dev.call("mgr_lstm_input_proj", cur, ldcur, mptr, L.Wp, L.bp, Z, B, T, fin, H)
                     R, ldr = 0, 0
                     if not last:
                         Y, ldy = self.Y1[name].view(di * H, (1,)), 2 * H
@@ -446,11 +451,15 @@ class Engine:
         if sp.fusion:
             Hf = sp.fusion["H"]
             jobs = []
+            pair = []
             for di, dname in enumerate(("fwd", "bwd")):
                 L = self.dirs["fusion/%s" % dname]
                 mptr = self._prep_mask(L, train, rand, 500 + di)
                 self._masks[(L.prefix, L.d)] = mptr
-                dev.call("mgr_lstm_input_proj", feat_buf, W, mptr, L.Wp, L.bp, self.ZF[di], B, T, W, Hf)
+                pair += [mptr, L.Wp, L.bp, self.ZF[di]]
+            dev.call("mgr_lstm_input_proj_pair", feat_buf, W, *pair, B, T, W, Hf)
+            for di, dname in enumerate(("fwd", "bwd")):
+                L = self.dirs["fusion/%s" % dname]
                 jobs.append(dict(Z=self.ZF[di], Up=L.Up, Y=self.YF.view(di * Hf, (1,)), ldy=2 * Hf, R=0, ldr=0,
                                  gates=L.gates if save else 0, cs=L.cs if save else 0, B=B, T=T, H=Hf,
                                  reverse=L.reverse))

@@ -203,6 +203,17 @@ def test_random_gemm_shapes(device, case):
     for g in range(4):
         Zref[:, :, gate == g] = masked_x(g) @ Wp[:, gate == g].astype(np.float64) + bp[gate == g]
     assert rel_err(Z.download(), Zref) < 2e-5
+    # both directions of a Bidirectional layer in one call: bit-identical to two calls, whichever kernel it picks
+    Wp2 = (rng.standard_normal((F, N)) * 0.2).astype(f32)
+    bp2 = rng.standard_normal(N).astype(f32)
+    mask2 = ((rng.random((4, B, F)) > 0.4) * 1.6).astype(f32) if use_mask else None
+    dW2_, db2_ = dev.array(Wp2), dev.array(bp2)
+    dM2 = dev.array(mask2) if use_mask else 0
+    Zb = dev.empty((B, T, N))
+    dev.call("mgr_lstm_input_proj", dX_, ldx, dM2, dW2_, db2_, Zb, B, T, F, H)
+    Za2, Zb2 = dev.empty((B, T, N)), dev.empty((B, T, N))
+    dev.call("mgr_lstm_input_proj_pair", dX_, ldx, dM, dW_, db_, Za2, dM2, dW2_, db2_, Zb2, B, T, F, H)
+    assert np.array_equal(Za2.download(), Z.download()) and np.array_equal(Zb2.download(), Zb.download())
     # tn (dW, dU, db) with a time-shifted h
     reverse = int(rng.integers(0, 2))
     ldh = H + int(rng.choice([0, 4, 5]))
