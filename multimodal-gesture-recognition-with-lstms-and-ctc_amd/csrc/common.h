@@ -30,6 +30,7 @@ struct mgr_ctx {
   int prof_launches[MGR_K_COUNT];
   int tune[MGR_TUNE_COUNT];
   unsigned* sticky_status;  // device word: give-up code of any persistent scan launch since the last mgr_scan_status
+  unsigned attr_done;       // bit k: function attributes of kernel family k have been set on this context's device
 };
 
 int mgr_fail(int code, const char* fmt, ...);

@@ -898,12 +898,11 @@ int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool a
     MGR_REQUIRE(total_wgs <= per_cu * c->cu_count, "cluster scan needs %d co-resident workgroups but the device holds %d",
                 total_wgs, per_cu * c->cu_count);
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!(c->attr_done & 1u)) {   // (function attributes are per device, hence per context)
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_ks), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    c->attr_done |= 1u;
   }
   bool ks_all = L.ksplit && any_exchange && !L.xcd_local && waves == 4;
   for (int i = 0; i < L.njobs && ks_all; ++i) {

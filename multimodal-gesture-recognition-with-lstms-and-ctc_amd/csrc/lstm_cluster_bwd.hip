@@ -286,11 +286,10 @@ int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs)
   int maxH = 0;
   for (int i = 0; i < L.njobs; ++i) maxH = L.job[i].H > maxH ? L.job[i].H : maxH;
   MGR_REQUIRE(total_wgs <= 2 * c->cu_count, "cluster BPTT needs %d co-resident workgroups", total_wgs);
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!(c->attr_done & 2u)) {
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    c->attr_done |= 2u;
   }
   // split roles (8 waves, > 80 KiB of LDS requested so that exactly one workgroup sits on a CU) whenever the launch fits one
   // workgroup per CU and has an exchange at all; tune key 8 = 1 keeps the 4-wave kernel
