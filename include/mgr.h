@@ -95,6 +95,15 @@ int mgr_lstm_input_proj(mgr_ctx* ctx, const float* X, int ldx, const float* mask
 int mgr_lstm_input_proj_pair(mgr_ctx* ctx, const float* X, int ldx, const float* mask4_fwd, const float* Wp_fwd,
                              const float* bp_fwd, float* Z_fwd, const float* mask4_rev, const float* Wp_rev,
                              const float* bp_rev, float* Z_rev, int B, int T, int F, int H);
+/* The same projection for a layer with Keras input dropout at rate drop_rate (the rate only selects the kernel; mask4
+ * holds the actual factors, 0 or 1/(1-p)): from drop_rate >= 0.3 on (and 128 <= F <= 2048) the K loop runs per gate
+ * over the kept features only (gemm.hip, k_gemm_nn_sparse) - the same sums with the zero terms left out, i.e. equal to
+ * mgr_lstm_input_proj up to fp32 summation order.  ws from mgr_lstm_input_proj_dropout_ws_bytes (index lists, rebuilt by
+ * every call).  tune key 9 = 1 keeps the dense kernel. */
+size_t mgr_lstm_input_proj_dropout_ws_bytes(int B, int F);
+int mgr_lstm_input_proj_dropout(mgr_ctx* ctx, const float* X, int ldx, const float* mask4, float drop_rate,
+                                const float* Wp, const float* bp, float* Z, int B, int T, int F, int H, void* ws,
+                                size_t ws_bytes);
 /* Recurrence. reverse=1 walks t = T-1..0 and writes outputs at their original t (Bidirectional backward
  * sub-layer).  Y[b,t,0:H] with row stride ldy gets h_t (+ R[b,t,0:H] with stride ldr when R != NULL: the
  * residual add / concat fusion of multimodal.py:111,117,155).  gates [B,T,H,4] (i,f,g,o after activation) and
@@ -123,7 +132,8 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
  * workgroup, 4 same with 8 tiles per workgroup.  key 1: !=0 makes scan_fwd check the give-up word synchronously.
  * key 2: print the scan plan.  key 3: opt into the XCD-local exchange path (measured slower; kept for study).
  * key 7: 1 = one-tile-per-wave clusters keep the LDS-image step instead of the K-split / register-direct gather step.
- * key 8: 1 = the multi-CU BPTT keeps its 4-wave kernel instead of the split-role (4 compute + 4 gather waves) one. */
+ * key 8: 1 = the multi-CU BPTT keeps its 4-wave kernel instead of the split-role (4 compute + 4 gather waves) one.
+ * key 9: 1 = mgr_lstm_input_proj_dropout always takes the dense kernel. */
 enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 12 };
 int mgr_tune(mgr_ctx* ctx, int key, int value);
 /* Fails (and reports through mgr_last_error) if any persistent multi-CU scan launched on this context ever gave up on a

@@ -332,6 +332,166 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nn2(const float* __restrict__ X
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ nn, dropout-aware
+// Keras input dropout zeroes a fraction p of the input features per (gate, sample) (speech_lstm_ctc_words.py:61,73:
+// p = 0.4 / 0.5; skeletal_lstm_ctc.py:313,327: 0.6; multimodal.py:159-168: 0.5): (x (.) m_g) . W_g only needs the kept
+// features.  k_mask_compact lists, per (gate, sample), the kept feature indices (ascending) followed by the dropped ones;
+// k_gemm_nn_sparse then runs ONE K LOOP PER GATE over the kept indices only (rounded up to a stage of 16 with dropped
+// ones, whose mask factor is 0): X columns and W rows are gathered by index while staging into LDS, each gate pass fills
+// its own accumulators for the same (row, unit) positions, and the epilogue stores the four gates of a unit as one float4
+// in the packed order the scans read.  At p = 0.5 that is half the MFMA work of the dense kernel for the same result.
+__global__ __launch_bounds__(64) void k_mask_compact(const float* __restrict__ mask4, int F, int Fp, int* __restrict__ kidx,
+                                                     float* __restrict__ kval, int* __restrict__ kcnt) {
+  const int gb = blockIdx.x, lane = threadIdx.x;
+  const float* m = mask4 + (size_t)gb * F;
+  int* out = kidx + (size_t)gb * Fp;
+  float* val = kval + (size_t)gb * Fp;
+  int n = 0;
+  for (int pass = 0; pass < 2; ++pass) {   // kept features first, then the dropped ones (factor 0: stage padding)
+    for (int f0 = 0; f0 < F; f0 += 64) {
+      const int f = f0 + lane;
+      const float v = f < F ? m[f] : 0.f;
+      const bool take = f < F && ((v != 0.f) == (pass == 0));
+      const unsigned long long bal = __ballot(take);
+      if (take) {
+        const int pos = n + __popcll(bal & ((1ull << lane) - 1ull));
+        out[pos] = f;
+        val[pos] = v;
+      }
+      n += __popcll(bal);
+    }
+    if (pass == 0 && lane == 0) kcnt[gb] = n;
+  }
+  for (int i = F + lane; i < Fp; i += 64) {   // F not a multiple of the stage depth: the last stage is filled up with zero terms
+    out[i] = 0;
+    val[i] = 0.f;
+  }
+}
+
+constexpr int SP_MAXF = 2048;   // feature-count limit of the sparse kernel (index + factor lists of one gate pass live in LDS)
+constexpr int SP_TM = 128, SP_TU = 64, SP_SK = 16;   // tile: 128 rows x 64 units x 4 gates, 16 k per stage
+
+// One workgroup per tile, units fastest (workgroups that hold a CU for the whole kernel were measured: no faster alone -
+// the float4 stores of a tile are 0.1 of 3.3 ms - and they starve the small kernels of the other stream).  Global loads
+// run two stages ahead of the MFMAs (two register sets): a gathered element costs an LDS index read plus a scattered
+// 4-byte global load.
+__global__ __launch_bounds__(256, 2) void k_gemm_nn_sparse(const float* __restrict__ X, int ldx, const int* __restrict__ kidx,
+                                                        const float* __restrict__ kval, const int* __restrict__ kcnt,
+                                                        const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                        float* __restrict__ Z, int B, int T, int Fp, int H) {
+  constexpr int TM = SP_TM, TU = SP_TU, SK = SP_SK;
+  constexpr int APT = TM / 16;        // A elements per thread and stage: 16 k x TM rows over 256 threads
+  constexpr int BPT = SK * TU / 256;  // B elements per thread and stage
+  constexpr int BKS = 256 / TU;       // k rows covered by one pass of the 256 threads over the B stage
+  __shared__ float As[2][SK][TM + 4];
+  __shared__ float Bs[2][SK][TU + 4];
+  __shared__ int Ls[SP_MAXF];
+  __shared__ float Vs[SP_MAXF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int N = 4 * H;
+  const int ak = tid & 15, ar = tid >> 4;   // A staging: this thread's k within the stage, its first row (then +16, +32, ...)
+  const int bu = tid % TU, bk = tid / TU;   // B staging: this thread's unit, its first k (then +BKS, ...)
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int ncol = (H + TU - 1) / TU, nrow = (T + TM - 1) / TM;
+  struct Regs {
+    float a[APT], w[BPT], v[BPT];
+  };
+  {
+    const int tile = blockIdx.x;
+    const int u0 = (tile % ncol) * TU, r0 = ((tile / ncol) % nrow) * TM, b = tile / (ncol * nrow);
+    const float* Xb = X + (size_t)b * T * ldx;
+    const int ucl = (u0 + bu < H) ? u0 + bu : H - 1;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][mt][r] = 0.f;
+    int arow[APT];   // row offsets of this thread's A elements (clamped: rows >= T are computed but never stored)
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+      int row = r0 + ar + 16 * i;
+      arow[i] = (row < T ? row : T - 1) * ldx;   // (one sample's [T, ldx] block stays below 2^31 elements)
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nst = (kcnt[g * B + b] + SK - 1) / SK;   // (<= Fp / 16)
+      {
+        const int* list = kidx + ((size_t)g * B + b) * Fp;
+        const float* lval = kval + ((size_t)g * B + b) * Fp;
+        for (int i = tid; i < nst * SK; i += 256) {
+          Ls[i] = list[i];
+          Vs[i] = lval[i];
+        }
+      }
+      __syncthreads();
+      const float* Wg = Wp + ucl * 4 + g;
+      auto fetch = [&](Regs& r, int st) {
+        const float* xp = Xb + Ls[st * SK + ak];
+#pragma unroll
+        for (int i = 0; i < APT; ++i) r.a[i] = xp[arow[i]];
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) {
+          const int q = st * SK + bk + BKS * j;
+          r.w[j] = Wg[(size_t)Ls[q] * N];
+          r.v[j] = Vs[q];
+        }
+      };
+      auto stash = [&](const Regs& r, int buf) {
+#pragma unroll
+        for (int i = 0; i < APT; ++i) As[buf][ak][ar + 16 * i] = r.a[i];
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) Bs[buf][bk + BKS * j][bu] = r.w[j] * r.v[j];
+      };
+      auto mma = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < SK / 2; ++ks) {
+          const float a0 = As[buf][ks * 2 + lh][wr * 64 + l31];
+          const float a1 = As[buf][ks * 2 + lh][wr * 64 + 32 + l31];
+          const float bb = Bs[buf][ks * 2 + lh][wc * 32 + l31];
+          acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb, acc[g][0], 0, 0, 0);
+          acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bb, acc[g][1], 0, 0, 0);
+        }
+      };
+      if (nst > 0) {
+        Regs R0, R1;
+        fetch(R0, 0);
+        if (nst > 1) fetch(R1, 1);
+        stash(R0, 0);
+        __syncthreads();
+        // stage st computes from LDS buffer st & 1; its data were fetched two iterations ago and stashed in the previous one
+        for (int st = 0; st < nst; st += 2) {
+          if (st + 2 < nst) fetch(R0, st + 2);
+          mma(0);
+          if (st + 1 < nst) stash(R1, 1);
+          __syncthreads();
+          if (st + 1 < nst) {
+            if (st + 3 < nst) fetch(R1, st + 3);
+            mma(1);
+            if (st + 2 < nst) stash(R0, 0);
+            __syncthreads();
+          }
+        }
+      }
+    }
+    const int unit = u0 + wc * 32 + l31;
+    if (unit < H) {
+      const float4 bias = *reinterpret_cast<const float4*>(bp + unit * 4);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = r0 + wr * 64 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+          if (row < T)
+            *reinterpret_cast<float4*>(Z + ((size_t)b * T + row) * N + unit * 4) =
+                make_float4(acc[0][mt][reg] + bias.x, acc[1][mt][reg] + bias.y, acc[2][mt][reg] + bias.z, acc[3][mt][reg] + bias.w);
+        }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ tn
 // slab[z][f][n] = sum over samples b = z, z+SG, ...  of  mask(b,f,n) * sum_t A[b,t+shift,f] * dZ[b,t,n]
 // grid: (ceil(N/128), ceil(F/128), SG)
@@ -570,6 +730,35 @@ int mgr_lstm_input_proj_pair(mgr_ctx* c, const float* X, int ldx, const float* m
   mgr_prof_begin(c, MGR_K_GEMM_NN);
   hipLaunchKernelGGL(k_gemm_nn2, grid, dim3(256), 0, mgr_stream(c), X, ldx, mask4_fwd, mask4_rev, Wp_fwd, Wp_rev, bp_fwd, bp_rev,
                      Z_fwd, Z_rev, B, T, F, Nd);
+  MGR_LAUNCH_CHECK();
+  mgr_prof_end(c, MGR_K_GEMM_NN);
+  return 0;
+}
+
+size_t mgr_lstm_input_proj_dropout_ws_bytes(int B, int F) {
+  const size_t Fp = (size_t)(F + SP_SK - 1) / SP_SK * SP_SK;
+  return 2 * mgr_align_up((size_t)4 * B * Fp * sizeof(int), 256) + mgr_align_up((size_t)4 * B * sizeof(int), 256);
+}
+
+int mgr_lstm_input_proj_dropout(mgr_ctx* c, const float* X, int ldx, const float* mask4, float drop_rate, const float* Wp,
+                                const float* bp, float* Z, int B, int T, int F, int H, void* ws, size_t ws_bytes) {
+  MGR_REQUIRE(c && X && Wp && bp && Z, "null argument");
+  MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0 && ldx >= F, "bad shape");
+  // the per-gate K loops pay when enough features are dropped and K is long enough to amortise four pipeline fills
+  const bool sparse = mask4 && drop_rate >= 0.3f && F >= 128 && F <= SP_MAXF && (size_t)T * ldx < (1u << 31) &&
+                      c->tune[9] == 0 && aligned16(bp) && aligned16(Z);
+  if (!sparse) return mgr_lstm_input_proj(c, X, ldx, mask4, Wp, bp, Z, B, T, F, H);
+  MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_input_proj_dropout_ws_bytes(B, F), "workspace too small");
+  const int Fp = (F + SP_SK - 1) / SP_SK * SP_SK;
+  const size_t lbytes = mgr_align_up((size_t)4 * B * Fp * sizeof(int), 256);
+  int* kidx = reinterpret_cast<int*>(ws);
+  float* kval = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + lbytes);
+  int* kcnt = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + 2 * lbytes);
+  hipStream_t s = mgr_stream(c);
+  mgr_prof_begin(c, MGR_K_GEMM_NN);
+  hipLaunchKernelGGL(k_mask_compact, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp, kidx, kval, kcnt);
+  const int ntiles = ((H + SP_TU - 1) / SP_TU) * ((T + SP_TM - 1) / SP_TM) * B;
+  hipLaunchKernelGGL(k_gemm_nn_sparse, dim3(ntiles), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, Wp, bp, Z, B, T, Fp, H);
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_GEMM_NN);
   return 0;

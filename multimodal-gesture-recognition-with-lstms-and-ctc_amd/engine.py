@@ -66,7 +66,7 @@ class _LstmDir:
         self.mask = None       # device [4,B,fin] when input dropout is active
         self.Z = None
         self.gates = self.cs = self.dZ = None
-        self.ws_scan = self.ws_pg = None
+        self.ws_scan = self.ws_pg = self.ws_sp = None
 
 
 class Engine:
@@ -127,6 +127,7 @@ class Engine:
                     L.ws_pg = dev.bytes(self.lib.mgr_lstm_param_grads_ws_bytes(B, T, fin, H))
                 if p > 0:
                     L.mask = dev.empty((4, B, fin))
+                    L.ws_sp = dev.bytes(self.lib.mgr_lstm_input_proj_dropout_ws_bytes(B, fin))   # kept-feature lists
                 L.p = p
                 self.dirs[base] = L
 
@@ -313,6 +314,18 @@ class Engine:
         self.Xin = self._xin_ring[slot]
         dev.stream(stream)
 
+    def _project_pair(self, X, ldx, pair, Ls, B, T, fin, H):
+        """Input projections of the two directions of one Bidirectional layer (pair = [mask, Wp, bp, Z] x 2).  With input
+        dropout active the library runs each direction's K loops over the kept features only (from p >= 0.3 on);
+        otherwise both directions go through one call that fuses them into one GEMM where that saves tiles."""
+        if pair[0] and Ls[0].ws_sp is not None:
+            for d in range(2):
+                m, Wp, bp, Z = pair[4 * d:4 * d + 4]
+                ws = Ls[d].ws_sp
+                self.dev.call("mgr_lstm_input_proj_dropout", X, ldx, m, float(Ls[d].p), Wp, bp, Z, B, T, fin, H, ws, ws.nbytes)
+        else:
+            self.dev.call("mgr_lstm_input_proj_pair", X, ldx, *pair, B, T, fin, H)
+
     def _prep_mask(self, L, train, rand, slot):
         """Returns the device pointer (or 0) of the [4,B,fin] input-dropout mask for this pass."""
         if not train or L.p <= 0:
@@ -395,15 +408,15 @@ class Engine:
                 else:
                     Hp = s["layers"][k - 1]["H"]
                     cur, ldcur, fin = self.Y1[name], 2 * Hp, 2 * Hp
-                pair = []
+                pair, Ls_pair = [], []
                 for di, dname in enumerate(("fwd", "bwd")):
                     L = self.dirs["%s/l%d/%s" % (name, k, dname)]
+                    Ls_pair.append(L)
                     slot += 1   # (every projection GEMM fills the chip: one stream keeps their timings honest)
                     mptr = self._prep_mask(L, train, rand, slot)
                     self._masks[(L.prefix, L.d)] = mptr
                     pair += [mptr, L.Wp, L.bp, self.Zbuf[name][di]]
-                # both directions read the same input: one call (one GEMM where that saves column tiles)
-                dev.call("mgr_lstm_input_proj_pair", cur, ldcur, *pair, B, T, fin, H)
+                self._project_pair(cur, ldcur, pair, Ls_pair, B, T, fin, H)
                 for di, dname in enumerate(("fwd", "bwd")):
                     L = self.dirs["%s/l%d/%s" % (name, k, dname)]
                     Z = self.Zbuf[name][di]
@@ -451,13 +464,14 @@ class Engine:
         if sp.fusion:
             Hf = sp.fusion["H"]
             jobs = []
-            pair = []
+            pair, Ls_pair = [], []
             for di, dname in enumerate(("fwd", "bwd")):
                 L = self.dirs["fusion/%s" % dname]
+                Ls_pair.append(L)
                 mptr = self._prep_mask(L, train, rand, 500 + di)
                 self._masks[(L.prefix, L.d)] = mptr
                 pair += [mptr, L.Wp, L.bp, self.ZF[di]]
-            dev.call("mgr_lstm_input_proj_pair", feat_buf, W, *pair, B, T, W, Hf)
+            self._project_pair(feat_buf, W, pair, Ls_pair, B, T, W, Hf)
             for di, dname in enumerate(("fwd", "bwd")):
                 L = self.dirs["fusion/%s" % dname]
                 jobs.append(dict(Z=self.ZF[di], Up=L.Up, Y=self.YF.view(di * Hf, (1,)), ldy=2 * Hf, R=0, ldr=0,

@@ -431,3 +431,32 @@ def test_input_proj_pair_equals_two_calls(device, B, T, F, H, masked):
             xg = X.astype(np.float64) * (M[d][g][:, None, :] if masked else 1.0)
             ref[:, :, gate == g] = xg @ W[d][:, gate == g].astype(np.float64) + bias[d][gate == g]
         assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("B,T,F,H,p", [(3, 130, 128, 100, 0.5), (2, 300, 1600, 100, 0.5), (2, 257, 1000, 500, 0.5),
+                                       (2, 140, 600, 300, 0.6), (1, 64, 250, 64, 0.4), (2, 100, 131, 20, 0.9),
+                                       (2, 50, 144, 33, 0.0), (2, 64, 160, 40, 1.0)])
+def test_input_proj_dropout_sparse_equals_dense(device, B, T, F, H, p):
+    """mgr_lstm_input_proj_dropout (per-gate K loops over the kept features only) against mgr_lstm_input_proj and numpy fp64:
+    the same sums with the zero terms left out.  Includes all-kept and all-dropped masks and unit counts that do not fill a tile."""
+    dev = device
+    rng = np.random.default_rng(B * 1000 + T + F + H)
+    f32 = np.float32
+    N = 4 * H
+    X = rng.standard_normal((B, T, F)).astype(f32)
+    W = (rng.standard_normal((F, N)) * 0.1).astype(f32)
+    bias = rng.standard_normal(N).astype(f32)
+    scale = 1.0 / (1.0 - p) if p < 1.0 else 1.0
+    M = ((rng.random((4, B, F)) >= p) * scale).astype(f32)
+    dX, dW, db, dM = dev.array(X), dev.array(W), dev.array(bias), dev.array(M)
+    dense, sparse = dev.empty((B, T, N)), dev.empty((B, T, N))
+    dev.call("mgr_lstm_input_proj", dX, F, dM, dW, db, dense, B, T, F, H)
+    ws = dev.bytes(dev.lib.mgr_lstm_input_proj_dropout_ws_bytes(B, F))
+    dev.call("mgr_lstm_input_proj_dropout", dX, F, dM, 0.5, dW, db, sparse, B, T, F, H, ws, ws.nbytes)
+    gate = np.arange(N) % 4
+    ref = np.empty((B, T, N))
+    for g in range(4):
+        ref[:, :, gate == g] = (X.astype(np.float64) * M[g][:, None, :]) @ W[:, gate == g].astype(np.float64) + bias[gate == g]
+    tol = 2e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(sparse.download() - ref).max() <= tol
+    assert np.abs(sparse.download() - dense.download()).max() <= tol
