@@ -100,7 +100,7 @@ int mgr_lstm_input_proj_pair(mgr_ctx* ctx, const float* X, int ldx, const float*
  * over the kept features only (gemm.hip, k_gemm_nn_sparse) - the same sums with the zero terms left out, i.e. equal to
  * mgr_lstm_input_proj up to fp32 summation order.  ws from mgr_lstm_input_proj_dropout_ws_bytes (index lists, rebuilt by
  * every call).  tune key 9 = 1 keeps the dense kernel. */
-size_t mgr_lstm_input_proj_dropout_ws_bytes(int B, int F);
+size_t mgr_lstm_input_proj_dropout_ws_bytes(int B, int F, int H);
 int mgr_lstm_input_proj_dropout(mgr_ctx* ctx, const float* X, int ldx, const float* mask4, float drop_rate,
                                 const float* Wp, const float* bp, float* Z, int B, int T, int F, int H, void* ws,
                                 size_t ws_bytes);

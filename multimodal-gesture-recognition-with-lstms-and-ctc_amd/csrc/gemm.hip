@@ -369,6 +369,19 @@ __global__ __launch_bounds__(64) void k_mask_compact(const float* __restrict__ m
   }
 }
 
+// Wg[g][f][u] = Wp[f][4u + g]: gate-major copy of the packed kernel, so that the row gather of one gate pass reads
+// contiguous units instead of every fourth float (a quarter of the L2 traffic of the B operand); F x 4H floats per call.
+__global__ __launch_bounds__(256) void k_gate_major(const float* __restrict__ Wp, float* __restrict__ Wg, int F, int H) {
+  const size_t n = (size_t)F * H;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float4 w = *reinterpret_cast<const float4*>(Wp + i * 4);   // (f, u): gates 0..3
+    Wg[i] = w.x;
+    Wg[n + i] = w.y;
+    Wg[2 * n + i] = w.z;
+    Wg[3 * n + i] = w.w;
+  }
+}
+
 constexpr int SP_MAXF = 2048;   // feature-count limit of the sparse kernel (index + factor lists of one gate pass live in LDS)
 constexpr int SP_TM = 128, SP_TU = 64, SP_SK = 16;   // tile: 128 rows x 64 units x 4 gates, 16 k per stage
 
@@ -379,7 +392,7 @@ constexpr int SP_TM = 128, SP_TU = 64, SP_SK = 16;   // tile: 128 rows x 64 unit
 __global__ __launch_bounds__(256, 2) void k_gemm_nn_sparse(const float* __restrict__ X, int ldx, const int* __restrict__ kidx,
                                                         const float* __restrict__ kval, const int* __restrict__ kcnt,
                                                         const float* __restrict__ Wp, const float* __restrict__ bp,
-                                                        float* __restrict__ Z, int B, int T, int Fp, int H) {
+                                                        float* __restrict__ Z, int B, int T, int Fp, int F, int H) {
   constexpr int TM = SP_TM, TU = SP_TU, SK = SP_SK;
   constexpr int APT = TM / 16;        // A elements per thread and stage: 16 k x TM rows over 256 threads
   constexpr int BPT = SK * TU / 256;  // B elements per thread and stage
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sparse(const float* __restri
         }
       }
       __syncthreads();
-      const float* Wg = Wp + ucl * 4 + g;
+      const float* Wg = Wp + (size_t)g * F * H + ucl;   // (Wp: the gate-major copy [4][F][H])
       auto fetch = [&](Regs& r, int st) {
         const float* xp = Xb + Ls[st * SK + ak];
 #pragma unroll
@@ -435,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sparse(const float* __restri
 #pragma unroll
         for (int j = 0; j < BPT; ++j) {
           const int q = st * SK + bk + BKS * j;
-          r.w[j] = Wg[(size_t)Ls[q] * N];
+          r.w[j] = Wg[(size_t)Ls[q] * H];
           r.v[j] = Vs[q];
         }
       };
@@ -735,9 +748,10 @@ int mgr_lstm_input_proj_pair(mgr_ctx* c, const float* X, int ldx, const float* m
   return 0;
 }
 
-size_t mgr_lstm_input_proj_dropout_ws_bytes(int B, int F) {
+size_t mgr_lstm_input_proj_dropout_ws_bytes(int B, int F, int H) {
   const size_t Fp = (size_t)(F + SP_SK - 1) / SP_SK * SP_SK;
-  return 2 * mgr_align_up((size_t)4 * B * Fp * sizeof(int), 256) + mgr_align_up((size_t)4 * B * sizeof(int), 256);
+  return 2 * mgr_align_up((size_t)4 * B * Fp * sizeof(int), 256) + mgr_align_up((size_t)4 * B * sizeof(int), 256) +
+         mgr_align_up((size_t)F * 4 * H * sizeof(float), 256);
 }
 
 int mgr_lstm_input_proj_dropout(mgr_ctx* c, const float* X, int ldx, const float* mask4, float drop_rate, const float* Wp,
@@ -746,19 +760,26 @@ int mgr_lstm_input_proj_dropout(mgr_ctx* c, const float* X, int ldx, const float
   MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0 && ldx >= F, "bad shape");
   // the per-gate K loops pay when enough features are dropped and K is long enough to amortise four pipeline fills
   const bool sparse = mask4 && drop_rate >= 0.3f && F >= 128 && F <= SP_MAXF && (size_t)T * ldx < (1u << 31) &&
-                      c->tune[9] == 0 && aligned16(bp) && aligned16(Z);
+                      c->tune[9] == 0 && aligned16(bp) && aligned16(Z) && aligned16(Wp);
   if (!sparse) return mgr_lstm_input_proj(c, X, ldx, mask4, Wp, bp, Z, B, T, F, H);
-  MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_input_proj_dropout_ws_bytes(B, F), "workspace too small");
+  MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_input_proj_dropout_ws_bytes(B, F, H), "workspace too small");
   const int Fp = (F + SP_SK - 1) / SP_SK * SP_SK;
   const size_t lbytes = mgr_align_up((size_t)4 * B * Fp * sizeof(int), 256);
-  int* kidx = reinterpret_cast<int*>(ws);
-  float* kval = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + lbytes);
-  int* kcnt = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + 2 * lbytes);
+  char* w = reinterpret_cast<char*>(ws);
+  int* kidx = reinterpret_cast<int*>(w);
+  float* kval = reinterpret_cast<float*>(w + lbytes);
+  int* kcnt = reinterpret_cast<int*>(w + 2 * lbytes);
+  float* Wg = reinterpret_cast<float*>(w + 2 * lbytes + mgr_align_up((size_t)4 * B * sizeof(int), 256));
   hipStream_t s = mgr_stream(c);
   mgr_prof_begin(c, MGR_K_GEMM_NN);
   hipLaunchKernelGGL(k_mask_compact, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp, kidx, kval, kcnt);
+  {
+    const size_t n = (size_t)F * H;
+    const int wgs = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_gate_major, dim3(wgs), dim3(256), 0, s, Wp, Wg, F, H);
+  }
   const int ntiles = ((H + SP_TU - 1) / SP_TU) * ((T + SP_TM - 1) / SP_TM) * B;
-  hipLaunchKernelGGL(k_gemm_nn_sparse, dim3(ntiles), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, Wp, bp, Z, B, T, Fp, H);
+  hipLaunchKernelGGL(k_gemm_nn_sparse, dim3(ntiles), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H);
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_GEMM_NN);
   return 0;

@@ -127,7 +127,7 @@ class Engine:
                     L.ws_pg = dev.bytes(self.lib.mgr_lstm_param_grads_ws_bytes(B, T, fin, H))
                 if p > 0:
                     L.mask = dev.empty((4, B, fin))
-                    L.ws_sp = dev.bytes(self.lib.mgr_lstm_input_proj_dropout_ws_bytes(B, fin))   # kept-feature lists
+                    L.ws_sp = dev.bytes(self.lib.mgr_lstm_input_proj_dropout_ws_bytes(B, fin, H))   # kept-feature lists
                 L.p = p
                 self.dirs[base] = L
 

@@ -451,7 +451,7 @@ def test_input_proj_dropout_sparse_equals_dense(device, B, T, F, H, p):
     dX, dW, db, dM = dev.array(X), dev.array(W), dev.array(bias), dev.array(M)
     dense, sparse = dev.empty((B, T, N)), dev.empty((B, T, N))
     dev.call("mgr_lstm_input_proj", dX, F, dM, dW, db, dense, B, T, F, H)
-    ws = dev.bytes(dev.lib.mgr_lstm_input_proj_dropout_ws_bytes(B, F))
+    ws = dev.bytes(dev.lib.mgr_lstm_input_proj_dropout_ws_bytes(B, F, H))
     dev.call("mgr_lstm_input_proj_dropout", dX, F, dM, 0.5, dW, db, sparse, B, T, F, H, ws, ws.nbytes)
     gate = np.arange(N) % 4
     ref = np.empty((B, T, N))
