@@ -383,27 +383,31 @@ __global__ __launch_bounds__(256) void k_gate_major(const float* __restrict__ Wp
 }
 
 constexpr int SP_MAXF = 2048;   // feature-count limit of the sparse kernel (index + factor lists of one gate pass live in LDS)
-constexpr int SP_TM = 128, SP_TU = 64, SP_SK = 16;   // tile: 128 rows x 64 units x 4 gates, 16 k per stage
+constexpr int SP_TM = 128, SP_SK = 16;   // tile: 128 rows x (32 WC) units x 4 gates, 16 k per stage
 
 // One workgroup per tile, units fastest (workgroups that hold a CU for the whole kernel were measured: no faster alone -
 // the float4 stores of a tile are 0.1 of 3.3 ms - and they starve the small kernels of the other stream).  Global loads
 // run two stages ahead of the MFMAs (two register sets): a gathered element costs an LDS index read plus a scattered
 // 4-byte global load.
-__global__ __launch_bounds__(256, 2) void k_gemm_nn_sparse(const float* __restrict__ X, int ldx, const int* __restrict__ kidx,
+// WC = waves along the units: 2 (256 threads, 64 units, two workgroups per CU) or 4 (512 threads, 128 units, one per CU:
+// the X tile is shared by twice the units, i.e. half the A-operand traffic per FLOP).
+template <int WC>
+__global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_gemm_nn_sparse(const float* __restrict__ X, int ldx, const int* __restrict__ kidx,
                                                         const float* __restrict__ kval, const int* __restrict__ kcnt,
                                                         const float* __restrict__ Wp, const float* __restrict__ bp,
                                                         float* __restrict__ Z, int B, int T, int Fp, int F, int H) {
-  constexpr int TM = SP_TM, TU = SP_TU, SK = SP_SK;
-  constexpr int APT = TM / 16;        // A elements per thread and stage: 16 k x TM rows over 256 threads
-  constexpr int BPT = SK * TU / 256;  // B elements per thread and stage
-  constexpr int BKS = 256 / TU;       // k rows covered by one pass of the 256 threads over the B stage
+  constexpr int TM = SP_TM, TU = 32 * WC, SK = SP_SK, NT = 128 * WC;
+  constexpr int APT = TM * SK / NT;   // A elements per thread and stage: 16 k x TM rows over NT threads
+  constexpr int ARS = NT / 16;        // rows covered by one pass of the threads over the A stage
+  constexpr int BPT = SK * TU / NT;   // B elements per thread and stage
+  constexpr int BKS = NT / TU;        // k rows covered by one pass of the threads over the B stage
   __shared__ float As[2][SK][TM + 4];
   __shared__ float Bs[2][SK][TU + 4];
   __shared__ int Ls[SP_MAXF];
   __shared__ float Vs[SP_MAXF];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave / WC, wc = wave % WC;
   const int N = 4 * H;
-  const int ak = tid & 15, ar = tid >> 4;   // A staging: this thread's k within the stage, its first row (then +16, +32, ...)
+  const int ak = tid & 15, ar = tid >> 4;   // A staging: this thread's k within the stage, its first row (then +ARS, ...)
   const int bu = tid % TU, bk = tid / TU;   // B staging: this thread's unit, its first k (then +BKS, ...)
   const int l31 = lane & 31, lh = lane >> 5;
   const int ncol = (H + TU - 1) / TU, nrow = (T + TM - 1) / TM;
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sparse(const float* __restri
     int arow[APT];   // row offsets of this thread's A elements (clamped: rows >= T are computed but never stored)
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
-      int row = r0 + ar + 16 * i;
+      int row = r0 + ar + ARS * i;
       arow[i] = (row < T ? row : T - 1) * ldx;   // (one sample's [T, ldx] block stays below 2^31 elements)
     }
 #pragma unroll
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sparse(const float* __restri
       {
         const int* list = kidx + ((size_t)g * B + b) * Fp;
         const float* lval = kval + ((size_t)g * B + b) * Fp;
-        for (int i = tid; i < nst * SK; i += 256) {
+        for (int i = tid; i < nst * SK; i += NT) {
           Ls[i] = list[i];
           Vs[i] = lval[i];
         }
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sparse(const float* __restri
       };
       auto stash = [&](const Regs& r, int buf) {
 #pragma unroll
-        for (int i = 0; i < APT; ++i) As[buf][ak][ar + 16 * i] = r.a[i];
+        for (int i = 0; i < APT; ++i) As[buf][ak][ar + ARS * i] = r.a[i];
 #pragma unroll
         for (int j = 0; j < BPT; ++j) Bs[buf][bk + BKS * j][bu] = r.w[j] * r.v[j];
       };
@@ -778,8 +782,16 @@ int mgr_lstm_input_proj_dropout(mgr_ctx* c, const float* X, int ldx, const float
     const int wgs = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(k_gate_major, dim3(wgs), dim3(256), 0, s, Wp, Wg, F, H);
   }
-  const int ntiles = ((H + SP_TU - 1) / SP_TU) * ((T + SP_TM - 1) / SP_TM) * B;
-  hipLaunchKernelGGL(k_gemm_nn_sparse, dim3(ntiles), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H);
+  // 128-unit tiles (tune key 11 = 2) are faster alone (audio L2 2.77 against 3.03 ms) but slower in the training step
+  // (39.7 against 38.5 ms/step): a 512-thread workgroup needs two free wave slots on all four SIMDs of a CU at once and
+  // gets in the way of the BPTT scan and the small kernels of the other stream
+  const bool wide = c->tune[11] == 2;
+  const int tu = wide ? 128 : 64;
+  const int ntiles = ((H + tu - 1) / tu) * ((T + SP_TM - 1) / SP_TM) * B;
+  if (wide)
+    hipLaunchKernelGGL(k_gemm_nn_sparse<4>, dim3(ntiles), dim3(512), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H);
+  else
+    hipLaunchKernelGGL(k_gemm_nn_sparse<2>, dim3(ntiles), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H);
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_GEMM_NN);
   return 0;
