@@ -178,7 +178,7 @@ def test_random_gemm_shapes(device, case):
     rng = np.random.default_rng(5000 + case)
     f32 = np.float32
     B, T = int(rng.integers(1, 9)), int(rng.integers(1, 300))
-    F, H = int(rng.integers(1, 200)), int(rng.integers(1, 80))
+    F, H = int(rng.integers(1, 200)) if case % 3 else int(rng.integers(128, 700)), int(rng.integers(1, 80)) if case % 2 else int(rng.integers(60, 140))
     N = 4 * H
     ldx = F + int(rng.choice([0, 0, 1, 3, 4, 8]))           # ldx not a multiple of 4 -> the unaligned (scalar) loaders
     use_mask = bool(rng.integers(0, 2))
@@ -214,6 +214,12 @@ def test_random_gemm_shapes(device, case):
     Za2, Zb2 = dev.empty((B, T, N)), dev.empty((B, T, N))
     dev.call("mgr_lstm_input_proj_pair", dX_, ldx, dM, dW_, db_, Za2, dM2, dW2_, db2_, Zb2, B, T, F, H)
     assert np.array_equal(Za2.download(), Z.download()) and np.array_equal(Zb2.download(), Zb.download())
+    # dropout-aware projection (K loops over the kept features; from F = 128 on, the dense kernel below that)
+    if use_mask:
+        Zs = dev.empty((B, T, N))
+        wsd = dev.bytes(dev.lib.mgr_lstm_input_proj_dropout_ws_bytes(B, F, H))
+        dev.call("mgr_lstm_input_proj_dropout", dX_, ldx, dM, 0.4, dW_, db_, Zs, B, T, F, H, wsd, wsd.nbytes)
+        assert rel_err(Zs.download(), Zref) < 2e-5
     # tn (dW, dU, db) with a time-shifted h
     reverse = int(rng.integers(0, 2))
     ldh = H + int(rng.choice([0, 4, 5]))
