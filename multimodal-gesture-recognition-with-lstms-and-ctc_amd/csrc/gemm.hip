@@ -414,9 +414,14 @@ __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_gemm_nn_sparse(co
   struct Regs {
     float a[APT], w[BPT], v[BPT];
   };
+  // Workgroup -> tile, XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the
+  // ncol workgroups that share one (sample, row tile) of X - and read it four times each, once per gate pass - are the ids
+  // x, x + 8, x + 16, ...: they meet in ONE L2 instead of pulling the same rows into all eight.
   {
-    const int tile = blockIdx.x;
-    const int u0 = (tile % ncol) * TU, r0 = ((tile / ncol) % nrow) * TM, b = tile / (ncol * nrow);
+    const int x = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int rt = (jj / ncol) * 8 + x;   // linear (sample, row tile)
+    if (rt >= nrow * B) return;
+    const int u0 = (jj % ncol) * TU, r0 = (rt % nrow) * TM, b = rt / nrow;
     const float* Xb = X + (size_t)b * T * ldx;
     const int ucl = (u0 + bu < H) ? u0 + bu : H - 1;
     f32x16 acc[4][2];
@@ -787,7 +792,7 @@ int mgr_lstm_input_proj_dropout(mgr_ctx* c, const float* X, int ldx, const float
   // gets in the way of the BPTT scan and the small kernels of the other stream
   const bool wide = c->tune[11] == 2;
   const int tu = wide ? 128 : 64;
-  const int ntiles = ((H + tu - 1) / tu) * ((T + SP_TM - 1) / SP_TM) * B;
+  const int ntiles = ((H + tu - 1) / tu) * ((((T + SP_TM - 1) / SP_TM) * B + 7) / 8) * 8;   // (row tiles padded to the 8 XCDs)
   if (wide)
     hipLaunchKernelGGL(k_gemm_nn_sparse<4>, dim3(ntiles), dim3(512), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H);
   else
