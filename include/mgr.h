@@ -168,6 +168,13 @@ size_t mgr_lstm_param_grads_ws_bytes(int B, int T, int F, int H);
 int mgr_lstm_param_grads(mgr_ctx* ctx, const float* X, int ldx, const float* mask4, const float* Hs, int ldh,
                          const float* dZ, float* dWp, float* dUp, float* dbp, int B, int T, int F, int H,
                          int reverse, void* ws, size_t ws_bytes);
+/* The same with Keras input dropout at rate drop_rate on X (mask4 holds the factors): from drop_rate >= 0.3 and F >= 128 on,
+ * dW is computed per (gate, sample) over the rows of the kept features only and gathered in sample order (gemm.hip,
+ * k_gemm_tn_sparse / k_dw_gather); dU and db as in mgr_lstm_param_grads.  Equal to it up to fp32 summation order. */
+size_t mgr_lstm_param_grads_dropout_ws_bytes(int B, int T, int F, int H);
+int mgr_lstm_param_grads_dropout(mgr_ctx* ctx, const float* X, int ldx, const float* mask4, float drop_rate,
+                                 const float* Hs, int ldh, const float* dZ, float* dWp, float* dUp, float* dbp, int B,
+                                 int T, int F, int H, int reverse, void* ws, size_t ws_bytes);
 /* dX[b,t,0:F] (stride lddx) (+)= sum_g mask4[g] (.) (dZ_g . W_g^T); accumulate=1 adds into dX. */
 int mgr_lstm_input_grad(mgr_ctx* ctx, const float* dZ, const float* Wp, const float* mask4, float* dX,
                         int lddx, int accumulate, int B, int T, int F, int H);

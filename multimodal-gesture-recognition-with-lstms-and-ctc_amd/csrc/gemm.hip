@@ -342,7 +342,8 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nn2(const float* __restrict__ X
 // its own accumulators for the same (row, unit) positions, and the epilogue stores the four gates of a unit as one float4
 // in the packed order the scans read.  At p = 0.5 that is half the MFMA work of the dense kernel for the same result.
 __global__ __launch_bounds__(64) void k_mask_compact(const float* __restrict__ mask4, int F, int Fp, int* __restrict__ kidx,
-                                                     float* __restrict__ kval, int* __restrict__ kcnt) {
+                                                     float* __restrict__ kval, int* __restrict__ kcnt,
+                                                     int* __restrict__ kpos /* [4B][F] list position of a kept feature, -1 if dropped; may be null */) {
   const int gb = blockIdx.x, lane = threadIdx.x;
   const float* m = mask4 + (size_t)gb * F;
   int* out = kidx + (size_t)gb * Fp;
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(64) void k_mask_compact(const float* __restrict__ m
         const int pos = n + __popcll(bal & ((1ull << lane) - 1ull));
         out[pos] = f;
         val[pos] = v;
+        if (kpos) kpos[(size_t)gb * F + f] = pass == 0 ? pos : -1;
       }
       n += __popcll(bal);
     }
@@ -601,6 +603,104 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const float* __restrict__ A,
     }
 }
 
+// ------------------------------------------------------------------------------------------------ tn, dropout-aware
+// dW_g[f, u] = sum_b m_g[b, f] * sum_t X[b, t, f] dZ_g[b, t, u]: for a (gate, sample) only the KEPT features have rows.
+// One workgroup takes 128 kept features of one (gate, sample) x 128 units of that gate and runs the dense K loop over
+// t (X columns gathered by index, dZ columns of the gate taken with stride 4); the partial tile goes, scaled by the
+// dropout factor, to P[(gate, sample)][list position][unit].  k_dw_gather then sums, per (feature, unit, gate), the samples
+// that kept the feature, in sample order (deterministic).  Half the MFMA work of the dense kernel at p = 0.5.
+// grid: 8 * ceil(B/8) * 4 * ceil(Fp/128) * ceil(H/128) workgroups, decoded below
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_sparse(const float* __restrict__ X, int ldx, const int* __restrict__ kidx,
+                                                        const float* __restrict__ kval, const int* __restrict__ kcnt,
+                                                        const float* __restrict__ dZ, float* __restrict__ P, int B, int T, int Fp,
+                                                        int H) {
+  __shared__ __attribute__((aligned(16))) float As2[NBUF][BK][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs2[NBUF][BK][LDS_LD];
+  __shared__ float rowf[BM];
+  static_assert(NBUF == 2 && BK == 16, "staging below assumes two LDS buffers of 16 k");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  // XCD-aware decode (consecutive workgroup ids go round-robin over the 8 XCDs): all workgroups of a sample - which share
+  // its X rows and dZ columns - get ids congruent mod 8, i.e. one L2
+  const int nft = (Fp + BM - 1) / BM, nut = (H + BN - 1) / BN, wps = 4 * nft * nut;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int b = (jj / wps) * 8 + xcd;
+  if (b >= B) return;
+  const int w = jj % wps, g = w / (nft * nut), gb = g * B + b;
+  const int q0 = ((w / nut) % nft) * BM, u0 = (w % nut) * BN;
+  const int cnt = kcnt[gb];
+  if (q0 >= cnt) return;   // (uniform) no kept feature in this row tile
+  const int N = 4 * H;
+  const int m = tid & 127, kb = tid >> 7;   // staging: this thread's row (feature) / column (unit) and first k (then +2, ...)
+  const int q = q0 + m < Fp ? q0 + m : Fp - 1;
+  const float* xcol = X + (size_t)b * T * ldx + kidx[(size_t)gb * Fp + q];
+  const int un = u0 + m < H ? u0 + m : H - 1;
+  const float* zcol = dZ + (size_t)b * T * N + 4 * un + g;
+  if (tid < BM) rowf[tid] = (q0 + tid < cnt) ? kval[(size_t)gb * Fp + q0 + tid] : 0.f;
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  float ra[8], rb[8];
+  auto fetch = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int t = t0 + kb + 2 * i;
+      const bool ok = t < T;
+      t = ok ? t : T - 1;
+      const float a = xcol[(size_t)t * ldx], z = zcol[(size_t)t * N];
+      ra[i] = ok ? a : 0.f;
+      rb[i] = ok ? z : 0.f;
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      As2[buf][kb + 2 * i][m] = ra[i];
+      Bs2[buf][kb + 2 * i][m] = rb[i];
+    }
+  };
+  const int nst = (T + BK - 1) / BK;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (int st = 0; st < nst; ++st) {
+    const bool more = st + 1 < nst;
+    if (more) fetch((st + 1) * BK);
+    mma_stage(As2[buf], Bs2[buf], acc, wr, wc, lane);
+    if (more) stash(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  float* out = P + (size_t)gb * Fp * H;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int u = u0 + ACC_COL(wc, nt, lane);
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = ACC_ROW(wr, mt, reg, lane);
+        if (q0 + r < cnt && u < H) out[(size_t)(q0 + r) * H + u] = acc[mt][nt][reg] * rowf[r];
+      }
+    }
+}
+
+// dWp[f][4u+g] = sum over the samples that kept feature f for gate g, in sample order
+__global__ __launch_bounds__(256) void k_dw_gather(const float* __restrict__ P, const int* __restrict__ kpos, float* __restrict__ dWp,
+                                                   int B, int F, int Fp, int H) {
+  const size_t n = (size_t)4 * F * H;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int u = (int)(i % H);
+    const int f = (int)((i / H) % F);
+    const int g = (int)(i / ((size_t)H * F));
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const int pos = kpos[((size_t)g * B + b) * F + f];
+      if (pos >= 0) s += P[(((size_t)g * B + b) * Fp + pos) * H + u];
+    }
+    dWp[(size_t)f * 4 * H + 4 * u + g] = s;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ nt
 // dX[b,r,f] (+)= sum_j dZ[b,r,j] * Wp[f,j] * mask4[j&3,b,f];  grid: (ceil(F/128), ceil(T/128), B)
 __global__ __launch_bounds__(256, 2) void k_gemm_nt(const float* __restrict__ dZ, const float* __restrict__ Wp,
@@ -781,7 +881,7 @@ int mgr_lstm_input_proj_dropout(mgr_ctx* c, const float* X, int ldx, const float
   float* Wg = reinterpret_cast<float*>(w + 2 * lbytes + mgr_align_up((size_t)4 * B * sizeof(int), 256));
   hipStream_t s = mgr_stream(c);
   mgr_prof_begin(c, MGR_K_GEMM_NN);
-  hipLaunchKernelGGL(k_mask_compact, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp, kidx, kval, kcnt);
+  hipLaunchKernelGGL(k_mask_compact, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp, kidx, kval, kcnt, (int*)nullptr);
   {
     const size_t n = (size_t)F * H;
     const int wgs = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
@@ -810,13 +910,8 @@ size_t mgr_lstm_param_grads_ws_bytes(int B, int T, int F, int H) {
   return a + b + d;
 }
 
-int mgr_lstm_param_grads(mgr_ctx* c, const float* X, int ldx, const float* mask4, const float* Hs, int ldh,
-                         const float* dZ, float* dWp, float* dUp, float* dbp, int B, int T, int F, int H, int reverse,
-                         void* ws, size_t ws_bytes) {
-  MGR_REQUIRE(c && X && Hs && dZ && dWp && dUp && dbp, "null argument");
-  MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0 && ldx >= F && ldh >= H, "bad shape");
-  MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_param_grads_ws_bytes(B, T, F, H), "workspace too small");
-  MGR_REQUIRE(aligned16(dZ), "dZ must be 16-byte aligned");
+static int param_grads_impl(mgr_ctx* c, const float* X, int ldx, const float* mask4, const float* Hs, int ldh, const float* dZ,
+                            float* dWp, float* dUp, float* dbp, int B, int T, int F, int H, int reverse, void* ws, bool with_dW) {
   int N = 4 * H;
   int sgW = tn_groups(B, F, N), sgU = tn_groups(B, H, N);
   char* w = reinterpret_cast<char*>(ws);
@@ -826,8 +921,7 @@ int mgr_lstm_param_grads(mgr_ctx* c, const float* X, int ldx, const float* mask4
   w += mgr_align_up((size_t)sgU * H * N * sizeof(float), 256);
   float* slabB = reinterpret_cast<float*>(w);
   hipStream_t s = mgr_stream(c);
-  mgr_prof_begin(c, MGR_K_GEMM_TN);
-  {
+  if (with_dW) {
     int vecA = (ldx % 4 == 0) && (F % 4 == 0) && aligned16(X);
     dim3 grid((N + BN - 1) / BN, (F + BM - 1) / BM, sgW);
     hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, s, X, ldx, 0, mask4, dZ, slabW, B, T, F, N, sgW, vecA);
@@ -850,6 +944,62 @@ int mgr_lstm_param_grads(mgr_ctx* c, const float* X, int ldx, const float* mask4
     hipLaunchKernelGGL(k_colsum, dim3(nwg), dim3(256), 0, s, dZ, slabB, rows, N, rpw);
     hipLaunchKernelGGL(k_reduce, dim3((N + 255) / 256), dim3(256), 0, s, slabB, dbp, (size_t)N, nwg);
   }
+  return 0;
+}
+
+int mgr_lstm_param_grads(mgr_ctx* c, const float* X, int ldx, const float* mask4, const float* Hs, int ldh,
+                         const float* dZ, float* dWp, float* dUp, float* dbp, int B, int T, int F, int H, int reverse,
+                         void* ws, size_t ws_bytes) {
+  MGR_REQUIRE(c && X && Hs && dZ && dWp && dUp && dbp, "null argument");
+  MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0 && ldx >= F && ldh >= H, "bad shape");
+  MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_param_grads_ws_bytes(B, T, F, H), "workspace too small");
+  MGR_REQUIRE(aligned16(dZ), "dZ must be 16-byte aligned");
+  mgr_prof_begin(c, MGR_K_GEMM_TN);
+  param_grads_impl(c, X, ldx, mask4, Hs, ldh, dZ, dWp, dUp, dbp, B, T, F, H, reverse, ws, true);
+  MGR_LAUNCH_CHECK();
+  mgr_prof_end(c, MGR_K_GEMM_TN);
+  return 0;
+}
+
+static size_t pg_dropout_extra(int B, int F, int H) {
+  const size_t Fp = (size_t)(F + SP_SK - 1) / SP_SK * SP_SK;
+  return 2 * mgr_align_up((size_t)4 * B * Fp * sizeof(int), 256) + mgr_align_up((size_t)4 * B * sizeof(int), 256) +
+         mgr_align_up((size_t)4 * B * F * sizeof(int), 256) + mgr_align_up((size_t)4 * B * Fp * H * sizeof(float), 256);
+}
+
+size_t mgr_lstm_param_grads_dropout_ws_bytes(int B, int T, int F, int H) {
+  return mgr_lstm_param_grads_ws_bytes(B, T, F, H) + pg_dropout_extra(B, F, H);
+}
+
+int mgr_lstm_param_grads_dropout(mgr_ctx* c, const float* X, int ldx, const float* mask4, float drop_rate, const float* Hs,
+                                 int ldh, const float* dZ, float* dWp, float* dUp, float* dbp, int B, int T, int F, int H,
+                                 int reverse, void* ws, size_t ws_bytes) {
+  MGR_REQUIRE(c && X && Hs && dZ && dWp && dUp && dbp, "null argument");
+  MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0 && ldx >= F && ldh >= H, "bad shape");
+  MGR_REQUIRE(aligned16(dZ), "dZ must be 16-byte aligned");
+  const bool sparse = mask4 && drop_rate >= 0.3f && F >= 128 && c->tune[9] == 0;
+  MGR_REQUIRE(ws && ws_bytes >= (sparse ? mgr_lstm_param_grads_dropout_ws_bytes(B, T, F, H) : mgr_lstm_param_grads_ws_bytes(B, T, F, H)),
+              "workspace too small");
+  mgr_prof_begin(c, MGR_K_GEMM_TN);
+  if (sparse) {
+    const int Fp = (F + SP_SK - 1) / SP_SK * SP_SK;
+    const size_t lbytes = mgr_align_up((size_t)4 * B * Fp * sizeof(int), 256);
+    char* w = reinterpret_cast<char*>(ws) + mgr_lstm_param_grads_ws_bytes(B, T, F, H);
+    int* kidx = reinterpret_cast<int*>(w);
+    float* kval = reinterpret_cast<float*>(w + lbytes);
+    int* kcnt = reinterpret_cast<int*>(w + 2 * lbytes);
+    w += 2 * lbytes + mgr_align_up((size_t)4 * B * sizeof(int), 256);
+    int* kpos = reinterpret_cast<int*>(w);
+    w += mgr_align_up((size_t)4 * B * F * sizeof(int), 256);
+    float* P = reinterpret_cast<float*>(w);
+    hipStream_t s = mgr_stream(c);
+    hipLaunchKernelGGL(k_mask_compact, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp, kidx, kval, kcnt, kpos);
+    const int grid = 8 * ((B + 7) / 8) * 4 * ((Fp + BM - 1) / BM) * ((H + BN - 1) / BN);
+    hipLaunchKernelGGL(k_gemm_tn_sparse, dim3(grid), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, dZ, P, B, T, Fp, H);
+    const size_t n = (size_t)4 * F * H;
+    hipLaunchKernelGGL(k_dw_gather, dim3((int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, P, kpos, dWp, B, F, Fp, H);
+  }
+  param_grads_impl(c, X, ldx, mask4, Hs, ldh, dZ, dWp, dUp, dbp, B, T, F, H, reverse, ws, !sparse);
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_GEMM_TN);
   return 0;

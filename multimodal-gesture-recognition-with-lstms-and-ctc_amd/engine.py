@@ -124,7 +124,8 @@ class Engine:
                     L.cs = dev.empty((B, T, H))
                     L.dZ = dev.empty((B, T, 4 * H))
                     L.ws_scan = dev.bytes(self.lib.mgr_lstm_scan_ws_bytes(B, T, H))
-                    L.ws_pg = dev.bytes(self.lib.mgr_lstm_param_grads_ws_bytes(B, T, fin, H))
+                    L.ws_pg = dev.bytes(self.lib.mgr_lstm_param_grads_dropout_ws_bytes(B, T, fin, H) if p > 0
+                                        else self.lib.mgr_lstm_param_grads_ws_bytes(B, T, fin, H))
                 if p > 0:
                     L.mask = dev.empty((4, B, fin))
                     L.ws_sp = dev.bytes(self.lib.mgr_lstm_input_proj_dropout_ws_bytes(B, fin, H))   # kept-feature lists
@@ -768,8 +769,12 @@ class Engine:
                 L = self.dirs["%s/%s" % (prefix, dname)]
                 H = L.H
                 mptr = self._masks.get((L.prefix, L.d), 0)
-                dev.call("mgr_lstm_param_grads", Xin, ldx, mptr, Hbuf.view(di * H, (1,)), ldh, L.dZ, L.gWp, L.gUp,
-                         L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes)
+                if mptr:   # input dropout was applied: dW only has rows for the kept features of each (gate, sample)
+                    dev.call("mgr_lstm_param_grads_dropout", Xin, ldx, mptr, float(L.p), Hbuf.view(di * H, (1,)), ldh, L.dZ,
+                             L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes)
+                else:
+                    dev.call("mgr_lstm_param_grads", Xin, ldx, mptr, Hbuf.view(di * H, (1,)), ldh, L.dZ, L.gWp, L.gUp,
+                             L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes)
         if not defer_param_grads:
             param_grads()
         if dX is not None:

@@ -460,3 +460,39 @@ def test_input_proj_dropout_sparse_equals_dense(device, B, T, F, H, p):
     tol = 2e-5 * max(1.0, np.abs(ref).max())
     assert np.abs(sparse.download() - ref).max() <= tol
     assert np.abs(sparse.download() - dense.download()).max() <= tol
+
+
+@pytest.mark.parametrize("B,T,F,H,p,reverse", [(3, 130, 128, 100, 0.5, 0), (2, 300, 1600, 100, 0.5, 1), (2, 77, 1000, 130, 0.5, 0),
+                                               (2, 140, 600, 300, 0.6, 1), (2, 100, 131, 20, 0.9, 0), (2, 50, 144, 33, 0.0, 1),
+                                               (2, 64, 160, 40, 1.0, 0)])
+def test_param_grads_dropout_sparse_equals_dense(device, B, T, F, H, p, reverse):
+    """mgr_lstm_param_grads_dropout (dW rows of the kept features only, per (gate, sample), gathered in sample order) against
+    mgr_lstm_param_grads and numpy fp64; dU and db are the shared path."""
+    dev = device
+    rng = np.random.default_rng(B * 977 + T + F + H)
+    f32 = np.float32
+    N = 4 * H
+    X = rng.standard_normal((B, T, F)).astype(f32)
+    Hs = rng.standard_normal((B, T, H)).astype(f32)
+    dZ = (rng.standard_normal((B, T, N)) * 0.3).astype(f32)
+    scale = 1.0 / (1.0 - p) if p < 1.0 else 1.0
+    M = ((rng.random((4, B, F)) >= p) * scale).astype(f32)
+    dX, dH, ddZ, dM = dev.array(X), dev.array(Hs), dev.array(dZ), dev.array(M)
+    outs = []
+    for sparse in (False, True):
+        gW, gU, gb = dev.empty((F, N)), dev.empty((H, N)), dev.empty((N,))
+        if sparse:
+            ws = dev.bytes(dev.lib.mgr_lstm_param_grads_dropout_ws_bytes(B, T, F, H))
+            dev.call("mgr_lstm_param_grads_dropout", dX, F, dM, 0.5, dH, H, ddZ, gW, gU, gb, B, T, F, H, reverse, ws, ws.nbytes)
+        else:
+            ws = dev.bytes(dev.lib.mgr_lstm_param_grads_ws_bytes(B, T, F, H))
+            dev.call("mgr_lstm_param_grads", dX, F, dM, dH, H, ddZ, gW, gU, gb, B, T, F, H, reverse, ws, ws.nbytes)
+        outs.append((gW.download(), gU.download(), gb.download()))
+    gate = np.arange(N) % 4
+    ref = np.empty((F, N))
+    for g in range(4):
+        ref[:, gate == g] = np.einsum("btf,btn->fn", X.astype(np.float64) * M[g][:, None, :], dZ[:, :, gate == g].astype(np.float64))
+    tol = 3e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(outs[1][0] - ref).max() <= tol
+    assert np.abs(outs[1][0] - outs[0][0]).max() <= tol
+    assert np.array_equal(outs[1][1], outs[0][1]) and np.array_equal(outs[1][2], outs[0][2])
