@@ -96,7 +96,7 @@ int mgr_lstm_input_proj_pair(mgr_ctx* ctx, const float* X, int ldx, const float*
                              const float* bp_fwd, float* Z_fwd, const float* mask4_rev, const float* Wp_rev,
                              const float* bp_rev, float* Z_rev, int B, int T, int F, int H);
 /* The same projection for a layer with Keras input dropout at rate drop_rate (the rate only selects the kernel; mask4
- * holds the actual factors, 0 or 1/(1-p)): from drop_rate >= 0.3 on (and 128 <= F <= 2048) the K loop runs per gate
+ * holds the actual factors, 0 or 1/(1-p)): from drop_rate >= 0.3 on (and 16 <= F <= 2048) the K loop runs per gate
  * over the kept features only (gemm.hip, k_gemm_nn_sparse) - the same sums with the zero terms left out, i.e. equal to
  * mgr_lstm_input_proj up to fp32 summation order.  ws from mgr_lstm_input_proj_dropout_ws_bytes (index lists, rebuilt by
  * every call).  tune key 9 = 1 keeps the dense kernel. */

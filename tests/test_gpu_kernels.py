@@ -435,7 +435,7 @@ def test_input_proj_pair_equals_two_calls(device, B, T, F, H, masked):
 
 @pytest.mark.parametrize("B,T,F,H,p", [(3, 130, 128, 100, 0.5), (2, 300, 1600, 100, 0.5), (2, 257, 1000, 500, 0.5),
                                        (2, 140, 600, 300, 0.6), (1, 64, 250, 64, 0.4), (2, 100, 131, 20, 0.9),
-                                       (2, 50, 144, 33, 0.0), (2, 64, 160, 40, 1.0)])
+                                       (2, 50, 144, 33, 0.0), (2, 64, 160, 40, 1.0), (3, 200, 39, 500, 0.4), (2, 129, 20, 300, 0.6), (2, 40, 16, 8, 0.5)])
 def test_input_proj_dropout_sparse_equals_dense(device, B, T, F, H, p):
     """mgr_lstm_input_proj_dropout (per-gate K loops over the kept features only) against mgr_lstm_input_proj and numpy fp64:
     the same sums with the zero terms left out.  Includes all-kept and all-dropped masks and unit counts that do not fill a tile."""
