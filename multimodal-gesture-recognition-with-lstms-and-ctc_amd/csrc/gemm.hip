@@ -982,6 +982,9 @@ int mgr_lstm_param_grads_dropout(mgr_ctx* c, const float* X, int ldx, const floa
   MGR_REQUIRE(ws && ws_bytes >= (sparse ? mgr_lstm_param_grads_dropout_ws_bytes(B, T, F, H) : mgr_lstm_param_grads_ws_bytes(B, T, F, H)),
               "workspace too small");
   mgr_prof_begin(c, MGR_K_GEMM_TN);
+  // dU / db first: they are short, and in the training step the long dW kernel then ends this direction's work (the step
+  // runs these under an encoder scan; what is left over after the scan is exposed)
+  param_grads_impl(c, X, ldx, mask4, Hs, ldh, dZ, dWp, dUp, dbp, B, T, F, H, reverse, ws, !sparse);
   if (sparse) {
     const int Fp = (F + SP_SK - 1) / SP_SK * SP_SK;
     const size_t lbytes = mgr_align_up((size_t)4 * B * Fp * sizeof(int), 256);
@@ -1000,7 +1003,6 @@ int mgr_lstm_param_grads_dropout(mgr_ctx* c, const float* X, int ldx, const floa
     const size_t n = (size_t)4 * F * H;
     hipLaunchKernelGGL(k_dw_gather, dim3((int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, P, kpos, dWp, B, F, Fp, H);
   }
-  param_grads_impl(c, X, ldx, mask4, Hs, ldh, dZ, dWp, dUp, dbp, B, T, F, H, reverse, ws, !sparse);
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_GEMM_TN);
   return 0;
