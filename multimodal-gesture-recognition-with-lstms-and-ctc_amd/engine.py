@@ -174,6 +174,8 @@ class Engine:
         self._prefetched_for = None
         self.defer_param_grads = os.environ.get("MGR_DEFER_TN", "1") != "0"
         self.defer_delay_us = int(os.environ.get("MGR_DEFER_DELAY_US", "150"))
+        self.EV_FPROJ = 45
+        self.es_runs_ahead = os.environ.get("MGR_ES_AHEAD", "1") != "0"
         # opt-in experiment (measured slower): start the next step's depth-1 scan before this step's fusion layer
         self.early_encoders = os.environ.get("MGR_EARLY_ENC", "0") == "1"
         self._masks = {}
@@ -473,6 +475,7 @@ class Engine:
                 self._masks[(L.prefix, L.d)] = mptr
                 pair += [mptr, L.Wp, L.bp, self.ZF[di]]
             self._project_pair(feat_buf, W, pair, Ls_pair, B, T, W, Hf)
+            dev.record(self.EV_FPROJ)   # (the next step's depth-1 scan is launched after these GEMMs, see enqueue_train_step)
             for di, dname in enumerate(("fwd", "bwd")):
                 L = self.dirs["fusion/%s" % dname]
                 jobs.append(dict(Z=self.ZF[di], Up=L.Up, Y=self.YF.view(di * Hf, (1,)), ldy=2 * Hf, R=0, ldr=0,
@@ -636,7 +639,10 @@ class Engine:
         EV_PREV = 40
         if pipelined:
             # the other FEAT buffer was last read by the previous step's fusion phase (its dW GEMMs, queued on stream 0)
-            if early:
+            # (not in a call that ran its own encoder pass in line on stream 0: that pass uses the encoder buffers)
+            ahead = (self.es_runs_ahead and have is not None and sp.fusion is not None and self.defer_param_grads
+                     and depth >= 2)
+            if early or ahead:
                 dev.stream(0)
                 dev.record(EV_PREV)   # only the launch that WRITES that buffer (the deepest scan) has to wait for it
             else:
@@ -742,7 +748,23 @@ class Engine:
                 # the dW/dU GEMMs of THIS step and the optimizer are held back until the next step's deepest projection
                 # GEMMs are done and then run beside its deepest encoder scan: GEMM next to GEMM gains nothing, whereas a
                 # big scan leaves most of the MFMA issue slots free (tools/overlap_probe.py: scan x1.12, GEMM at 1/3 speed)
-                self._enqueue_encoders(True, None, nxt, ES, self.rng_step, before_last_scan=under_last_scan)
+                if ahead:
+                    # the encoder stream does not wait for this stream's previous step as a whole: its depth-1 projections
+                    # start as soon as its own previous pass is done (beside the small kernels that end that step), the
+                    # depth-1 scan is launched after this step's fusion projections (a persistent launch placed among
+                    # chip-filling GEMMs gets a poor CU set), and only the deepest scan - the one that overwrites the FEAT
+                    # buffer the previous step's dW GEMMs read - waits for that step
+                    for tag, k in self._encoder_phases(True, None, nxt, ES, self.rng_step):
+                        if tag != "projected":
+                            continue
+                        if k == 0:
+                            dev.stream(ES)
+                            dev.wait_event(ES, self.EV_FPROJ)
+                        if k == depth - 1:
+                            under_last_scan()
+                            dev.wait_event(ES, EV_PREV)
+                else:
+                    self._enqueue_encoders(True, None, nxt, ES, self.rng_step, before_last_scan=under_last_scan)
             self._prefetched = nxt
             dev.stream(0)
 
