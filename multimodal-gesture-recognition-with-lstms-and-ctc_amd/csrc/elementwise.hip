@@ -79,14 +79,17 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
   }
 }
 
-// one block per 32 columns; 8 row-groups reduce through LDS
-__global__ void k_maxnorm(float* __restrict__ W, int rows, int cols, float maxv, float eps) {
-  __shared__ float part[8][32];
+// one block per 32 columns; 32 row-groups (1024 threads) reduce through LDS: the matrix is small (1600 x 400 for the fusion
+// layer), the kernel sits on the critical chain between the optimizer and the next step's projections and runs beside
+// chip-filling GEMMs there, so what counts is the length of each thread's dependent load chain
+constexpr int MN_RG = 32;
+__global__ __launch_bounds__(32 * MN_RG) void k_maxnorm(float* __restrict__ W, int rows, int cols, float maxv, float eps) {
+  __shared__ float part[MN_RG][32];
   int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   int c = blockIdx.x * 32 + tx;
   float s = 0.f;
   if (c < cols)
-    for (int r = ty; r < rows; r += 8) {
+    for (int r = ty; r < rows; r += MN_RG) {
       float w = W[(size_t)r * cols + c];
       s += w * w;
     }
@@ -94,14 +97,14 @@ __global__ void k_maxnorm(float* __restrict__ W, int rows, int cols, float maxv,
   __syncthreads();
   if (ty == 0) {
     float t = 0.f;
-    for (int k = 0; k < 8; ++k) t += part[k][tx];
+    for (int k = 0; k < MN_RG; ++k) t += part[k][tx];
     float nrm = sqrtf(t);
     part[0][tx] = fminf(fmaxf(nrm, 0.f), maxv) / (eps + nrm);
   }
   __syncthreads();
   float sc = part[0][tx];
   if (c < cols)
-    for (int r = ty; r < rows; r += 8) W[(size_t)r * cols + c] *= sc;
+    for (int r = ty; r < rows; r += MN_RG) W[(size_t)r * cols + c] *= sc;
 }
 
 __global__ void k_add2d(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb, float* __restrict__ O,
@@ -238,7 +241,7 @@ int mgr_adam_step(mgr_ctx* c, float* p, const float* g, float* m, float* v, size
 int mgr_maxnorm_cols(mgr_ctx* c, float* W, int rows, int cols, float maxv, float eps) {
   MGR_REQUIRE(c && W, "null argument");
   MGR_REQUIRE(rows > 0 && cols > 0, "bad shape");
-  hipLaunchKernelGGL(k_maxnorm, dim3((cols + 31) / 32), dim3(kBlock), 0, mgr_stream(c), W, rows, cols, maxv, eps);
+  hipLaunchKernelGGL(k_maxnorm, dim3((cols + 31) / 32), dim3(32 * MN_RG), 0, mgr_stream(c), W, rows, cols, maxv, eps);
   MGR_LAUNCH_CHECK();
   return 0;
 }
