@@ -787,15 +787,49 @@ __global__ void k_reduce(const float* __restrict__ slab, float* __restrict__ out
   }
 }
 
-// column sums of dZ [rows, N] -> slab[wg][N]; each WG takes a contiguous row range, thread per column (coalesced)
+// column sums of dZ [rows, N] -> slab[wg][N]; each WG takes a contiguous row range; thread = (four columns, row lane):
+// float4 loads, two row lanes summed through LDS (N = 4H is a multiple of 4)
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dZ, float* __restrict__ slab, size_t rows, int N,
                                                 int rows_per_wg) {
-  size_t rbeg = (size_t)blockIdx.x * rows_per_wg;
-  size_t rend = rbeg + rows_per_wg < rows ? rbeg + rows_per_wg : rows;
-  for (int n = threadIdx.x; n < N; n += 256) {
-    float s = 0.f;
-    for (size_t r = rbeg; r < rend; ++r) s += dZ[r * N + n];
-    slab[(size_t)blockIdx.x * N + n] = s;
+  __shared__ float4 part[128];
+  const size_t rbeg = (size_t)blockIdx.x * rows_per_wg;
+  const size_t rend = rbeg + rows_per_wg < rows ? rbeg + rows_per_wg : rows;
+  const int cl = threadIdx.x & 127, ry = threadIdx.x >> 7, N4 = N / 4;
+  for (int c0 = 0; c0 < N4; c0 += 128) {
+    const int c4 = c0 + cl;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < N4)
+      for (size_t r = rbeg + ry; r < rend; r += 2) {
+        const float4 v = *reinterpret_cast<const float4*>(dZ + r * N + 4 * c4);
+        s.x += v.x;
+        s.y += v.y;
+        s.z += v.z;
+        s.w += v.w;
+      }
+    if (ry == 1) part[cl] = s;
+    __syncthreads();
+    if (ry == 0 && c4 < N4) {
+      const float4 o = part[cl];
+      *reinterpret_cast<float4*>(slab + (size_t)blockIdx.x * N + 4 * c4) = make_float4(s.x + o.x, s.y + o.y, s.z + o.z, s.w + o.w);
+    }
+    __syncthreads();
+  }
+}
+
+// out[i] = sum_k slab[k][i] for MANY slabs of a SHORT vector (the bias gradient: hundreds of row-block partial sums of 4H
+// numbers): 8 slab lanes per element, summed through LDS in a fixed order
+__global__ __launch_bounds__(256) void k_reduce_tall(const float* __restrict__ slab, float* __restrict__ out, int n, int nslab) {
+  __shared__ float part[8][32];
+  const int e = blockIdx.x * 32 + (threadIdx.x & 31), kl = threadIdx.x >> 5;
+  float s = 0.f;
+  if (e < n)
+    for (int k = kl; k < nslab; k += 8) s += slab[(size_t)k * n + e];
+  part[kl][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (kl == 0 && e < n) {
+    float t = 0.f;
+    for (int k = 0; k < 8; ++k) t += part[k][threadIdx.x & 31];
+    out[e] = t;
   }
 }
 
@@ -943,7 +977,7 @@ static int param_grads_impl(mgr_ctx* c, const float* X, int ldx, const float* ma
     int rpw = (int)((rows + nwg - 1) / nwg);
     nwg = (int)((rows + rpw - 1) / rpw);
     hipLaunchKernelGGL(k_colsum, dim3(nwg), dim3(256), 0, s, dZ, slabB, rows, N, rpw);
-    hipLaunchKernelGGL(k_reduce, dim3((N + 255) / 256), dim3(256), 0, s, slabB, dbp, (size_t)N, nwg);
+    hipLaunchKernelGGL(k_reduce_tall, dim3((N + 31) / 32), dim3(256), 0, s, slabB, dbp, N, nwg);
   }
   return 0;
 }
