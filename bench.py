@@ -10,6 +10,11 @@ One JSON line on rank 0.  Inputs are synthetic and resident in HBM before the ti
 full training step (frozen encoders fwd, fusion BiLSTM fwd/bwd, CTC, Adam) with device-side noise/dropout
 RNG and one loss read-back, exactly K of them between barrier+sync pairs; value = all ranks' frames / max time.
 The multi-process rendezvous (RCCL unique id) is a plain TCP exchange on MASTER_ADDR:MASTER_PORT+101; torch is not imported.
+
+    python bench.py --gpus 2 --comm host      # world > 1 WITHOUT RCCL: gradients are summed on the host (parallel.HostComm);
+                                              # ranks may then share one GPU (per-rank batch is divided so that every rank's
+                                              # persistent scans stay co-resident) - a functional check of the data-parallel
+                                              # step on a 1-GPU box, not a scaling measurement
 """
 import argparse
 import json
@@ -76,10 +81,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--show-plan", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the next step's frozen-encoder pass")
-    ap.add_argument("--scan-path", type=int, default=0, help="0 auto, 3/4 clusters of 4/8 tiles, 5 paired batch groups")
+    ap.add_argument("--scan-path", type=int, default=0, help="0 auto, 3/4 clusters of 4/8 tiles per workgroup")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-T", type=int, default=400)
     ap.add_argument("--cpu-B", type=int, default=64)
+    ap.add_argument("--comm", choices=("rccl", "host"), default="rccl",
+                    help="gradient all-reduce: RCCL over xGMI (one GPU per rank) or summed on the host (ranks may share a GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,35 +105,37 @@ def main():
     from mgr_amd.parallel import RcclComm
     from mgr_amd.synthetic import synthetic_arrays, synthetic_weights
 
+    from mgr_amd.parallel import HostComm
     spec, B, T, Lmax = baseline_config(args.config)
     if args.batch:
         B = args.batch
     if args.maxlen:
         T = args.maxlen
-    # (MGR_DEVICE_OVERRIDE: debugging aid to run several ranks on one GPU where the communication library permits it)
-    dev = _capi.Device(int(os.environ.get("MGR_DEVICE_OVERRIDE", local_rank)))
+    ndev = _capi.device_count()
+    share = 1
+    if world > ndev:
+        # more ranks than GPUs: only the host communicator can do that (RCCL refuses two ranks on one device).  Each rank's
+        # persistent scans must be co-resident with the other ranks' on the shared GPU, so the per-rank batch is divided.
+        if args.comm != "host":
+            raise SystemExit("bench.py: %d ranks on %d GPU(s) needs --comm host" % (world, ndev))
+        share = (world + ndev - 1) // ndev
+        if not args.batch:
+            B = max(16, B // share)
+    dev = _capi.Device(local_rank % max(1, ndev))
     if args.show_plan:
         dev.call("mgr_tune", 2, 1)
     if args.scan_path:
         dev.call("mgr_tune", 0, args.scan_path)
-    if os.environ.get("MGR_BWD_SPLIT") in ("0", "2"):   # experiment hook: 0 = always the 4-wave BPTT cluster kernel, 2 = always split roles
-        dev.call("mgr_tune", 8, 1 if os.environ["MGR_BWD_SPLIT"] == "0" else 2)
-    if os.environ.get("MGR_GATHER_DELAY"):
-        dev.call("mgr_tune", 6, int(os.environ["MGR_GATHER_DELAY"]))
-    if os.environ.get("MGR_SCAN_CFG"):   # experiment hook: "<cfg for H>=400>:<cfg for H<400>", 1-based indices into kCfgs
-        a, b = os.environ["MGR_SCAN_CFG"].split(":")
-        dev.call("mgr_tune", 4, int(a))
-        dev.call("mgr_tune", 5, int(b))
 
     comm = None
-    if world == 1 and os.environ.get("MGR_FORCE_COMM"):
-        # debugging aid: a 1-rank RCCL communicator, so that the all-reduce / barrier code path runs on a single GPU
-        comm = RcclComm(dev, 0, 1, lambda uid: uid)
     if world > 1:
-        # rendezvous over the launcher's MASTER_ADDR / MASTER_PORT (+101); importing torch here would pull the wheel's own
-        # HIP / HSA / RCCL copies into the process next to the ROCm installation's
-        from mgr_amd.parallel import tcp_bootstrap
-        comm = RcclComm(dev, rank, world, tcp_bootstrap(rank, world))
+        if args.comm == "host":
+            comm = HostComm(dev, rank, world)
+        else:
+            # rendezvous over the launcher's MASTER_ADDR / MASTER_PORT (+101); importing torch here would pull the wheel's
+            # own HIP / HSA / RCCL copies into the process next to the ROCm installation's
+            from mgr_amd.parallel import tcp_bootstrap
+            comm = RcclComm(dev, rank, world, tcp_bootstrap(rank, world))
 
     eng = Engine(spec, B, T, Lmax, device=dev, seed=1000 + rank, comm=comm, world=world)
     eng.set_weights(synthetic_weights(spec, 20131900 + 3))
@@ -188,17 +197,22 @@ def main():
             fl = flops_family[dom] * B * T * args.steps
             ach = fl / (fam[dom]["ms"] * 1e-3) / 1e12
             # HBM bytes per launch of that family from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-            # their own runs, tools/profile_round.sh + summarize_profile.py); null when no such pass is on file
+            # their own runs, tools/profile_round.sh + summarize_profile.py) - only if that pass was taken on THIS tree
+            # (hash of the device sources + engine schedule); null otherwise
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if args.config == "F" and os.path.exists(tpath):
+            if args.config == "F" and world == 1 and os.path.exists(tpath):
+                from mgr_amd._build import source_hash
                 with open(tpath) as fh:
-                    traffic = json.load(fh).get("bytes_per_launch", {}).get(dom)
-                traffic = round(traffic) if traffic else None
+                    rec = json.load(fh)
+                if rec.get("src_sha") == source_hash():
+                    traffic = rec.get("bytes_per_launch", {}).get(dom)
+                    traffic = round(traffic) if traffic else None
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 5), "traffic": traffic,
                     "avg_launch_ms": round(fam[dom]["ms"] / max(1, fam[dom]["launches"]), 4)}
-        whole = spec.flops_per_frame() * value / 1e12
+        whole = spec.flops_per_frame() * value / 1e12                    # algorithmic (dense) FLOP of SURVEY 8(d)
+        whole_ex = spec.flops_per_frame(executed=True) * value / 1e12     # what the dropout-aware kernels really multiply
         # ---- parity: same weights / batch / injected randomness on a short-T slice vs the fp64 oracle ----
         parity = None
         if not args.no_parity and world == 1:
@@ -216,9 +230,13 @@ def main():
                "config": {"workload": "BASELINE configs[2]: multimodal_fusion fusion BiLSTM+CTC train step "
                                       "(frozen audio 2xBiLSTM(500)+skeletal 2xBiLSTM(300), fusion BiLSTM(100), Dense 22, CTC)"
                           if args.config == "F" else args.config,
-                          "per_gpu_batch": B, "global_batch": B * world, "maxlen": T, "parallelism": "dp%d" % world},
-               "roofline": roof, "cpu_baseline": cpu, "whole_step_tflops": round(whole, 3),
-               "whole_step_frac_of_mfma_peak": round(whole / MFMA_F32_PEAK_TFLOPS, 5),
+                          "per_gpu_batch": B, "global_batch": B * world, "maxlen": T, "parallelism": "dp%d" % world,
+                          "comm": (args.comm if world > 1 else None), "ranks_per_gpu": share},
+               "roofline": roof, "cpu_baseline": cpu,
+               "whole_step_tflops_algorithmic": round(whole, 3),
+               "whole_step_frac_of_mfma_peak_algorithmic": round(whole / MFMA_F32_PEAK_TFLOPS, 5),
+               "whole_step_tflops_executed": round(whole_ex, 3),
+               "whole_step_frac_of_mfma_peak_executed": round(whole_ex / MFMA_F32_PEAK_TFLOPS, 5),
                "loss": losses[-1], "ctc_loss_parity": parity, "kernel_ms": fam,
                "speedup_vs_cpu": round(value / cpu["value"], 1) if cpu else None}
         print(json.dumps(out))

@@ -130,20 +130,33 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
 /* Tuning / test hooks.  key 0 (MGR_TUNE_SCAN_PATH): 0 auto, 1 force the L2-streaming fallback kernels,
  * 2 force one workgroup per batch group (no inter-CU exchange) where it fits, 3 force clusters with 4 tiles per
  * workgroup, 4 same with 8 tiles per workgroup.  key 1: !=0 makes scan_fwd check the give-up word synchronously.
- * key 2: print the scan plan.  key 3: opt into the XCD-local exchange path (measured slower; kept for study).
- * key 7: 1 = one-tile-per-wave clusters keep the LDS-image step instead of the K-split / register-direct gather step.
- * key 8: 1 = the multi-CU BPTT keeps its 4-wave kernel instead of the split-role (4 compute + 4 gather waves) one.
+ * key 2: print the scan plan.
+ * key 7: one-tile-per-wave clusters: 0 = K-split / register-direct gather step, 1 = LDS-image step, 2 = K-split step with
+ *        hidden units in identity order (cross-check of the kernel's private unit permutation).
+ * key 8: 1 = the multi-CU BPTT keeps its 4-wave kernel instead of the split-role (4 compute + 4 gather waves) one, 2 = always split.
  * key 9: 1 = mgr_lstm_input_proj_dropout always takes the dense kernel. */
 enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 12 };
 int mgr_tune(mgr_ctx* ctx, int key, int value);
-/* Fails (and reports through mgr_last_error) if any persistent multi-CU scan launched on this context ever gave up on a
- * bounded spin (a deadlocked or lost peer): such a launch returns promptly but its outputs are garbage.  Ordered on the
- * current stream; cheap (one 4-byte read back) - call it where results are consumed, e.g. with the loss. */
+/* Health of the persistent multi-CU scans launched on this context since the last mgr_scan_status_clear: *out receives the OR
+ * of their status bits.  MGR_SCAN_GAVE_UP: a bounded spin expired (a dead-locked or lost peer) - the launch returned promptly
+ * but its outputs are garbage; the call FAILS (mgr_last_error).  MGR_SCAN_NONFINITE: a hidden state became NaN / Inf (diverged
+ * weights, bad checkpoint); the outputs carry NaN from that step on exactly as the reference's would, the call succeeds.
+ * Ordered on the current stream; cheap (one 4-byte read back) - call it where results are consumed, e.g. with the loss. */
+enum { MGR_SCAN_GAVE_UP = 1, MGR_SCAN_NONFINITE = 8 };
 int mgr_scan_status(mgr_ctx* ctx, unsigned* out);
+/* Forget the recorded status bits (enqueued on the current stream), e.g. after restoring a good checkpoint. */
+int mgr_scan_status_clear(mgr_ctx* ctx);
+/* Placement aid (never a correctness dependency): the current stream waits, on the device, until every workgroup of the NEXT
+ * persistent scan launched on this context (on any stream) has started, or timeout_us (<= 100000) has passed.  Chip-filling
+ * GEMMs enqueued behind it therefore arrive when the scan is resident instead of racing its workgroups for the CUs. */
+int mgr_stream_wait_next_resident(mgr_ctx* ctx, int timeout_us);
+/* Persistent launches on different streams are admitted against the chip's workgroup slots; one that would not fit beside the
+ * launches still in flight is ordered behind them (co-residency by construction).  Counters: launches so far, and how many of
+ * them had to be serialised that way. */
+int mgr_persist_stats(mgr_ctx* ctx, int* launches, int* serialised);
 /* Diagnostic: out[b] = XCC (XCD) id the workgroup b of a (nblocks, threads, lds_bytes) launch ran on. */
 int mgr_probe_xcc(mgr_ctx* ctx, int nblocks, int threads, int lds_bytes, int32_t* out);
-/* Hold the current stream for ~us microseconds on the device (bounded; 0 <= us <= 100000).  Scheduling aid: lets a
- * persistent multi-CU scan launched on another stream become resident before this stream's chip-filling GEMMs start. */
+/* Diagnostic (tools/overlap_probe.py): hold the current stream for ~us microseconds on the device (bounded; 0 <= us <= 100000). */
 int mgr_stream_delay(mgr_ctx* ctx, int us);
 /* BPTT: dY[b,t,0:H] (row stride lddy) is dLoss/dh_t from above; Y (stride ldy) is the layer's own output as
  * written by scan_fwd WITHOUT residual (needed only through gates/cs here).  Produces dZ [B,T,4H] packed. */

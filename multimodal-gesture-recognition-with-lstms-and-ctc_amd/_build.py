@@ -23,6 +23,20 @@ def _hipcc():
     raise RuntimeError("hipcc not found; cannot build libmgr.so")
 
 
+def source_hash():
+    """sha256 over the device sources, the C ABI header and the engine's schedule: profiles/pmc_traffic.json records it, and
+    bench.py reports the profiled HBM traffic only for the tree it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files += [os.path.join(HERE, "..", "include", "mgr.h"), os.path.join(HERE, "engine.py")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
@@ -50,7 +64,9 @@ def build(force=False, verbose=True, jobs=4):
         hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
         hdrs.append(os.path.join(HERE, "..", "include", "mgr.h"))
         newest = max(os.path.getmtime(p) for p in [src] + hdrs)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > newest:
+        asm_ok = s not in ISA_CHECKED or any(f.startswith(s.replace(".hip", "") + "-hip-amdgcn") and f.endswith(".s")
+                                             for f in os.listdir(objdir))
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > newest and asm_ok:
             continue
         cmd = [hipcc] + flags + ["-c", src, "-o", obj]
         if s in ISA_CHECKED:
@@ -81,7 +97,7 @@ def build(force=False, verbose=True, jobs=4):
     return LIB
 
 
-ISA_CHECKED = {"lstm_cluster.hip": ["k_scan_cluster_ks"]}
+ISA_CHECKED = {"lstm_cluster.hip": ["k_scan_cluster_ks", "k_scan_cluster_ks_id"]}
 
 
 def _regs(tok):
@@ -101,16 +117,15 @@ def check_hidden_loads(objdir):
     experimental BPTT variant: the workgroup then spins until its bounded give-up).  This check reads the device assembly
     kept by --save-temps and fails the build if any move / spill instruction reads those registers."""
     import re
-    if os.environ.get("MGR_SKIP_ISA_CHECK"):   # diagnostic builds only (extra code may legitimately copy the registers)
-        return
     for src, kernels in ISA_CHECKED.items():
         stem = src.replace(".hip", "")
         cands = [f for f in os.listdir(objdir) if f.startswith(stem + "-hip-amdgcn") and f.endswith(".s")]
         if not cands:
-            continue   # the object was up to date and no assembly of this build exists: nothing new to check
+            raise RuntimeError("ISA check: no device assembly of %s in %s (build() keeps it with --save-temps=obj); the "
+                               "register-polling scan step must not ship unchecked" % (src, objdir))
         text = open(os.path.join(objdir, cands[0])).read().split("\n")
         for kname in kernels:
-            start = next((i for i, l in enumerate(text) if re.match(r"^_Z\w*%s\w*:" % kname, l)), None)
+            start = next((i for i, l in enumerate(text) if re.match(r"^_Z\w*\d%sE\w*:" % kname, l)), None)
             if start is None:
                 raise RuntimeError("ISA check: kernel %s not found in %s" % (kname, cands[0]))
             end = next(i for i in range(start, len(text)) if "s_endpgm" in text[i])

@@ -56,6 +56,9 @@ SIGNATURES = {
     "mgr_host_free": (i32, [vp, vp]),
     "mgr_h2d_async": (i32, [vp, vp, vp, sz]),
     "mgr_scan_status": (i32, [vp, vp]),
+    "mgr_scan_status_clear": (i32, [vp]),
+    "mgr_stream_wait_next_resident": (i32, [vp, i32]),
+    "mgr_persist_stats": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
     "mgr_skeletal_features": (i32, [vp, vp, sz, vp]),
     "mgr_lstm_scan_bwd_multi_ws_bytes": (sz, [i32, vp]),
     "mgr_lstm_scan_bwd_multi": (i32, [vp, i32, vp, vp, sz]),
@@ -83,6 +86,8 @@ SIGNATURES = {
     "mgr_ctc_beam_ws_bytes": (sz, [i32, i32, i32, i32]),
     "mgr_ctc_beam_search": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_float, i32, vp, vp, vp, vp, sz]),
 }
+
+SCAN_GAVE_UP, SCAN_NONFINITE = 1, 8   # enum in include/mgr.h (mgr_scan_status)
 
 (K_GEMM_NN, K_GEMM_TN, K_GEMM_NT, K_SCAN_FWD, K_SCAN_BWD, K_DENSE_FWD, K_DENSE_BWD, K_CTC, K_ADAM, K_MISC) = range(10)
 KERNEL_FAMILIES = ["gemm_nn", "gemm_tn", "gemm_nt", "scan_fwd", "scan_bwd", "dense_fwd", "dense_bwd", "ctc", "adam", "misc"]

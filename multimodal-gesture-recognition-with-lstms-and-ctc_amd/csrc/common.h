@@ -8,6 +8,8 @@
 
 #include "../../include/mgr.h"
 
+constexpr int MGR_MAX_PERSIST = 8;
+
 struct mgr_ctx {
   int device;
   int cu_count;
@@ -29,7 +31,16 @@ struct mgr_ctx {
   float prof_ms[MGR_K_COUNT];
   int prof_launches[MGR_K_COUNT];
   int tune[MGR_TUNE_COUNT];
-  unsigned* sticky_status;  // device word: give-up code of any persistent scan launch since the last mgr_scan_status
+  unsigned* sticky_status;  // device words: [0] status bits of every persistent launch since the last clear, [1] resident seq
+  // persistent launches that may still be running (lstm.hip: mgr_persist_admit / mgr_persist_commit)
+  struct Persist {
+    hipEvent_t done;
+    int active, stream, wgs, waves, per_cu;
+    unsigned seq;
+  };
+  Persist persist[MGR_MAX_PERSIST];
+  unsigned persist_seq;     // sequence number of the last persistent launch of this context
+  int persist_serialised;   // launches that had to be ordered behind another stream's persistent launch
   unsigned attr_done;       // bit k: function attributes of kernel family k have been set on this context's device
 };
 

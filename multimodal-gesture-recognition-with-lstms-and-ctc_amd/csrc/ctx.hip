@@ -57,6 +57,8 @@ int mgr_ctx_destroy(mgr_ctx* c) {
   for (int i = 0; i < MGR_NUM_EVENTS; ++i) hipEventDestroy(c->events[i]);
   for (int i = 0; i < 64; ++i) hipEventDestroy(c->xev[i]);
   if (c->sticky_status) hipFree(c->sticky_status);
+  for (int i = 0; i < MGR_MAX_PERSIST; ++i)
+    if (c->persist[i].done) hipEventDestroy(c->persist[i].done);
   for (int f = 0; f < MGR_K_COUNT; ++f) {
     for (int i = 0; i < c->prof_cap[f]; ++i) {
       hipEventDestroy(c->prof_pairs[f][i].a);
@@ -175,7 +177,15 @@ int mgr_scan_status(mgr_ctx* c, unsigned* out) {
   // on the CURRENT stream: the caller decides what it is ordered after
   MGR_HIP(hipMemcpyAsync(out, c->sticky_status, sizeof(unsigned), hipMemcpyDeviceToHost, mgr_stream(c)));
   MGR_HIP(hipStreamSynchronize(mgr_stream(c)));
-  MGR_REQUIRE(*out == 0, "a persistent scan gave up on a bounded spin (code %u): its outputs are invalid", *out);
+  // MGR_SCAN_NONFINITE alone is not an error of the library: the outputs carry the NaN, like the reference's would
+  MGR_REQUIRE((*out & ~(unsigned)MGR_SCAN_NONFINITE) == 0,
+              "a persistent scan gave up on a bounded spin (code %u): its outputs are invalid", *out);
+  return 0;
+}
+
+int mgr_scan_status_clear(mgr_ctx* c) {
+  MGR_REQUIRE(c, "null ctx");
+  MGR_HIP(hipMemsetAsync(c->sticky_status, 0, sizeof(unsigned), mgr_stream(c)));
   return 0;
 }
 

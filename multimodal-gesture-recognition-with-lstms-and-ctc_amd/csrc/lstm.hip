@@ -14,16 +14,14 @@ int mgr_scan_bwd_mfma(mgr_ctx*, const float*, int, const float*, const float*, c
 
 namespace {
 
-constexpr size_t kScanHdrBytes = 8192;  // [0,2048): status + stamps; [2048,8192): XCC id per workgroup of the launch
-
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 struct Cfg {
-  int nw, tpw, pair;
+  int nw, tpw;
 };
-// candidate (active waves, tiles per wave, batch groups per workgroup) configurations
-constexpr int NCFG = 5;
-const Cfg kCfgs[NCFG] = {{4, 1, 1}, {8, 1, 1}, {8, 2, 1}, {8, 4, 1}, {4, 1, 2}};
+// candidate (active waves, tiles per wave) configurations
+constexpr int NCFG = 4;
+const Cfg kCfgs[NCFG] = {{4, 1}, {8, 1}, {8, 2}, {8, 4}};
 
 struct Plan {
   bool cluster[MGR_MAX_SCAN_JOBS];
@@ -37,7 +35,7 @@ size_t job_ws(const mgr_scan_job& j) {
   int ks = j.H / 4;
   size_t img = (size_t)((ks + 3) / 4) * 256;
   int nbg = (j.B + 15) / 16;
-  return mgr_align_up((size_t)nbg * 2 * img * sizeof(float), 256) + mgr_align_up((size_t)nbg * 64 * sizeof(unsigned), 256);
+  return mgr_align_up((size_t)nbg * 2 * img * sizeof(float), 256);
 }
 
 // Choose per-job configurations: minimise the slowest job's per-step MFMA time subject to all workgroups
@@ -54,7 +52,6 @@ void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
     if (ok) {
       ok = false;
       for (int k = 0; k < NCFG; ++k) ok = ok || mgr_cluster_supported(ks, kCfgs[k].tpw);
-      ok = ok || mgr_cluster_pair_supported(ks);
     }
     if (path == 1) ok = false;
     P.cluster[i] = ok;
@@ -68,39 +65,30 @@ void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
   for (int code = 0; code < combos; ++code) {
     int x = code, total = 0;
     long worst = 0, sum = 0;
-    bool feas = true, exch = false, anypair = false;
+    bool feas = true, exch = false;
     for (int k = 0; k < n; ++k) {
       cur[k] = x % NCFG;
       x /= NCFG;
       const mgr_scan_job& j = jobs[idx[k]];
       Cfg f = kCfgs[cur[k]];
       int ks = j.H / 4;
-      if (f.pair == 2 ? !mgr_cluster_pair_supported(ks) : !mgr_cluster_supported(ks, f.tpw)) feas = false;
+      if (!mgr_cluster_supported(ks, f.tpw)) feas = false;
       if (path == 3 && cur[k] != 0) feas = false;
       if (path == 4 && cur[k] != 1) feas = false;
-      if (path == 5 && cur[k] != 4) feas = false;
-      {  // experiment hooks: tune keys 4 / 5 force the configuration index (+1) of jobs with H >= 400 / H < 400
-        int forced = j.H >= 400 ? c->tune[4] : c->tune[5];
-        if (forced > 0 && cur[k] != forced - 1) feas = false;
-      }
-      if (path != 5 && f.pair == 2) feas = false;  // measured slower than one group per workgroup: opt-in only
       if (path == 2 && (f.nw * f.tpw < ks)) feas = false;  // force single-CU (no exchange)
       int tiles = f.nw * f.tpw;
       int G = (ks + tiles - 1) / tiles;
       if (G > 64) feas = false;
       if (G > 1) exch = true;
       int nbg = (j.B + 15) / 16;
-      if (f.pair == 2 && (G == 1 || nbg < 2)) feas = false;  // pairing only pays when there is a hand-off to hide
       // (classes of jobs are laid out on workgroup ranges rounded up to a multiple of 8 - the XCD count - at launch; count
       // every job rounded up so that a plan accepted here always passes the launcher's co-residency check)
-      total += (G * ((nbg + f.pair - 1) / f.pair) + 7) / 8 * 8;
-      if (f.pair == 2) anypair = true;
+      total += (G * nbg + 7) / 8 * 8;
       // per-step estimate in cycles: MFMA chain per SIMD (+15% issue overhead) + cell update + exchange / barrier
       int tiles_here = std::min(tiles, ks);
       int per_simd = (tiles_here + 3) / 4;
       long t = (long)per_simd * ks * 37 + 700 + (G > 1 ? 3300 : 400);
-      if (f.pair == 2) t = 2 * ((long)ks * 37 + 700 + 500);  // two groups back to back, hand-off hidden
-      if (total > c->cu_count && f.pair == 1) t += (long)per_simd * ks * 12;  // a second workgroup on the CU competes for the MFMA pipe part of the time
+      if (total > c->cu_count) t += (long)per_simd * ks * 12;  // a second workgroup on the CU competes for the MFMA pipe part of the time
       worst = std::max(worst, t);
       sum += t;
     }
@@ -111,14 +99,8 @@ void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
       if (kCfgs[cur[k]].nw != 4) all4 = false;
       maxks = std::max(maxks, jobs[idx[k]].H / 4);
     }
-    size_t lds2 = (size_t)(anypair ? 4 : 2) * ((maxks + 3) / 4) * 1024;
+    size_t lds2 = (size_t)2 * ((maxks + 3) / 4) * 1024;
     int capacity = (all4 && lds2 <= 80 * 1024) ? 2 * c->cu_count : c->cu_count;
-    // the paired kernel is its own launch configuration (4 waves, one workgroup per CU): all jobs or none
-    bool allpair = true;
-    for (int k = 0; k < n; ++k)
-      if (kCfgs[cur[k]].pair != 2) allpair = false;
-    if (anypair && !allpair) feas = false;
-    if (anypair) capacity = c->cu_count;
     if (!feas || (exch && total > capacity)) continue;
     long cost = worst * 1000 + sum / n;
     if (best_cost < 0 || cost < best_cost) {
@@ -136,7 +118,7 @@ void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
     int tiles = P.cfg[i].nw * P.cfg[i].tpw;
     P.G[i] = (jobs[i].H / 4 + tiles - 1) / tiles;
     P.nbg[i] = (jobs[i].B + 15) / 16;
-    P.wgs[i] = P.G[i] * ((P.nbg[i] + P.cfg[i].pair - 1) / P.cfg[i].pair);
+    P.wgs[i] = P.G[i] * P.nbg[i];
     P.total += P.wgs[i];
     if (P.G[i] > 1) P.exchange = true;
   }
@@ -144,6 +126,51 @@ void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
 }
 
 }  // namespace
+
+// Lay the cluster jobs of one launch out on workgroup ranges: jobs with identical geometry (the two directions of a layer)
+// form a class that shares one contiguous range, every class starts on a multiple of 8 (the XCD round-robin).
+template <class SameFn, class SizeFn>
+static int layout_classes(int njobs, const bool* use, SameFn same, SizeFn G_of, const int* nbg, int* cls_begin_of, int* cls_clusters_of,
+                          int* cls_cluster0_of) {
+  int cls_of[MGR_MAX_SCAN_JOBS], ncls = 0, cls_first[MGR_MAX_SCAN_JOBS], cls_clusters[MGR_MAX_SCAN_JOBS];
+  for (int i = 0; i < njobs; ++i) {
+    if (!use[i]) continue;
+    int found = -1;
+    for (int k = 0; k < ncls; ++k)
+      if (same(cls_first[k], i)) found = k;
+    if (found < 0) {
+      found = ncls++;
+      cls_first[found] = i;
+      cls_clusters[found] = 0;
+    }
+    cls_of[i] = found;
+    cls_clusters[found] += nbg[i];
+  }
+  int cls_begin[MGR_MAX_SCAN_JOBS], cls_next[MGR_MAX_SCAN_JOBS], begin = 0;
+  for (int k = 0; k < ncls; ++k) {
+    begin = (begin + 7) / 8 * 8;
+    cls_begin[k] = begin;
+    cls_next[k] = 0;
+    begin += G_of(cls_first[k]) * cls_clusters[k];
+  }
+  for (int i = 0; i < njobs; ++i) {
+    if (!use[i]) continue;
+    const int k = cls_of[i];
+    cls_begin_of[i] = cls_begin[k];
+    cls_clusters_of[i] = cls_clusters[k];
+    cls_cluster0_of[i] = cls_next[k];
+    cls_next[k] += nbg[i];
+  }
+  return begin;   // grid size
+}
+
+static int check_launch_status(mgr_ctx* c, unsigned* status, const char* what) {
+  unsigned st = 0;   // tune key 1: synchronous give-up check (tests)
+  MGR_HIP(hipMemcpyAsync(&st, status, sizeof(st), hipMemcpyDeviceToHost, mgr_stream(c)));
+  MGR_HIP(hipStreamSynchronize(mgr_stream(c)));
+  MGR_REQUIRE(st == 0, "%s: a bounded spin gave up (status %u)", what, st);
+  return 0;
+}
 
 extern "C" {
 
@@ -181,7 +208,7 @@ size_t mgr_lstm_scan_ws_bytes(int B, int T, int H) {
 }
 
 size_t mgr_lstm_scan_multi_ws_bytes(int njobs, const mgr_scan_job* jobs) {
-  size_t s = kScanHdrBytes;  // status word + diagnostic stamps + XCC table
+  size_t s = kScanHdrBytes;
   for (int i = 0; i < njobs; ++i) s += job_ws(jobs[i]);
   return s;
 }
@@ -210,43 +237,12 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     char* w = reinterpret_cast<char*>(ws);
     status = reinterpret_cast<unsigned*>(w);
     char* base = w;
-    L.xcc = reinterpret_cast<unsigned*>(w + 2048);
     w += kScanHdrBytes;
-    // classes: cluster jobs with identical geometry (same H and configuration, e.g. the two directions of a layer) share
-    // one XCD-interleaved workgroup range
-    int cls_of[MGR_MAX_SCAN_JOBS], ncls = 0, cls_first[MGR_MAX_SCAN_JOBS], cls_clusters[MGR_MAX_SCAN_JOBS];
-    for (int i = 0; i < njobs; ++i) {
-      if (!P.cluster[i]) continue;
-      int found = -1;
-      for (int k = 0; k < ncls; ++k) {
-        int f = cls_first[k];
-        if (jobs[f].H == jobs[i].H && P.cfg[f].nw == P.cfg[i].nw && P.cfg[f].tpw == P.cfg[i].tpw &&
-            P.cfg[f].pair == P.cfg[i].pair)
-          found = k;
-      }
-      if (found < 0) {
-        found = ncls++;
-        cls_first[found] = i;
-        cls_clusters[found] = 0;
-      }
-      cls_of[i] = found;
-      cls_clusters[found] += P.nbg[i];
-    }
-    int cls_begin[MGR_MAX_SCAN_JOBS], begin = 0, cls_next[MGR_MAX_SCAN_JOBS];
-    for (int k = 0; k < ncls; ++k) {
-      begin = (begin + 7) / 8 * 8;  // keep every class aligned to the 8-XCD round-robin
-      cls_begin[k] = begin;
-      cls_next[k] = 0;
-      int f = cls_first[k];
-      int per = cls_clusters[k];
-      if (P.cfg[f].pair == 2) {  // pair mode maps job-major: every member job rounds its own batch groups up to pairs
-        per = 0;
-        for (int i = 0; i < njobs; ++i)
-          if (P.cluster[i] && cls_of[i] == k) per += (P.nbg[i] + 1) / 2;
-      }
-      begin += P.G[f] * per;
-    }
-    P.total = begin;
+    int cb[MGR_MAX_SCAN_JOBS], cn[MGR_MAX_SCAN_JOBS], c0[MGR_MAX_SCAN_JOBS];
+    P.total = layout_classes(
+        njobs, P.cluster,
+        [&](int a, int b) { return jobs[a].H == jobs[b].H && P.cfg[a].nw == P.cfg[b].nw && P.cfg[a].tpw == P.cfg[b].tpw; },
+        [&](int a) { return P.G[a]; }, P.nbg, cb, cn, c0);
     for (int i = 0; i < njobs; ++i) {
       if (!P.cluster[i]) continue;
       const mgr_scan_job& j = jobs[i];
@@ -255,38 +251,33 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
       size_t img = (size_t)((ks + 3) / 4) * 256;
       cj.Z = j.Z; cj.Up = j.Up; cj.Y = j.Y; cj.R = j.R; cj.G = j.gates; cj.Cs = j.cs;
       cj.ldy = j.ldy; cj.ldr = j.ldr; cj.B = j.B; cj.T = j.T; cj.H = j.H; cj.reverse = j.reverse;
-      cj.ks = ks; cj.tpw = P.cfg[i].tpw; cj.nw = P.cfg[i].nw; cj.pair = P.cfg[i].pair;
+      cj.ks = ks; cj.tpw = P.cfg[i].tpw; cj.nw = P.cfg[i].nw;
       cj.G_ = P.G[i]; cj.nbg = P.nbg[i];
-      const int k = cls_of[i];
-      cj.cls_begin = cls_begin[k];
-      cj.cls_nclusters = cls_clusters[k];
-      cj.cls_cluster0 = cls_next[k];
-      cj.wg_begin = cls_begin[k];  // (pair mode maps job-major inside its class range)
-      if (cj.pair == 2) {
-        cj.wg_begin = cls_begin[k] + P.G[i] * cls_next[k];
-        cls_next[k] += (P.nbg[i] + 1) / 2;
-      } else {
-        cls_next[k] += P.nbg[i];
-      }
-      cj.flags = reinterpret_cast<unsigned*>(w);
-      w += mgr_align_up((size_t)P.nbg[i] * 64 * sizeof(unsigned), 256);
+      cj.cls_begin = cb[i]; cj.cls_nclusters = cn[i]; cj.cls_cluster0 = c0[i];
       cj.xbuf = reinterpret_cast<float*>(w);
       w += mgr_align_up((size_t)P.nbg[i] * 2 * img * sizeof(float), 256);
     }
-    L.status = status;
-    L.sticky = c->sticky_status;
-    L.xcd_local = c->tune[3];
-    L.gather_delay = c->tune[6];
-    L.ksplit = c->tune[7] == 0;   // tune key 7: 1 = keep the LDS-image step for one-tile-per-wave clusters
+    // tune key 7: 0 = K-split step (register-direct gather, permuted unit order), 1 = LDS-image step for every cluster,
+    // 2 = K-split step with the identity unit order
+    L.ksplit = c->tune[7] == 0 ? 1 : (c->tune[7] == 2 ? 2 : 0);
     if (c->tune[2]) {  // tune key 2: print the plan
       for (int i = 0; i < L.njobs; ++i)
-        fprintf(stderr, "[mgr scan plan] job %d: H=%d ks=%d nw=%d tpw=%d pair=%d G=%d nbg=%d wg_begin=%d\n", i, L.job[i].H,
-                L.job[i].ks, L.job[i].nw, L.job[i].tpw, L.job[i].pair, L.job[i].G_, L.job[i].nbg, L.job[i].wg_begin);
+        fprintf(stderr, "[mgr scan plan] job %d: H=%d ks=%d nw=%d tpw=%d G=%d nbg=%d wg_begin=%d\n", i, L.job[i].H,
+                L.job[i].ks, L.job[i].nw, L.job[i].tpw, L.job[i].G_, L.job[i].nbg, L.job[i].cls_begin);
       fprintf(stderr, "[mgr scan plan] total %d workgroups, exchange=%d\n", P.total, (int)P.exchange);
     }
-    // flags + status must be zero at every launch (epochs count from 1 within the call)
+    int waves, per_cu;
+    mgr_cluster_geometry(L, P.exchange, &waves, &per_cu);
+    L.cm.status = status;
+    L.cm.sticky = c->sticky_status;
+    L.cm.total_wgs = P.total;
+    r = mgr_persist_admit(c, P.total, waves, per_cu, &L.cm.seq);
+    if (r) return r;
+    // exchange slots + status must be zero at every launch (epochs count from 1 within the call)
     MGR_HIP(hipMemsetAsync(base, 0, (size_t)(w - base), mgr_stream(c)));
     r = mgr_cluster_launch(c, L, P.total, P.exchange);
+    if (r) return r;
+    r = mgr_persist_commit(c, P.total, waves, per_cu);
     if (r) return r;
   }
   for (int i = 0; i < njobs; ++i) {
@@ -297,12 +288,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
   }
   r = mgr_prof_end(c, MGR_K_SCAN_FWD);
   if (r) return r;
-  if (status && c->tune[1]) {  // tune key 1: synchronous status check (tests)
-    unsigned st = 0;
-    MGR_HIP(hipMemcpyAsync(&st, status, sizeof(st), hipMemcpyDeviceToHost, mgr_stream(c)));
-    MGR_HIP(hipStreamSynchronize(mgr_stream(c)));
-    MGR_REQUIRE(st == 0, "cluster scan: a bounded spin gave up (status %u)", st);
-  }
+  if (status && c->tune[1]) return check_launch_status(c, status, "cluster scan");
   return 0;
 }
 
@@ -332,17 +318,14 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
   w += kScanHdrBytes;
   ClusterBwdLaunch L;
   memset(&L, 0, sizeof(L));
-  L.status = status;
-  L.sticky = c->sticky_status;
-  L.xcc = reinterpret_cast<unsigned*>(base + 2048);
-  L.xcd_local = c->tune[3];
-  int total = 0;
+  int total = 0, nbg[MGR_MAX_SCAN_JOBS];
   bool use_cluster[MGR_MAX_SCAN_JOBS];
   // cluster kernel when instantiated and the whole launch is co-resident (two 4-wave workgroups per CU)
   for (int i = 0; i < njobs; ++i) {
     const mgr_scan_bwd_job& j = jobs[i];
+    nbg[i] = (j.B + 15) / 16;
     use_cluster[i] = (path == 0 || path == 3) && mgr_cluster_bwd_supported(j.H);
-    if (use_cluster[i]) total += ((j.H + 15) / 16) * ((j.B + 15) / 16);
+    if (use_cluster[i]) total += ((j.H + 15) / 16) * nbg[i];
   }
   if (total + 8 * njobs > 2 * c->cu_count)
     for (int i = 0; i < njobs; ++i) use_cluster[i] = false;
@@ -351,46 +334,32 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
     wj[i] = w;
     w += bwd_job_ws(jobs[i]);
   }
-  // classes of identical geometry (the two directions of a layer) share one XCD-interleaved workgroup range
-  int cls_of[MGR_MAX_SCAN_JOBS], ncls = 0, cls_first[MGR_MAX_SCAN_JOBS], cls_clusters[MGR_MAX_SCAN_JOBS];
-  for (int i = 0; i < njobs; ++i) {
-    if (!use_cluster[i]) continue;
-    int found = -1;
-    for (int k = 0; k < ncls; ++k)
-      if (jobs[cls_first[k]].H == jobs[i].H) found = k;
-    if (found < 0) {
-      found = ncls++;
-      cls_first[found] = i;
-      cls_clusters[found] = 0;
-    }
-    cls_of[i] = found;
-    cls_clusters[found] += (jobs[i].B + 15) / 16;
-  }
-  int cls_begin[MGR_MAX_SCAN_JOBS], cls_next[MGR_MAX_SCAN_JOBS], begin = 0;
-  for (int k = 0; k < ncls; ++k) {
-    begin = (begin + 7) / 8 * 8;
-    cls_begin[k] = begin;
-    cls_next[k] = 0;
-    begin += ((jobs[cls_first[k]].H + 15) / 16) * cls_clusters[k];
-  }
+  int cb[MGR_MAX_SCAN_JOBS], cn[MGR_MAX_SCAN_JOBS], c0[MGR_MAX_SCAN_JOBS];
+  const int grid = layout_classes(
+      njobs, use_cluster, [&](int a, int b) { return jobs[a].H == jobs[b].H; }, [&](int a) { return (jobs[a].H + 15) / 16; }, nbg,
+      cb, cn, c0);
   for (int i = 0; i < njobs; ++i) {
     if (!use_cluster[i]) continue;
     const mgr_scan_bwd_job& j = jobs[i];
     ClusterBwdJob& cj = L.job[L.njobs++];
     cj.dY = j.dY; cj.gates = j.gates; cj.cs = j.cs; cj.Up = j.Up; cj.dZ = j.dZ;
     cj.lddy = j.lddy; cj.B = j.B; cj.T = j.T; cj.H = j.H; cj.reverse = j.reverse;
-    cj.G_ = (j.H + 15) / 16; cj.nbg = (j.B + 15) / 16;
-    const int k = cls_of[i];
-    cj.cls_begin = cls_begin[k];
-    cj.cls_nclusters = cls_clusters[k];
-    cj.cls_cluster0 = cls_next[k];
-    cj.wg_begin = cls_begin[k];
-    cls_next[k] += cj.nbg;
+    cj.G_ = (j.H + 15) / 16; cj.nbg = nbg[i];
+    cj.cls_begin = cb[i]; cj.cls_nclusters = cn[i]; cj.cls_cluster0 = c0[i];
     cj.xbuf = reinterpret_cast<float*>(wj[i]);
   }
   if (L.njobs > 0) {
+    int waves, per_cu;
+    mgr_cluster_bwd_geometry(c, L, grid, &waves, &per_cu);
+    L.cm.status = status;
+    L.cm.sticky = c->sticky_status;
+    L.cm.total_wgs = grid;
+    r = mgr_persist_admit(c, grid, waves, per_cu, &L.cm.seq);
+    if (r) return r;
     MGR_HIP(hipMemsetAsync(base, 0, (size_t)(w - base), mgr_stream(c)));
-    r = mgr_cluster_bwd_launch(c, L, begin);
+    r = mgr_cluster_bwd_launch(c, L, grid);
+    if (r) return r;
+    r = mgr_persist_commit(c, grid, waves, per_cu);
     if (r) return r;
   }
   for (int i = 0; i < njobs; ++i) {
@@ -408,12 +377,7 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
   }
   r = mgr_prof_end(c, MGR_K_SCAN_BWD);
   if (r) return r;
-  if (L.njobs > 0 && c->tune[1]) {
-    unsigned st = 0;
-    MGR_HIP(hipMemcpyAsync(&st, status, sizeof(st), hipMemcpyDeviceToHost, mgr_stream(c)));
-    MGR_HIP(hipStreamSynchronize(mgr_stream(c)));
-    MGR_REQUIRE(st == 0, "cluster BPTT: a bounded spin gave up (status %u)", st);
-  }
+  if (L.njobs > 0 && c->tune[1]) return check_launch_status(c, status, "cluster BPTT");
   return 0;
 }
 
@@ -423,6 +387,98 @@ int mgr_lstm_scan_bwd(mgr_ctx* c, const float* dY, int lddy, const float* gates,
   j.dY = dY; j.gates = gates; j.cs = cs; j.Up = Up; j.dZ = dZ;
   j.lddy = lddy; j.B = B; j.T = T; j.H = H; j.reverse = reverse;
   return mgr_lstm_scan_bwd_multi(c, 1, &j, ws, ws_bytes);
+}
+
+}  // extern "C"
+
+// ---- admission of persistent launches -----------------------------------------------------------------------------------
+// A persistent scan's workgroups spin on their peers, so ALL of them must be resident at once.  Inside one launch the grid is
+// checked against the chip (mgr_cluster_launch).  Across the streams of a context (the encoder scans of step n+1 beside the
+// fusion scan / BPTT of step n, engine.py) this ledger does the same: every persistent launch records (workgroups, waves per
+// workgroup, workgroups per CU) and an event behind its kernel; a new launch that would not fit beside the launches that may
+// still be running is ORDERED BEHIND them (hipStreamWaitEvent) instead of being allowed to dead-lock with them.  Capacity:
+// a CU holds two 4-wave or one 8-wave workgroup of these kernels (they use > 128 VGPRs); as soon as any launch needs a CU of its
+// own, every workgroup in flight is counted as a whole CU (4-wave workgroups are dealt one per CU first, so each may block one).
+// Kernels that are not persistent (GEMMs, ...) leave on their own and need no entry.
+int mgr_persist_admit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu, unsigned* seq_out) {
+  (void)waves_per_wg;
+  bool ordered[MGR_MAX_PERSIST] = {};   // launches this one has been put behind
+  for (;;) {
+    int shared = wgs, any_excl = per_cu == 1 ? 1 : 0, oldest = -1;
+    for (int i = 0; i < MGR_MAX_PERSIST; ++i) {
+      mgr_ctx::Persist& e = c->persist[i];
+      if (!e.active || ordered[i] || e.stream == c->cur) continue;   // (same stream: ordered before this launch anyway)
+      if (hipEventQuery(e.done) == hipSuccess) {
+        e.active = 0;
+        continue;
+      }
+      shared += e.wgs;
+      any_excl |= e.per_cu == 1;
+      if (oldest < 0 || e.seq < c->persist[oldest].seq) oldest = i;
+    }
+    const int capacity = any_excl ? c->cu_count : 2 * c->cu_count;
+    if (oldest < 0 || shared <= capacity) break;
+    // does not fit beside what may still be running: run behind the oldest of them, then look again
+    MGR_HIP(hipStreamWaitEvent(mgr_stream(c), c->persist[oldest].done, 0));
+    ordered[oldest] = true;
+    c->persist_serialised += 1;
+  }
+  *seq_out = ++c->persist_seq;
+  return 0;
+}
+
+int mgr_persist_commit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu) {
+  int slot = -1;
+  for (int i = 0; i < MGR_MAX_PERSIST && slot < 0; ++i)
+    if (!c->persist[i].active) slot = i;
+  if (slot < 0) {   // every entry still marked active: retire those that have finished, else reuse the oldest after waiting for it
+    int oldest = 0;
+    for (int i = 0; i < MGR_MAX_PERSIST; ++i) {
+      if (hipEventQuery(c->persist[i].done) == hipSuccess) slot = i;
+      if (c->persist[i].seq < c->persist[oldest].seq) oldest = i;
+    }
+    if (slot < 0) {
+      MGR_HIP(hipEventSynchronize(c->persist[oldest].done));
+      slot = oldest;
+    }
+  }
+  mgr_ctx::Persist& e = c->persist[slot];
+  if (!e.done) MGR_HIP(hipEventCreateWithFlags(&e.done, hipEventDisableTiming));
+  MGR_HIP(hipEventRecord(e.done, mgr_stream(c)));
+  e.active = 1;
+  e.stream = c->cur;
+  e.wgs = wgs;
+  e.waves = waves_per_wg;
+  e.per_cu = per_cu;
+  e.seq = c->persist_seq;
+  return 0;
+}
+
+namespace {
+// one lane polls the context's "resident" word until the launch with sequence number `seq` has all its workgroups on the chip
+__global__ void k_wait_resident(const unsigned* resident, unsigned seq, unsigned timeout_us) {
+  const unsigned long long t0 = wall_clock64();   // 100 MHz
+  while (__hip_atomic_load(resident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+    __builtin_amdgcn_s_sleep(32);
+    if (wall_clock64() - t0 > 100ull * timeout_us) break;   // placement hint only: never a correctness dependency
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int mgr_stream_wait_next_resident(mgr_ctx* c, int timeout_us) {
+  MGR_REQUIRE(c && timeout_us >= 0, "bad argument");
+  hipLaunchKernelGGL(k_wait_resident, dim3(1), dim3(1), 0, mgr_stream(c), c->sticky_status + 1, c->persist_seq + 1, (unsigned)timeout_us);
+  MGR_LAUNCH_CHECK();
+  return 0;
+}
+
+int mgr_persist_stats(mgr_ctx* c, int* launches, int* serialised) {
+  MGR_REQUIRE(c, "null ctx");
+  if (launches) *launches = (int)c->persist_seq;
+  if (serialised) *serialised = c->persist_serialised;
+  return 0;
 }
 
 }  // extern "C"

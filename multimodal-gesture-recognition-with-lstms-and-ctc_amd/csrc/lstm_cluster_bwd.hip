@@ -30,14 +30,10 @@ constexpr int BW_WAVES = 4;
 //   loads share vmcnt; the acknowledgement of a wave's 8 x 16-byte stores per step was 2.7 of 7.8 us at H = 500), and the
 //   compute waves never wait on vmcnt for the exchange at all.  Plain compiler-managed loads - no register polling.
 template <int H, bool SPLIT>
-__device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg, int ug, int cl, unsigned* xcc, int xcd_local,
-                                                float* smem, unsigned* status) {
+__device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg, int ug, float* smem, unsigned* status) {
   constexpr int N = 4 * H;
   constexpr int GT = (H + 15) / 16;          // tiles of 16 units = workgroups per cluster
   constexpr int TPW = (GT + BW_WAVES - 1) / BW_WAVES;  // tiles per wave (tile m = wave + 4*i)
-  (void)xcc;
-  (void)xcd_local;
-  (void)cl;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool gatherer = SPLIT ? wave_id >= BW_WAVES : true;    // runs step 1 (gather)
@@ -136,7 +132,7 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
             if ((spins & 255u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) failed = true;
             if (spins > POLL_LIMIT) {
               failed = true;
-              if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (lane == 0) __hip_atomic_store(status, MGR_ST_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
         }
@@ -236,19 +232,19 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
 
 template <bool SPLIT>
 __device__ __forceinline__ void scan_cluster_bwd_body(const ClusterBwdLaunch& L, float* smem) {
+  mgr_cluster_enter(L.cm);
   const int bid = blockIdx.x;
   for (int k = 0; k < L.njobs; ++k) {
     const ClusterBwdJob& jb = L.job[k];
     const int w = bid - jb.cls_begin;
     if (w < 0 || w >= jb.cls_nclusters * jb.G_) continue;
-    // members of a cluster are CONTIGUOUS workgroup ids by default (the round-robin dispatcher then spreads them over
-    // all XCDs, which measured best for the write-through exchange); the XCD-local experiment interleaves them instead
-    const int cl = L.xcd_local ? w % jb.cls_nclusters : w / jb.G_;
-    const int ug = L.xcd_local ? w / jb.cls_nclusters : w % jb.G_;
-    const int bg = cl - jb.cls_cluster0;
+    // members of a cluster are CONTIGUOUS workgroup ids (the round-robin dispatcher then spreads them over all XCDs, which
+    // measured best for the write-through exchange)
+    const int ug = w % jb.G_;
+    const int bg = w / jb.G_ - jb.cls_cluster0;
     if (bg < 0 || bg >= jb.nbg) continue;
 #define BW_CASE(HH) \
-  if (jb.H == HH) { cluster_bwd_run<HH, SPLIT>(jb, bg, ug, cl, L.xcc, L.xcd_local, smem, L.status); return mgr_cluster_exit(L.status, L.sticky); }
+  if (jb.H == HH) { cluster_bwd_run<HH, SPLIT>(jb, bg, ug, smem, L.cm.status); return mgr_cluster_exit(L.cm); }
     BW_FOREACH(BW_CASE)
 #undef BW_CASE
     return;
@@ -282,23 +278,34 @@ bool mgr_cluster_bwd_supported(int H) {
   return false;
 }
 
-int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs) {
+// split roles (8 waves, > 80 KiB of LDS requested so that exactly one workgroup sits on a CU) whenever the launch fits one
+// workgroup per CU, has an exchange at all and the layers are wide: at H = 100 (7 workgroups per cluster, two 16-byte stores
+// per lane and step) the store acknowledgement is 0.35 of 2.2 us and the 8-wave workgroups cost config F 0.7 % end to end,
+// at H = 300 / 500 they save a third of the step (E: 60 -> 48 ms/step, S_ref 24 -> 21).  tune key 8: 1 = never, 2 = always.
+static bool bwd_split(const mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs) {
   int maxH = 0;
-  for (int i = 0; i < L.njobs; ++i) maxH = L.job[i].H > maxH ? L.job[i].H : maxH;
+  bool exchange = false;
+  for (int i = 0; i < L.njobs; ++i) {
+    maxH = L.job[i].H > maxH ? L.job[i].H : maxH;
+    exchange = exchange || L.job[i].G_ > 1;
+  }
+  return exchange && (maxH >= 200 || c->tune[8] == 2) && total_wgs <= c->cu_count && c->tune[8] != 1;
+}
+
+void mgr_cluster_bwd_geometry(const mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs, int* waves, int* per_cu) {
+  const bool split = bwd_split(c, L, total_wgs);
+  *waves = split ? 2 * BW_WAVES : BW_WAVES;
+  *per_cu = split ? 1 : 2;
+}
+
+int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs) {
   MGR_REQUIRE(total_wgs <= 2 * c->cu_count, "cluster BPTT needs %d co-resident workgroups", total_wgs);
   if (!(c->attr_done & 2u)) {
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     c->attr_done |= 2u;
   }
-  // split roles (8 waves, > 80 KiB of LDS requested so that exactly one workgroup sits on a CU) whenever the launch fits one
-  // workgroup per CU and has an exchange at all; tune key 8 = 1 keeps the 4-wave kernel
-  // ... and the layers are wide: at H = 100 (7 workgroups per cluster, two 16-byte stores per lane and step) the store
-  // acknowledgement is 0.35 of 2.2 us and the 8-wave workgroups cost config F 0.7 % end to end, at H = 300 / 500 they
-  // save a third of the step (E: 60 -> 48 ms/step, S_ref 24 -> 21)
-  bool exchange = false;
-  for (int i = 0; i < L.njobs; ++i) exchange = exchange || L.job[i].G_ > 1;
-  if (exchange && (maxH >= 200 || c->tune[8] == 2) && total_wgs <= c->cu_count && c->tune[8] != 1) {   // (key 8 = 2 forces it)
+  if (bwd_split(c, L, total_wgs)) {
     size_t lds = 84 * 1024;
     hipLaunchKernelGGL(k_scan_cluster_bwd_split, dim3(total_wgs), dim3(2 * BW_WAVES * 64), lds, mgr_stream(c), L);
   } else {

@@ -7,7 +7,6 @@ Keras' ``train_on_batch`` / ``predict_on_batch`` do for the reference (multimoda
 multimodal_fusion/sequence_decoding.py:121); there is no CPU fallback.
 """
 import ctypes as C
-import os
 import math
 
 import numpy as np
@@ -69,12 +68,41 @@ class _LstmDir:
         self.ws_scan = self.ws_pg = self.ws_sp = None
 
 
+class Schedule:
+    """How one training step is laid out over the context's streams.  The default is the schedule bench.py
+    and fit_generator run; the switches exist so that tests can show every layout computes the same step.
+
+    pipeline            with frozen encoders, the encoder pass of step n+1 runs on a second stream beside step n's
+                        fusion layer / CTC / BPTT / optimizer
+    defer_param_grads   step n's dW / dU / db GEMMs and the optimizer are held back until the deepest projection GEMMs of
+                        step n+1 are done and then run beside its deepest encoder scan (GEMM beside GEMM gains nothing)
+    encoders_run_ahead  the encoder stream does not wait for the previous step as a whole: only the scan that overwrites
+                        the FEAT buffer that step's dW GEMMs read waits for it
+    resident_wait_us    upper bound of the device-side wait that lets the deepest encoder scan become resident before the
+                        deferred GEMMs are released (mgr_stream_wait_next_resident); 0 = no wait
+    """
+
+    def __init__(self, pipeline=True, defer_param_grads=True, encoders_run_ahead=True, resident_wait_us=2000):
+        self.pipeline = bool(pipeline)
+        self.defer_param_grads = bool(defer_param_grads)
+        self.encoders_run_ahead = bool(encoders_run_ahead)
+        self.resident_wait_us = int(resident_wait_us)
+
+
 class Engine:
-    def __init__(self, spec, B, T, Lmax, device=0, seed=1234, comm=None, world=1, inference_only=False):
+    def __init__(self, spec, B, T, Lmax, device=0, seed=1234, comm=None, world=1, inference_only=False, schedule=None):
         self.spec = spec
         self.B, self.T, self.Lmax = int(B), int(T), int(Lmax)
+        cdev = getattr(comm, "dev", None)
+        if cdev is not None:
+            # the all-reduce is enqueued on the communicator's context: it must be THIS engine's context, or it would not be
+            # ordered against the gradient kernels and the optimizer
+            if isinstance(device, Device) and device is not cdev:
+                raise ValueError("the communicator was created on another Device than the engine's")
+            device = cdev
         self._own_dev = not isinstance(device, Device)
         self.dev = device if isinstance(device, Device) else Device(device)
+        self.schedule = schedule or Schedule()
         self.mem = _Arena(self.dev)           # device buffers owned by this engine
         self.lib = self.dev.lib
         self.seed = int(seed)
@@ -172,12 +200,6 @@ class Engine:
         self._feat_idx = 0
         self._prefetched = None
         self._prefetched_for = None
-        self.defer_param_grads = os.environ.get("MGR_DEFER_TN", "1") != "0"
-        self.defer_delay_us = int(os.environ.get("MGR_DEFER_DELAY_US", "150"))
-        self.EV_FPROJ = 45
-        self.es_runs_ahead = os.environ.get("MGR_ES_AHEAD", "1") != "0"
-        # opt-in experiment (measured slower): start the next step's depth-1 scan before this step's fusion layer
-        self.early_encoders = os.environ.get("MGR_EARLY_ENC", "0") == "1"
         self._masks = {}
         any_tr_stream = any(s["trainable"] for s in sp.streams)
         if sp.fusion:
@@ -346,17 +368,16 @@ class Engine:
     def _forward(self, train, rand):
         """Encoders + fusion + head, all on stream 0 (predict / parity / non-pipelined training)."""
         if self._prefetched is not None:   # a pipelined encoder pass is in flight: let it finish, then discard it
-            self.dev.wait(0, 5)
+            self.dev.wait(0, self.ES)
             self._prefetched = None
         self._enqueue_encoders(train, rand, self.FEAT, 0, self.rng_step)
         self._enqueue_fusion_head(train, rand, self.FEAT, self.rng_step)
         if train:
             self.rng_step += 1
 
-    def _enqueue_encoders(self, train, rand, feat_buf, es, rng_step, hold_scans_for=None, before_last_scan=None):
+    def _enqueue_encoders(self, train, rand, feat_buf, es, rng_step, hold_scans_for=None):
         """Noise + every encoder depth (input-projection GEMMs, then all recurrences of the depth in one multi-scan
         call), written into feat_buf.  Everything is enqueued on stream `es`."""
-        depth = max(len(s["layers"]) for s in self.spec.streams)
         for tag, k in self._encoder_phases(train, rand, feat_buf, es, rng_step):
             if tag != "projected":
                 continue
@@ -366,8 +387,6 @@ class Engine:
                 # instead of 11 ms), so the deep scans wait for that stream's queued work first
                 self.dev.stream(es)
                 self.dev.wait(es, hold_scans_for)
-            if before_last_scan is not None and k == depth - 1 and k >= 1:
-                before_last_scan()
 
     def _encoder_phases(self, train, rand, feat_buf, es, rng_step):
         """Generator form of the encoder pass: yields ("projected", k) after the projection GEMMs of depth k are enqueued
@@ -475,7 +494,7 @@ class Engine:
                 self._masks[(L.prefix, L.d)] = mptr
                 pair += [mptr, L.Wp, L.bp, self.ZF[di]]
             self._project_pair(feat_buf, W, pair, Ls_pair, B, T, W, Hf)
-            dev.record(self.EV_FPROJ)   # (the next step's depth-1 scan is launched after these GEMMs, see enqueue_train_step)
+            dev.record(self.EV_FPROJ)   # (the next step's depth-1 scan is launched after these GEMMs, _enqueue_next_encoders)
             for di, dname in enumerate(("fwd", "bwd")):
                 L = self.dirs["fusion/%s" % dname]
                 jobs.append(dict(Z=self.ZF[di], Up=L.Up, Y=self.YF.view(di * Hf, (1,)), ldy=2 * Hf, R=0, ldr=0,
@@ -516,8 +535,20 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------ public
     def _check_scans(self):
+        """Raises if a persistent scan gave up on a bounded spin (its outputs are garbage); a non-finite hidden state is not
+        an error of the engine - the outputs / loss carry the NaN like the reference's would - and is remembered in
+        `nonfinite_seen` until clear_scan_status()."""
         st = C.c_uint(0)
-        self.dev.call("mgr_scan_status", C.byref(st))   # raises if a persistent scan gave up on a bounded spin
+        self.dev.call("mgr_scan_status", C.byref(st))
+        if st.value & _capi.SCAN_NONFINITE:
+            self.nonfinite_seen = True
+
+    nonfinite_seen = False
+
+    def clear_scan_status(self):
+        """Forget recorded scan status bits (after recovering from a diverged run / a give-up)."""
+        self.dev.call("mgr_scan_status_clear")
+        self.nonfinite_seen = False
 
     def predict(self, inputs):
         """Softmax output (B,T,C) with learning phase 0 (sequence_decoding.py:81)."""
@@ -589,9 +620,8 @@ class Engine:
         dev.stream(self.LOSS_STREAM)
         v = float(self.loss_mean.download()[0])
         self._synced_step = self._step_id - 1
-        st = C.c_uint(0)
         try:
-            dev.call("mgr_scan_status", C.byref(st))   # raises if a persistent scan ever gave up: results would be garbage
+            self._check_scans()   # raises if a persistent scan ever gave up: results would be garbage
         finally:
             dev.stream(0)
         return v
@@ -603,64 +633,50 @@ class Engine:
         sp = self.spec
         return bool(sp.fusion) and not any(s["trainable"] for s in sp.streams) and not self.inference_only
 
+    ES = 5          # encoder stream when steps are pipelined
+    EV_PREV = 40    # end of the previous step's fusion phase on stream 0 (its dW GEMMs read the other FEAT buffer)
+    EV_FPROJ = 45   # this step's fusion projection GEMMs are done
+
     def enqueue_train_step(self, inputs, labels, input_length, label_length, rand=None, apply_update=True,
                            upload=True, prefetch_next=False, next_inputs=None):
         """Enqueue one training step.  With prefetch_next (device-RNG training of a network whose encoders are frozen)
         the NEXT step's encoder pass is enqueued on a second stream into the other FEAT buffer right after this step's
-        fusion work, and this step consumes the encoder pass enqueued by the previous call."""
+        fusion work, and this step consumes the encoder pass enqueued by the previous call (Schedule)."""
         sp, dev, B, T = self.spec, self.dev, self.B, self.T
-        ES = 5  # encoder stream when pipelining
-        pipelined = prefetch_next and rand is None and self.can_pipeline
-        have = getattr(self, "_prefetched", None)
+        sch, ES = self.schedule, self.ES
+        pipelined = prefetch_next and rand is None and self.can_pipeline and sch.pipeline
+        depth = max(len(s_["layers"]) for s_ in sp.streams)
+        # ---- 1. this step's encoder pass: the one the previous call prefetched, or in line on stream 0
+        have = self._prefetched
         if have is not None:
             stale = rand is not None or not self.can_pipeline
             if upload and self._prefetched_for is not None and inputs is not self._prefetched_for:
                 stale = True   # the caller did not come back with the batch it announced
             if stale:
                 dev.wait(0, ES)
-                have = self._prefetched = None
+                have = None
+        self._prefetched = None
         if have is None:
             if upload:
                 self._upload_inputs(inputs, rand, True)
             cur = self._feat_ring[self._feat_idx]
-            self._enqueue_encoders(True, rand, cur, 0, self.rng_step)   # nothing prefetched: do it now, in line
+            self._enqueue_encoders(True, rand, cur, 0, self.rng_step)
         else:
             cur = have
             dev.wait(0, ES)          # this step's encoder pass (enqueued by the previous call) must be complete
         if upload:
             self._upload_labels(labels, input_length, label_length)
-        self._prefetched = None
-        depth = max(len(s_["layers"]) for s_ in sp.streams)
-        # early start: the next step's depth-1 projections and scan are enqueued BEFORE this step's fusion layer, whose
-        # projection GEMMs then run beside that scan instead of beside the depth-1 projection GEMMs
-        early = (pipelined and have is not None and sp.fusion is not None and self.defer_param_grads
-                 and self.early_encoders and depth >= 2)
-        phases = None
-        EV_PREV = 40
+        defer = pipelined and sch.defer_param_grads and sp.fusion is not None and depth >= 2
+        # (not in a call that ran its own encoder pass in line on stream 0: that pass uses the encoder buffers)
+        ahead = defer and sch.encoders_run_ahead and have is not None
         if pipelined:
             # the other FEAT buffer was last read by the previous step's fusion phase (its dW GEMMs, queued on stream 0)
-            # (not in a call that ran its own encoder pass in line on stream 0: that pass uses the encoder buffers)
-            ahead = (self.es_runs_ahead and have is not None and sp.fusion is not None and self.defer_param_grads
-                     and depth >= 2)
-            if early or ahead:
+            if ahead:
                 dev.stream(0)
-                dev.record(EV_PREV)   # only the launch that WRITES that buffer (the deepest scan) has to wait for it
+                dev.record(self.EV_PREV)   # only the launch that WRITES that buffer (the deepest scan) has to wait for it
             else:
                 dev.wait(ES, 0)
-        if early:
-            self._feat_idx ^= 1
-            nxt = self._feat_ring[self._feat_idx]
-            self._prefetched_for = next_inputs
-            if next_inputs is not None:
-                dev.stream(ES)
-                self._upload_inputs(next_inputs, None, True, stream=ES)
-                self._xin_user[self._xin_slot] = self._step_id + 1
-            phases = self._encoder_phases(True, None, nxt, ES, self.rng_step + 1)
-            assert next(phases) == ("projected", 0)
-            dev.wait(0, ES)           # this step's fusion projections start when the next step's depth-1 ones are done
-            assert next(phases) == ("scanned", 0)
-            dev.stream(0)
-            dev.call("mgr_stream_delay", self.defer_delay_us)   # ... and after that scan's workgroups are resident
+        # ---- 2. fusion layer, head, CTC, loss read-back point
         self._enqueue_fusion_head(True, rand, cur, self.rng_step)
         self.rng_step += 1
         Cn, D = sp.num_classes, sp.head_width
@@ -674,12 +690,13 @@ class Engine:
         this_step = self._step_id
         self._step_id += 1
         self._lab_user[self._lab_slot] = this_step
+        any_tr_stream = any(s["trainable"] for s in sp.streams)
         if have is None:   # this step's own inputs (a prefetched set was tagged when it was uploaded)
             # trainable first layers read them again in their dW GEMMs, which only the NEXT step's loss read-back covers
-            self._xin_user[self._xin_slot] = this_step + (1 if any(s_["trainable"] for s_ in sp.streams) else 0)
+            self._xin_user[self._xin_slot] = this_step + (1 if any_tr_stream else 0)
+        # ---- 3. backward
         feat, ldf = self._feat
         hm, p_head, hseed = self._head_args
-        any_tr_stream = any(s["trainable"] for s in sp.streams)
         W = sp.concat_width
         if sp.fusion:
             dA, ldda = self.dYF, 2 * sp.fusion["H"]
@@ -694,17 +711,14 @@ class Engine:
         if sp.fusion:
             Hf = sp.fusion["H"]
             deferred = self._bilstm_backward("fusion", self.dYF, 2 * Hf, self._featin, W, W, self.YF, 2 * Hf,
-                                             self.dFEAT if any_tr_stream else None, W,
-                                             defer_param_grads=pipelined and self.defer_param_grads)
+                                             self.dFEAT if any_tr_stream else None, W, defer_param_grads=defer)
         if any_tr_stream:
             col = 0
-            for si, s in enumerate(sp.streams):
-                wout = sp.stream_width(s)
+            for s in sp.streams:
                 if s["trainable"]:
                     self._stream_backward(s, col)
-                col += wout
-        dev.stream(0)
-        if any_tr_stream:
+                col += sp.stream_width(s)
+            dev.stream(0)
             dev.record(self.EV_IN[self._xin_slot])   # trainable first layers read the inputs again in their dW GEMMs
 
         def finish():
@@ -714,59 +728,55 @@ class Engine:
             if apply_update:
                 self.apply_gradients()
 
-        def under_last_scan():
-            dev.wait(0, ES)
-            dev.stream(0)
-            # both streams become ready at the same instant; the scan's workgroups must be placed first (one per CU)
-            # or they trickle in behind GEMM waves and the whole scan runs at half speed (measured 22.7 vs 11.4 ms)
-            dev.call("mgr_stream_delay", self.defer_delay_us)
-            finish()
-
+        # ---- 4. parameter gradients + optimizer, and (pipelined) the next step's encoder pass
         if not pipelined:
             finish()
-        elif early:
-            for tag, k in phases:
-                if tag == "projected" and k == depth - 1:
-                    under_last_scan()
-                    dev.wait_event(ES, EV_PREV)
-            self._prefetched = nxt
-            dev.stream(0)
         else:
-            # encoder pass of the NEXT step, into the other FEAT buffer, concurrent with everything enqueued above
-            # (stream ES was made to wait for the previous step's fusion phase before this step's was enqueued)
-            self._feat_idx ^= 1
-            nxt = self._feat_ring[self._feat_idx]
-            self._prefetched_for = next_inputs
-            if next_inputs is not None:
-                dev.stream(ES)
-                self._upload_inputs(next_inputs, None, True, stream=ES)
-                self._xin_user[self._xin_slot] = self._step_id   # (already advanced: the step that will consume it)
-            if deferred is None:
-                finish()
-                self._enqueue_encoders(True, None, nxt, ES, self.rng_step, hold_scans_for=0)
-            else:
-                # the dW/dU GEMMs of THIS step and the optimizer are held back until the next step's deepest projection
-                # GEMMs are done and then run beside its deepest encoder scan: GEMM next to GEMM gains nothing, whereas a
-                # big scan leaves most of the MFMA issue slots free (tools/overlap_probe.py: scan x1.12, GEMM at 1/3 speed)
-                if ahead:
-                    # the encoder stream does not wait for this stream's previous step as a whole: its depth-1 projections
-                    # start as soon as its own previous pass is done (beside the small kernels that end that step), the
-                    # depth-1 scan is launched after this step's fusion projections (a persistent launch placed among
-                    # chip-filling GEMMs gets a poor CU set), and only the deepest scan - the one that overwrites the FEAT
-                    # buffer the previous step's dW GEMMs read - waits for that step
-                    for tag, k in self._encoder_phases(True, None, nxt, ES, self.rng_step):
-                        if tag != "projected":
-                            continue
-                        if k == 0:
-                            dev.stream(ES)
-                            dev.wait_event(ES, self.EV_FPROJ)
-                        if k == depth - 1:
-                            under_last_scan()
-                            dev.wait_event(ES, EV_PREV)
-                else:
-                    self._enqueue_encoders(True, None, nxt, ES, self.rng_step, before_last_scan=under_last_scan)
-            self._prefetched = nxt
-            dev.stream(0)
+            self._enqueue_next_encoders(next_inputs, finish, defer, ahead, depth)
+        dev.stream(0)
+
+    def _enqueue_next_encoders(self, next_inputs, finish, defer, ahead, depth):
+        """Encoder pass of the NEXT step on stream ES into the other FEAT buffer, concurrent with what enqueue_train_step
+        has put on stream 0; `finish` (this step's parameter-gradient GEMMs + optimizer) is placed according to the schedule."""
+        dev, ES = self.dev, self.ES
+        self._feat_idx ^= 1
+        nxt = self._feat_ring[self._feat_idx]
+        self._prefetched_for = next_inputs
+        if next_inputs is not None:
+            dev.stream(ES)
+            self._upload_inputs(next_inputs, None, True, stream=ES)
+            self._xin_user[self._xin_slot] = self._step_id   # (already advanced: the step that will consume it)
+        if not defer:
+            finish()
+            self._enqueue_encoders(True, None, nxt, ES, self.rng_step, hold_scans_for=0)
+        else:
+            # The dW/dU GEMMs of THIS step and the optimizer are held back until the next step's deepest projection GEMMs are
+            # done and then run beside its deepest encoder scan: GEMM next to GEMM gains nothing, whereas a big scan leaves
+            # most of the MFMA issue slots free (tools/overlap_probe.py: scan x1.12, GEMM at 1/3 speed).
+            # With `ahead` the encoder stream does not wait for this stream's previous step as a whole: its depth-1
+            # projections start as soon as its own previous pass is done (beside the small kernels that end that step), the
+            # depth-1 scan is launched after this step's fusion projections (a persistent launch placed among chip-filling
+            # GEMMs gets a poor CU set), and only the deepest scan - the one that overwrites the FEAT buffer the previous
+            # step's dW GEMMs read - waits for that step.
+            for tag, k in self._encoder_phases(True, None, nxt, ES, self.rng_step):
+                if tag != "projected":
+                    continue
+                if ahead and k == 0:
+                    dev.stream(ES)
+                    dev.wait_event(ES, self.EV_FPROJ)
+                if k == depth - 1:
+                    dev.wait(0, ES)
+                    dev.stream(0)
+                    # Both streams become ready at the same instant.  The scan's workgroups must be placed first (one or
+                    # two per CU): if GEMM waves get there first the scan's workgroups trickle in behind them and the
+                    # whole scan runs at half speed (measured 22.7 vs 11.4 ms).  So the GEMMs wait - on the device - until
+                    # the scan launched next on this context reports every workgroup resident.
+                    if self.schedule.resident_wait_us > 0:
+                        dev.call("mgr_stream_wait_next_resident", self.schedule.resident_wait_us)
+                    finish()
+                    if ahead:
+                        dev.wait_event(ES, self.EV_PREV)
+        self._prefetched = nxt
 
     def _bilstm_backward(self, prefix, dY, lddy, Xin, ldx, fin, Hbuf, ldh, dX, lddx, defer_param_grads=False):
         """BPTT + parameter grads of one Bidirectional layer (both directions in one persistent launch).

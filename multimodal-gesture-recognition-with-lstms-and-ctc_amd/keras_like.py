@@ -362,8 +362,14 @@ class Model:
             self._engine.spec = self.spec
 
     def distribute(self, comm, world):
-        """Attach a data-parallel communicator (mgr_amd.parallel) before the first batch."""
-        self.comm, self.world = comm, world
+        """Attach a data-parallel communicator (mgr_amd.parallel.RcclComm / HostComm) before the first batch.  The engine is
+        built on the communicator's Device (the all-reduce must be ordered on the engine's own stream) and draws its
+        dropout / noise from a per-rank seed; every rank feeds ITS shard of the global batch (parallel.shard_batch)."""
+        if self._engine is not None:
+            raise RuntimeError("distribute() must be called before the first batch")
+        self.comm, self.world = comm, int(world)
+        if getattr(comm, "dev", None) is not None:
+            self.device = comm.dev
 
     def _ensure_engine(self, B, T, Lmax, inference_only=False):
         from .engine import Engine
@@ -376,7 +382,8 @@ class Model:
             e.close()
         else:
             opt_state = None
-        self._engine = Engine(self.spec, B, T, max(Lmax, 1), device=self.device, seed=self.seed, comm=self.comm,
+        rank = int(getattr(self.comm, "rank", 0) or 0)
+        self._engine = Engine(self.spec, B, T, max(Lmax, 1), device=self.device, seed=self.seed + 7919 * rank, comm=self.comm,
                               world=self.world, inference_only=inference_only)
         self._engine.set_weights(w)
         if opt_state is not None and not inference_only:
@@ -409,13 +416,14 @@ class Model:
         return e.train_step(ins, labels, x["input_length"], x["label_length"], rand=rand, next_inputs=nxt)
 
     def _cached_split(self, x):
-        """_split_inputs with identity preserved across calls (the engine matches a prefetched batch by identity)."""
-        key = id(x)
+        """_split_inputs with identity preserved across calls (the engine matches a prefetched batch by identity).
+        The cache entry holds a reference to `x` itself and is matched with `is`: an `id()` key alone can be reused by
+        CPython for a NEW batch as soon as the old dict is freed, which would silently train on stale inputs."""
         c = getattr(self, "_split_cache", None)
-        if c is not None and c[0] == key:
+        if c is not None and c[0] is x:
             return c[1]
         ins = self._split_inputs(x)
-        self._split_cache = (key, ins)
+        self._split_cache = (x, ins)
         return ins
 
     def test_on_batch(self, x, y=None, rand=None):

@@ -8,7 +8,10 @@ identically (clipping after the reduce is what makes 8x64 equivalent to 1x512).
 Communicators:
   RcclComm  - mgr_comm_* of libmgr.so (RCCL over xGMI); the 128-byte unique id is distributed by the
               caller's bootstrap callable (torch.distributed's store in bench.py, or anything else).
-  HostComm  - a host-side stand-in with the same interface used by the world_size-2 gloo CPU tests.
+  HostComm  - the same interface without RCCL: device -> host copy, rank-ordered sum over plain TCP sockets (star through
+              rank 0), host -> device copy, all on the engine's stream.  Lets a world > 1 step run where RCCL cannot (several
+              ranks on ONE GPU: `bench.py --gpus 2 --comm host`, tests/test_gpu_dataparallel.py) and is the reference the RCCL
+              path is compared with.  Not a performance path.
 """
 import ctypes as C
 
@@ -61,6 +64,106 @@ class RcclComm:
         if self.comm:
             self.dev.lib.mgr_comm_destroy(self.comm)
             self.comm = None
+
+
+class HostComm:
+    """Drop-in for RcclComm that reduces on the host.  `dev` is the engine's Device (the copies run on ITS current stream, so
+    they are ordered after the gradient kernels and before the optimizer exactly like the RCCL kernel would be); `dev=None`
+    gives a host-only communicator (numpy in, numpy out) for CPU tests.  Reduction order is rank order on rank 0 and the
+    result is broadcast, so every replica receives the same bits."""
+
+    PORT_OFFSET = 102
+
+    def __init__(self, dev, rank, world, addr=None, port=None, timeout=600.0):
+        import os
+        import socket
+        import time
+        self.dev, self.rank, self.world = dev, int(rank), int(world)
+        self.addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        self.port = int(port or int(os.environ.get("MASTER_PORT", "29500")) + self.PORT_OFFSET)
+        self.peers = {}        # rank 0: rank -> socket
+        self.sock = None       # other ranks: socket to rank 0
+        if self.world == 1:
+            return
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind(("127.0.0.1" if self.addr == "localhost" else self.addr, self.port))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            for _ in range(self.world - 1):
+                c, _ = srv.accept()
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                c.settimeout(timeout)
+                r = int.from_bytes(self._recv_exact(c, 4), "little")
+                self.peers[r] = c
+            srv.close()
+            if sorted(self.peers) != list(range(1, self.world)):
+                raise RuntimeError("HostComm: expected ranks 1..%d, got %s" % (self.world - 1, sorted(self.peers)))
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    c = socket.create_connection((self.addr, self.port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise RuntimeError("HostComm rank %d: rank 0 not reachable at %s:%d" % (self.rank, self.addr, self.port))
+                    time.sleep(0.05)
+            c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            c.settimeout(timeout)
+            c.sendall(self.rank.to_bytes(4, "little"))
+            self.sock = c
+
+    @staticmethod
+    def _recv_exact(c, n):
+        buf = bytearray(n)
+        view = memoryview(buf)
+        got = 0
+        while got < n:
+            k = c.recv_into(view[got:], n - got)
+            if k == 0:
+                raise RuntimeError("HostComm: peer closed the connection")
+            got += k
+        return bytes(buf)
+
+    def _reduce_host(self, a, op):
+        """a: contiguous float32 numpy array; returns the reduction over all ranks (same bits on every rank)."""
+        if self.world == 1:
+            return a
+        if self.rank == 0:
+            acc = a.copy()
+            for r in range(1, self.world):          # rank order: deterministic
+                other = np.frombuffer(self._recv_exact(self.peers[r], a.nbytes), dtype=np.float32)
+                acc = op(acc, other)
+            raw = acc.tobytes()
+            for r in range(1, self.world):
+                self.peers[r].sendall(raw)
+            return acc
+        self.sock.sendall(a.tobytes())
+        return np.frombuffer(self._recv_exact(self.sock, a.nbytes), dtype=np.float32).copy()
+
+    def allreduce_sum_host(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        return self._reduce_host(a.ravel(), np.add).reshape(a.shape)
+
+    def allreduce_sum(self, darr, n):
+        view = darr.view(0, (int(n),))
+        view.upload(self._reduce_host(view.download(), np.add))    # both copies synchronise the engine's current stream
+
+    def allreduce_max_scalar(self, value):
+        return float(self._reduce_host(np.array([value], np.float32), np.maximum)[0])
+
+    def barrier(self):
+        self.allreduce_max_scalar(0.0)
+
+    def close(self):
+        for c in list(self.peers.values()) + ([self.sock] if self.sock else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self.peers, self.sock = {}, None
 
 
 def data_parallel_update(local_grads, allreduce_sum, world):

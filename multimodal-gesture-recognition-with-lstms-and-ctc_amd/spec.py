@@ -94,15 +94,20 @@ class NetworkSpec:
             n += k
         return n
 
-    def flops_per_frame(self):
+    def flops_per_frame(self, executed=False):
         """Algorithmic FLOP per padded frame of one training step (2 x MAC), SURVEY 8(d) accounting:
-        forward of every layer, backward (dZ.U^T, dW, dU [, dX]) of trainable ones, Dense fwd+bwd."""
+        forward of every layer, backward (dZ.U^T, dW, dU [, dX]) of trainable ones, Dense fwd+bwd.
+        executed=True: what the device really multiplies in a training step - the dropout-aware projection and dW kernels
+        (used from p >= 0.3 on, 16 <= F <= 2048) skip the products with dropped features, i.e. run the (1 - p) share of
+        their K loops; the skipped terms are exact zeros, the result is the dense one."""
         mac = 0
-        for prefix, fin, H, _, tr in self.lstm_layers():
-            fwd = 2 * (fin * 4 * H + H * 4 * H)
+        for prefix, fin, H, p, tr in self.lstm_layers():
+            keep = (1.0 - p) if (executed and p >= 0.3 and 16 <= fin <= 2048) else 1.0
+            proj = fin * 4 * H
+            fwd = 2 * (proj * keep + H * 4 * H)
             mac += fwd
             if tr:
-                bwd = 2 * (fin * 4 * H + 2 * H * 4 * H)  # dW + (dh_rec, dU)
+                bwd = 2 * (proj * keep + 2 * H * 4 * H)  # dW + (dh_rec, dU)
                 first = prefix.endswith("/l0")
                 if not first and prefix != "fusion":
                     bwd += 2 * fin * 4 * H  # dX to a trainable layer below
@@ -110,4 +115,4 @@ class NetworkSpec:
                     bwd += 2 * fin * 4 * H
                 mac += bwd
         mac += self.head_width * self.head["C"] * 3
-        return 2 * mac
+        return 2 * mac if executed else int(2 * mac)

@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: takes minutes (CPU oracle over a whole decode set)")
+    # The 2-rank data-parallel GPU tests (test_gpu_dataparallel.py) fork their rank processes from multiprocessing's fork
+    # server.  It has to be started HERE, before anything in this process initialises the GPU: a process that has done so
+    # must not exec another program, and a forked copy of it is no place to start a second GPU context either.
+    if "not gpu" not in (config.getoption("-m", default="") or ""):
+        from multiprocessing import forkserver
+        forkserver.ensure_running()
 
 
 @pytest.fixture(scope="session")

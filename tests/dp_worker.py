@@ -1,0 +1,85 @@
+"""Rank process of the 2-rank data-parallel GPU tests (tests/test_gpu_dataparallel.py).  Runs in a process forked from a fork
+server that never touched the GPU; initialises the GPU itself.  One GPU is shared by all ranks (Device(0)), gradients are
+summed by parallel.HostComm - everything else is the product path: Engine.enqueue_train_step's pipelined schedule, shard_batch,
+Engine.apply_gradients' world > 1 branch (all-reduce -> /world -> clip -> Adam -> max-norm)."""
+import os
+import sys
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dp_spec(exact):
+    """The reference-size fusion network; `exact` removes every random draw (dropout 0, noise 0) so that a sharded run and a
+    one-process run see identical arithmetic and can be compared number by number."""
+    import mgr_amd  # noqa: F401
+    from mgr_amd.configs import fusion_spec
+    from mgr_amd.spec import NetworkSpec
+    d = fusion_spec().to_dict()
+    if exact:
+        for s in d["streams"]:
+            s["noise"] = 0.0
+            for lay in s["layers"]:
+                lay["dropout"] = 0.0
+        d["fusion"]["dropout"] = 0.0
+        d["head"]["dropout"] = 0.0
+    return NetworkSpec.from_dict(d)
+
+
+def dp_batches(spec, B, T, Lmax, nbatch):
+    from mgr_amd.synthetic import synthetic_arrays
+    out = []
+    for i in range(nbatch):
+        xs, labels, il, ll = synthetic_arrays(spec, B, T, Lmax, 500 + i, lmin=2, lmax=6)
+        out.append(dict(xs, the_labels=labels, input_length=il, label_length=ll))
+    return out
+
+
+def run_steps(eng, spec, batches, steps, pipelined=True):
+    """`steps` training steps over the batches in turn through the host-batch path fit_generator uses (next batch announced so
+    that its encoder pass is prefetched).  Returns the per-step local mean losses."""
+    names = [s["name"] for s in spec.streams]
+    splits = [{n: b[n] for n in names} for b in batches]     # stable objects: the engine matches the announced batch by identity
+    losses = []
+    for i in range(steps):
+        b, ins = batches[i % len(batches)], splits[i % len(batches)]
+        nxt = splits[(i + 1) % len(batches)] if (pipelined and i + 1 < steps) else None
+        losses.append(eng.train_step(ins, b["the_labels"], b["input_length"], b["label_length"], next_inputs=nxt))
+    return losses
+
+
+def dp_rank(rank, world, port, out_path, exact, B, T, Lmax, steps):
+    try:
+        sys.path.insert(0, ROOT)
+        import mgr_amd  # noqa: F401
+        from mgr_amd import _capi
+        from mgr_amd.engine import Engine
+        from mgr_amd.parallel import HostComm, shard_batch
+        from mgr_amd.synthetic import synthetic_weights
+        dev = _capi.Device(0)
+        comm = HostComm(dev, rank, world, addr="127.0.0.1", port=port, timeout=120.0)
+        spec = dp_spec(exact)
+        eng = Engine(spec, B // world, T, Lmax, device=dev, seed=100 + rank, comm=comm, world=world)
+        assert eng.can_pipeline
+        eng.set_weights(synthetic_weights(spec, 3))
+        mine = [shard_batch(b, rank, world) for b in dp_batches(spec, B, T, Lmax, 2)]
+        losses = run_steps(eng, spec, mine, steps)
+        dev.sync()
+        import ctypes
+        st = ctypes.c_uint(7)
+        dev.call("mgr_scan_status", ctypes.byref(st))
+        nl, ns = ctypes.c_int(), ctypes.c_int()
+        dev.call("mgr_persist_stats", ctypes.byref(nl), ctypes.byref(ns))
+        w, g = eng.get_weights(), eng.get_grads()
+        comm.barrier()
+        np.savez(out_path, losses=np.array(losses, np.float64), status=st.value, persist=np.array([nl.value, ns.value]),
+                 **{"w__" + k.replace("/", "__"): v for k, v in w.items()},
+                 **{"g__" + k.replace("/", "__"): v for k, v in g.items()})
+        comm.close()
+        eng.close()
+    except BaseException:
+        with open(out_path + ".err", "w") as f:
+            f.write(traceback.format_exc())
+        raise

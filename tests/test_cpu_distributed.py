@@ -125,3 +125,43 @@ def test_tcp_bootstrap_distributes_the_unique_id():
     for p in procs:
         p.join(30)
     assert all(got[r] == bytes(range(128)) for r in range(world))
+
+
+def _hostcomm_rank(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import mgr_amd  # noqa: F401
+    from mgr_amd.parallel import HostComm
+    comm = HostComm(None, rank, world, addr="127.0.0.1", port=port, timeout=30.0)
+    rng = np.random.default_rng(rank)
+    a = (rng.standard_normal(1001) * 10.0 ** rng.integers(-3, 4, 1001)).astype(np.float32)
+    s1 = comm.allreduce_sum_host(a)
+    s2 = comm.allreduce_sum_host(a.reshape(7, 143))           # a second collective on the same connections, another shape
+    mx = comm.allreduce_max_scalar(float(rank) + 0.5)
+    comm.barrier()
+    comm.close()
+    q.put((rank, a, s1, s2, mx))
+
+
+def test_hostcomm_sums_in_rank_order_and_every_rank_gets_the_same_bits():
+    """parallel.HostComm (the communicator of the 2-rank GPU test and of `bench.py --comm host`): star reduction through rank
+    0 in RANK ORDER ((r0 + r1) + r2 in fp32), the result broadcast - so replicas stay bit-identical."""
+    import multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    procs = [ctx.Process(target=_hostcomm_rank, args=(r, world, port, q)) for r in (1, 2, 0)]   # clients may start first
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, a, s1, s2, mx = q.get(timeout=60)
+        got[r] = (a, s1, s2, mx)
+    for p in procs:
+        p.join(30)
+    expect = (got[0][0] + got[1][0]) + got[2][0]                # fp32, rank order
+    for r in range(world):
+        assert np.array_equal(got[r][1], expect)
+        assert np.array_equal(got[r][2], expect.reshape(7, 143))
+        assert got[r][3] == 2.5

@@ -214,6 +214,12 @@ def test_hidden_load_isa_check():
     objdir = os.path.join(os.path.dirname(_build.__file__), "build")
     if any(f.endswith(".s") and "amdgcn" in f for f in os.listdir(objdir)):
         _build.check_hidden_loads(objdir)
+    good_id = """
+_ZN12_GLOBAL__N_120k_scan_cluster_ks_idE13ClusterLaunch:
+\tglobal_load_dwordx4 v[54:57], v[102:103], off sc1
+\tv_mfma_f32_16x16x4_f32 v[0:3], v54, v4, v[0:3]
+\ts_endpgm
+"""
     bad = """
 _ZN12_GLOBAL__N_117k_scan_cluster_ksE13ClusterLaunch:
 \tv_mov_b32_e32 v9, v54
@@ -222,8 +228,10 @@ _ZN12_GLOBAL__N_117k_scan_cluster_ksE13ClusterLaunch:
 \tv_mov_b64_e32 v[50:51], v[54:55]
 \tv_mfma_f32_16x16x4_f32 v[0:3], v50, v4, v[0:3]
 \ts_endpgm
-"""
+""" + good_id
     with tempfile.TemporaryDirectory() as d:
+        with pytest.raises(RuntimeError, match="no device assembly"):
+            _build.check_hidden_loads(d)     # a build without the assembly must not pass unchecked
         with open(os.path.join(d, "lstm_cluster-hip-amdgcn-amd-amdhsa-gfx950.s"), "w") as f:
             f.write(bad)
         with pytest.raises(RuntimeError, match="copies a register"):
@@ -231,3 +239,31 @@ _ZN12_GLOBAL__N_117k_scan_cluster_ksE13ClusterLaunch:
         with open(os.path.join(d, "lstm_cluster-hip-amdgcn-amd-amdhsa-gfx950.s"), "w") as f:
             f.write(bad.replace("\tv_mov_b64_e32 v[50:51], v[54:55]\n", "").replace("v50, v4", "v54, v4"))
         _build.check_hidden_loads(d)     # the copy BEFORE the load and the MFMA consuming the loaded register are fine
+
+
+def test_train_on_batch_with_fresh_temporaries_never_reuses_a_stale_split():
+    """Model._cached_split must match batches by object identity while holding the object: an id() key alone is reused by
+    CPython as soon as the previous dict is freed and would make train_on_batch train on the first batch's inputs."""
+    spec = configs.fusion_spec(h_audio=8, h_skeletal=4, h_fusion=4)
+    m = Model(spec)
+
+    def make(i):
+        return {"the_input_audio": np.full((2, 6, 39), float(i)), "the_input_skeletal": np.full((2, 6, 20), float(-i))}
+
+    for i in range(8):
+        ins = m._cached_split(make(i))
+        assert ins["the_input_audio"][0, 0, 0] == float(i) and ins["the_input_skeletal"][0, 0, 0] == float(-i)
+    x = make(3)
+    assert m._cached_split(x) is m._cached_split(x)       # the same object twice: one split (prefetch matching relies on it)
+
+
+def test_executed_flop_accounting():
+    """bench.py reports the algorithmic FLOP of SURVEY 8(d) and, beside it, what the dropout-aware kernels really execute."""
+    spec, B, T, Lmax = configs.baseline_config("F")
+    alg, ex = spec.flops_per_frame(), spec.flops_per_frame(executed=True)
+    assert alg == 27794400 and 0.6 * alg < ex < 0.8 * alg
+    # by hand: projections of audio l1 (1000 -> 500, p .5), skeletal l1 (600 -> 300, p .6), fusion (1600 -> 100, p .5) fwd + dW
+    skipped = 2 * (2 * 1000 * 2000 * 0.5 + 2 * 600 * 1200 * 0.6 + 2 * 2 * 1600 * 400 * 0.5)
+    skipped += 2 * (2 * 39 * 2000 * 0.4)      # audio l0: F = 39, p = .4 also takes the dropout-aware kernel
+    skipped += 2 * (2 * 20 * 1200 * 0.6)      # skeletal l0: F = 20, p = .6
+    assert abs((alg - ex) - skipped) < 1e-6 * alg

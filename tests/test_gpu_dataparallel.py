@@ -1,0 +1,96 @@
+"""-m gpu: a REAL world-size-2 data-parallel training step on the one GPU of the test box (BASELINE configs[3]).
+
+Two rank processes share GPU 0; each owns half of the global batch and its own Engine with the pipelined two-stream schedule
+on; gradients are summed by parallel.HostComm (RCCL refuses two ranks on one device).  Everything else is the path the 8-GPU
+bench runs: shard_batch, Engine.apply_gradients' world > 1 branch (all-reduce -> /world -> clip -> Adam -> max-norm), the deferred
+dW -> all-reduce -> Adam ordering of the pipelined schedule.  The rank processes are forked from a fork server that
+tests/conftest.py starts before anything touches the GPU (a process that has initialised the GPU must not exec)."""
+import multiprocessing as mp
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from tests import dp_worker
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(tmp_path, world, exact, B, T, Lmax, steps):
+    from multiprocessing import forkserver
+    if getattr(forkserver._forkserver, "_forkserver_pid", None) is None:
+        pytest.skip("the fork server must be started before the GPU is initialised: run through `pytest -m gpu` (tests/conftest.py)")
+    ctx = mp.get_context("forkserver")
+    port = _free_port()
+    outs = [str(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    procs = [ctx.Process(target=dp_worker.dp_rank, args=(r, world, port, outs[r], exact, B, T, Lmax, steps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    for r, p in enumerate(procs):
+        if p.is_alive():
+            p.kill()
+            pytest.fail("rank %d did not finish" % r)
+        err = outs[r] + ".err"
+        assert p.exitcode == 0, open(err).read() if os.path.exists(err) else "rank %d exit code %s" % (r, p.exitcode)
+    return [np.load(o) for o in outs]
+
+
+
+def test_two_ranks_on_one_gpu_equal_one_process_on_the_full_batch(device, tmp_path):
+    """No random draws (dropout / noise 0): 4 pipelined steps of 2 ranks x B/2 must reproduce 1 process x B - per-step losses,
+    the all-reduced gradient, the updated weights - up to fp32 summation order; the two replicas must agree bit for bit."""
+    from mgr_amd.engine import Engine
+    from mgr_amd.synthetic import synthetic_weights
+    B, T, Lmax, steps, world = 32, 96, 8, 4, 2
+    ranks = _run_ranks(tmp_path, world, True, B, T, Lmax, steps)
+    # the same steps in one process on the full batch (this process, same GPU)
+    spec = dp_worker.dp_spec(True)
+    eng = Engine(spec, B, T, Lmax, device=device, seed=100)
+    eng.set_weights(synthetic_weights(spec, 3))
+    ref_losses = dp_worker.run_steps(eng, spec, dp_worker.dp_batches(spec, B, T, Lmax, 2), steps)
+    device.sync()
+    w_ref, g_ref = eng.get_weights(), eng.get_grads()
+    eng.close()
+    r0, r1 = ranks
+    assert int(r0["status"]) == 0 and int(r1["status"]) == 0            # no persistent scan gave up, nothing went non-finite
+    # losses: the global mean is the mean of the ranks' local means
+    glob = (r0["losses"] + r1["losses"]) / world
+    assert np.allclose(glob, ref_losses, rtol=2e-6), (glob, ref_losses)
+    assert np.all(np.isfinite(glob)) and len(set(np.round(glob, 3))) > 1
+    for k, v in w_ref.items():
+        kk = k.replace("/", "__")
+        assert np.array_equal(r0["w__" + kk], r1["w__" + kk]), k          # replicas stay bit-identical
+        # Adam's step is lr * m / (sqrt(v) + eps): where a gradient is ~0 a summation-order difference moves it by a fraction of lr
+        assert np.allclose(r0["w__" + kk], v, rtol=0, atol=5e-5), (k, np.abs(r0["w__" + kk] - v).max())
+    for k, v in g_ref.items():
+        kk = k.replace("/", "__")
+        assert np.array_equal(r0["g__" + kk], r1["g__" + kk]), k
+        # the gradient buffer holds the all-reduced SUM of the ranks' local means = world x the full-batch mean gradient
+        assert rel_err(r0["g__" + kk] / world, v) < 2e-5, (k, rel_err(r0["g__" + kk] / world, v))
+    # weights moved by about lr per step where gradients are non-trivial
+    assert np.abs(w_ref["dense/W"] - synthetic_weights(spec, 3)["dense/W"]).max() > 1e-4
+
+
+def test_two_ranks_with_device_rng_stay_in_lockstep(device, tmp_path):
+    """The real configuration (dropout .4-.6, noise .5, per-rank RNG seeds): replicas must still hold identical weights after
+    5 pipelined steps, losses finite and different between the ranks (different shards, different masks)."""
+    ranks = _run_ranks(tmp_path, 2, False, 32, 96, 8, 5)
+    r0, r1 = ranks
+    assert int(r0["status"]) == 0 and int(r1["status"]) == 0
+    assert np.all(np.isfinite(r0["losses"])) and np.all(np.isfinite(r1["losses"]))
+    assert not np.array_equal(r0["losses"], r1["losses"])
+    for k in r0.files:
+        if k.startswith(("w__", "g__")):
+            assert np.array_equal(r0[k], r1[k]), k

@@ -57,7 +57,7 @@ for k in sorted(f, key=lambda k: -f[k]["FETCH_SIZE"]):
     out.append("| %s | %d | %.1f | %.1f |" % (k, fc[k], 2 * f[k]["FETCH_SIZE"] / fc[k] / 1024,
                                            w[k]["WRITE_SIZE"] / max(1, wc[k]) / 1024))
 # per-family HBM bytes per launch for bench.py's roofline.traffic (read + write, FETCH_SIZE x2-corrected, KB -> bytes)
-FAMILY = {"k_scan_cluster_ks": "scan_fwd", "k_scan_cluster": "scan_fwd", "k_scan_cluster2": "scan_fwd", "k_scan_simple": "scan_fwd",
+FAMILY = {"k_scan_cluster_ks": "scan_fwd", "k_scan_cluster": "scan_fwd", "k_scan_cluster_ks_id": "scan_fwd", "k_scan_simple": "scan_fwd",
           "k_scan_fwd_mfma": "scan_fwd", "k_scan_cluster_bwd": "scan_bwd", "k_scan_bwd_mfma": "scan_bwd", "k_gemm_nn": "gemm_nn",
           "k_gemm_tn": "gemm_tn", "k_gemm_nt": "gemm_nt"}
 fam_bytes, fam_n = collections.defaultdict(float), collections.Counter()
@@ -67,8 +67,16 @@ for k in f:
         fam_bytes[fam] += (2 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"]) * 1024.0
         fam_n[fam] += fc[k]
 if fam_n:
-    import json
-    json.dump({"tag": tag, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1",
+    import subprocess
+    sys.path.insert(0, ".")
+    import mgr_amd  # noqa: F401
+    from mgr_amd._build import source_hash
+    try:
+        head = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        head = None
+    # src_sha ties the numbers to the tree they were measured on: bench.py reports `traffic` only when its own tree hashes the same
+    json.dump({"tag": tag, "src_sha": source_hash(), "head_at_summary": head, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1",
                "bytes_per_launch": {k: fam_bytes[k] / fam_n[k] for k in fam_n}},
               open("profiles/pmc_traffic.json", "w"), indent=1)
 s, sc = pmc("SQ_VALU_MFMA_BUSY_CYCLES")
