@@ -1,0 +1,161 @@
+"""-m gpu: residency by construction of the persistent multi-CU scans (lstm.hip: mgr_persist_admit, lstm_cluster.h:
+mgr_cluster_enter, mgr_stream_wait_next_resident) and the non-finite guard of the register-polling scan step."""
+import ctypes
+import time
+
+import numpy as np
+import pytest
+
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _scan_jobs(dev, rng, B, T, H, ndir=2, scale=0.1):
+    """ndir random recurrences (Z, U) on the device + their job structs; returns (jobs, outputs Y, keep-alive list)."""
+    jobs, ys, keep = [], [], []
+    for d in range(ndir):
+        Z = dev.array((rng.standard_normal((B, T, 4 * H)) * 0.5).astype(np.float32))
+        U = dev.array((rng.standard_normal((H, 4 * H)) * scale / np.sqrt(H)).astype(np.float32))
+        Up = dev.empty((H, 4 * H))
+        dev.call("mgr_lstm_pack", U, Up, H, H, 0)
+        Y = dev.zeros((B, T, H))
+        jobs.append(dict(Z=Z, Up=Up, Y=Y, ldy=H, R=0, ldr=0, gates=0, cs=0, B=B, T=T, H=H, reverse=d & 1))
+        ys.append(Y)
+        keep += [Z, U, Up]
+    return jobs, ys, keep
+
+
+def _launch(dev, jobs, ws=None):
+    from mgr_amd import _capi
+    arr = _capi.make_scan_jobs(jobs)
+    if ws is None:
+        ws = dev.bytes(dev.lib.mgr_lstm_scan_multi_ws_bytes(len(jobs), arr))
+    _capi.check(dev.lib.mgr_lstm_scan_fwd_multi(dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes))
+    return ws
+
+
+def _persist_stats(dev):
+    nl, ns = ctypes.c_int(), ctypes.c_int()
+    dev.call("mgr_persist_stats", ctypes.byref(nl), ctypes.byref(ns))
+    return nl.value, ns.value
+
+
+def test_persistent_launches_that_do_not_fit_together_are_serialised(device):
+    """Three H = 500, B = 64 bidirectional scans (256 workgroups each, two per CU = 512 slots) on three streams: two fit the chip
+    together, the third must be ordered behind them by the admission ledger instead of dead-locking with them; every launch
+    computes what it computes alone."""
+    dev = device
+    rng = np.random.default_rng(5)
+    B, T, H = 64, 300, 500
+    sets = [_scan_jobs(dev, rng, B, T, H) for _ in range(3)]
+    # reference: one after the other on one stream
+    dev.stream(0)
+    ref = []
+    for jobs, ys, _ in sets:
+        _launch(dev, jobs)
+        dev.sync()
+        ref.append([y.download() for y in ys])
+        for y in ys:
+            y.zero()
+    dev.sync()
+    n0, s0 = _persist_stats(dev)
+    wss = []
+    for i, (jobs, ys, _) in enumerate(sets):
+        dev.stream(1 + i)
+        wss.append(_launch(dev, jobs))
+    dev.stream(0)
+    dev.sync()
+    n1, s1 = _persist_stats(dev)
+    assert n1 - n0 == 3
+    assert s1 - s0 >= 1, "768 spinning workgroups were let onto 512 slots"
+    st = ctypes.c_uint(7)
+    dev.call("mgr_scan_status", ctypes.byref(st))
+    assert st.value == 0
+    for (jobs, ys, _), r in zip(sets, ref):
+        for y, yr in zip(ys, r):
+            assert np.array_equal(y.download(), yr)
+
+
+def test_wait_next_resident_releases_when_the_scan_is_resident_and_never_hangs(device):
+    dev = device
+    rng = np.random.default_rng(6)
+    jobs, ys, keep = _scan_jobs(dev, rng, 64, 200, 300)
+    ws = _launch(dev, jobs)      # warm-up (module load, attributes)
+    dev.sync()
+    # (a) the gate is enqueued BEFORE the scan it waits for (the order engine.py uses); bound 200 ms, must pass in a few
+    dev.stream(1)
+    t0 = time.perf_counter()
+    dev.call("mgr_stream_wait_next_resident", 100000)
+    dev.stream(2)
+    _launch(dev, jobs, ws)
+    dev.stream(0)
+    dev.sync()
+    assert time.perf_counter() - t0 < 0.05
+    # (b) no persistent launch follows: the gate gives up after its bound - a placement aid never blocks a stream for good
+    dev.stream(1)
+    t0 = time.perf_counter()
+    dev.call("mgr_stream_wait_next_resident", 3000)
+    dev.stream(0)
+    dev.sync()
+    dt = time.perf_counter() - t0
+    assert 0.002 < dt < 0.05, dt
+
+
+@pytest.mark.parametrize("variant", [0, 2])
+def test_non_finite_hidden_state_propagates_as_nan_instead_of_hanging(device, variant):
+    """An Inf recurrent weight makes h NaN at the first step that multiplies it.  The register-polling step marks words that
+    have not landed with a NaN pattern, so a NaN h must never be published: the cell publishes a finite value, keeps the NaN
+    in Y and raises MGR_SCAN_NONFINITE - the launch finishes in its normal time and mgr_scan_status does not fail."""
+    from mgr_amd import _capi
+    dev = device
+    rng = np.random.default_rng(7)
+    B, T, H = 20, 50, 300
+    Z = dev.array((rng.standard_normal((B, T, 4 * H)) * 0.5).astype(np.float32))
+    Uh = (rng.standard_normal((H, 4 * H)) * 0.1 / np.sqrt(H)).astype(np.float32)
+    Uh[17, 4 * 33 + 2] = np.inf
+    Up = dev.empty((H, 4 * H))
+    dev.call("mgr_lstm_pack", dev.array(Uh), Up, H, H, 0)
+    Y = dev.zeros((B, T, H))
+    ws = dev.bytes(dev.lib.mgr_lstm_scan_ws_bytes(B, T, H))
+    dev.call("mgr_scan_status_clear")
+    dev.call("mgr_tune", 0, 3)
+    dev.call("mgr_tune", 7, variant)
+    try:
+        t0 = time.perf_counter()
+        dev.call("mgr_lstm_scan_fwd", Z, Up, Y, H, 0, 0, 0, 0, B, T, H, 0, ws, ws.nbytes)
+        dev.sync()
+        assert time.perf_counter() - t0 < 0.5          # a give-up takes ~1 s
+        st = ctypes.c_uint(0)
+        dev.call("mgr_scan_status", ctypes.byref(st))  # does not raise
+        assert st.value == _capi.SCAN_NONFINITE
+        y = Y.download()
+        assert np.isnan(y).any() and not np.isnan(y[:, 0]).any()      # step 0 multiplies h_0 = 0 ... by Inf: NaN from t = 0 or 1 on
+    finally:
+        dev.call("mgr_tune", 0, 0)
+        dev.call("mgr_tune", 7, 0)
+        dev.call("mgr_scan_status_clear")
+    st = ctypes.c_uint(7)
+    dev.call("mgr_scan_status", ctypes.byref(st))
+    assert st.value == 0
+
+
+def test_engine_reports_nan_loss_for_a_diverged_encoder(device):
+    from mgr_amd.configs import fusion_spec
+    from mgr_amd.engine import Engine
+    from mgr_amd.synthetic import synthetic_arrays, synthetic_weights
+    spec = fusion_spec()
+    B, T, Lmax = 16, 40, 6
+    eng = Engine(spec, B, T, Lmax, device=device, seed=1)
+    w = synthetic_weights(spec, 3)
+    bad = {k: v.copy() for k, v in w.items()}
+    bad["the_input_audio/l0/fwd/U"][3, 5] = np.inf
+    xs, labels, il, ll = synthetic_arrays(spec, B, T, Lmax, 9, lmin=2, lmax=5)
+    eng.set_weights(bad)
+    loss = eng.train_step(xs, labels, il, ll, apply_update=False)       # no exception, no 1 s stall
+    assert np.isnan(loss) and eng.nonfinite_seen
+    eng.clear_scan_status()
+    eng.set_weights(w)
+    loss = eng.train_step(xs, labels, il, ll, apply_update=False)
+    assert np.isfinite(loss) and not eng.nonfinite_seen
+    eng.close()

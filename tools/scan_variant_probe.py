@@ -17,7 +17,7 @@ for hs in ((500,), (500, 300)):
     arr = _capi.make_scan_jobs(jobs)
     ws = dev.bytes(lib.mgr_lstm_scan_multi_ws_bytes(len(jobs), arr))
     ref = None
-    for xl in (0, 1):
+    for xl in (0, 2, 1):   # K-split (permuted unit order) | K-split (identity order) | LDS-image step
         dev.call("mgr_tune", 7, xl); dev.call("mgr_tune", 1, 1)
         _capi.check(lib.mgr_lstm_scan_fwd_multi(dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes)); dev.sync()
         dev.record(0)
