@@ -174,6 +174,9 @@ def main():
         n, ms = dev.prof_get(i)
         fam[name] = {"launches": n, "ms": round(ms, 3)}
     dev.prof_enable(0)
+    import ctypes
+    n_persist, n_serial = ctypes.c_int(), ctypes.c_int()
+    dev.call("mgr_persist_stats", ctypes.byref(n_persist), ctypes.byref(n_serial))
 
     frames = B * T * world * args.steps
     value = frames / dt
@@ -237,6 +240,7 @@ def main():
                "whole_step_frac_of_mfma_peak_algorithmic": round(whole / MFMA_F32_PEAK_TFLOPS, 5),
                "whole_step_tflops_executed": round(whole_ex, 3),
                "whole_step_frac_of_mfma_peak_executed": round(whole_ex / MFMA_F32_PEAK_TFLOPS, 5),
+               "persistent_launches": {"total": n_persist.value, "serialised_by_admission": n_serial.value},
                "loss": losses[-1], "ctc_loss_parity": parity, "kernel_ms": fam,
                "speedup_vs_cpu": round(value / cpu["value"], 1) if cpu else None}
         print(json.dumps(out))

@@ -404,7 +404,9 @@ int mgr_persist_admit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu, unsigne
   (void)waves_per_wg;
   bool ordered[MGR_MAX_PERSIST] = {};   // launches this one has been put behind
   for (;;) {
-    int shared = wgs, any_excl = per_cu == 1 ? 1 : 0, oldest = -1;
+    // launches of ONE stream run one after the other: a stream can hold at most its largest launch on the chip at a time
+    int per_stream[MGR_NUM_STREAMS] = {};
+    int any_excl = per_cu == 1 ? 1 : 0, oldest = -1;
     for (int i = 0; i < MGR_MAX_PERSIST; ++i) {
       mgr_ctx::Persist& e = c->persist[i];
       if (!e.active || ordered[i] || e.stream == c->cur) continue;   // (same stream: ordered before this launch anyway)
@@ -412,10 +414,12 @@ int mgr_persist_admit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu, unsigne
         e.active = 0;
         continue;
       }
-      shared += e.wgs;
+      per_stream[e.stream] = e.wgs > per_stream[e.stream] ? e.wgs : per_stream[e.stream];
       any_excl |= e.per_cu == 1;
       if (oldest < 0 || e.seq < c->persist[oldest].seq) oldest = i;
     }
+    int shared = wgs;
+    for (int s = 0; s < MGR_NUM_STREAMS; ++s) shared += per_stream[s];
     const int capacity = any_excl ? c->cu_count : 2 * c->cu_count;
     if (oldest < 0 || shared <= capacity) break;
     // does not fit beside what may still be running: run behind the oldest of them, then look again

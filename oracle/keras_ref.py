@@ -346,7 +346,7 @@ def _lse64(a, b):
     return m + math.log1p(math.exp(-abs(a - b)))
 
 
-def ctc_beam_search(P, input_length, beam_width=10, skip=2, blank=None, eps=1e-8, merge_repeated=True):
+def ctc_beam_search(P, input_length, beam_width=10, skip=2, blank=None, eps=1e-8, merge_repeated=True, top_paths=1):
     """CTC prefix beam search without LM (spec: K.ctc_decode(greedy=False, beam_width=10,
     top_paths=1) -> tf.nn.ctc_beam_search_decoder; BASELINE.json config 5).
     NOT present in the reference - this oracle IS the specification the HIP path matches.
@@ -358,7 +358,13 @@ def ctc_beam_search(P, input_length, beam_width=10, skip=2, blank=None, eps=1e-8
     "extend prefix r by label c".  An extension that reproduces the prefix of another
     live beam r2 is merged into r2's stay candidate (stay term first).  Candidates are
     ranked by lse(p_blank, p_nonblank) descending, ties by smaller idx; -inf dropped.
-    Returns (label lists of the best path per sample, their log-probabilities).
+    Returns (label lists of the best path per sample, their log-probabilities); with top_paths > 1 every sample's entry
+    is the ranked list of its top_paths best beams instead (tf.nn.ctc_beam_search_decoder's top_paths).
+
+    Pinned to third-party vectors (tests/golden/thirdparty_kat.json): the decoded sequences of TensorFlow's
+    ctc_decoder_ops_test.testCTCDecoderBeamSearch / Keras' backend_test.test_ctc_decode_beam (beam_width 2: the narrow beam
+    returns [1, 0] ahead of the truly most probable labelling [0, 1, 0]), and - independent of any library - to the
+    exhaustive enumeration of all C^T paths on tiny cases (tests/test_cpu_kat.py).
     """
     B, T, C = P.shape
     if blank is None:
@@ -370,7 +376,8 @@ def ctc_beam_search(P, input_length, beam_width=10, skip=2, blank=None, eps=1e-8
         beams = [((), 0.0, NEG_INF)]  # ranked: (prefix, log p_blank, log p_nonblank)
         for t in range(Tp):
             u = P[bidx, skip + t].astype(np.float64) + eps
-            logy = np.log(u) - math.log(float(u.sum()))
+            with np.errstate(divide="ignore"):      # (eps = 0 with exact zeros in P: log 0 = -inf is the intended log-zero)
+                logy = np.log(u) - math.log(float(u.sum()))
             index = {pref: r for r, (pref, _, _) in enumerate(beams)}
             cand = {}  # idx -> [prefix, pb, pnb]
             for r, (pref, pb, pnb) in enumerate(beams):
@@ -393,12 +400,15 @@ def ctc_beam_search(P, input_length, beam_width=10, skip=2, blank=None, eps=1e-8
             ranked = sorted(((-_lse64(e[1], e[2]), idx) for idx, e in cand.items()
                              if _lse64(e[1], e[2]) != NEG_INF))
             beams = [tuple(cand[idx]) for _, idx in ranked[:beam_width]]
-        pref, pb, pnb = beams[0]
-        seq = list(pref)
-        if merge_repeated:
-            seq = [k for k, _ in itertools.groupby(seq)]
-        outs.append(seq)
-        scores.append(_lse64(pb, pnb))
+        seqs, scs = [], []
+        for pref, pb, pnb in beams[:max(1, top_paths)]:
+            seq = list(pref)
+            if merge_repeated:
+                seq = [k for k, _ in itertools.groupby(seq)]
+            seqs.append(seq)
+            scs.append(_lse64(pb, pnb))
+        outs.append(seqs[0] if top_paths == 1 else seqs)
+        scores.append(scs[0] if top_paths == 1 else scs)
     return outs, scores
 
 
