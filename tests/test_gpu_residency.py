@@ -104,16 +104,18 @@ def test_wait_next_resident_releases_when_the_scan_is_resident_and_never_hangs(d
 
 @pytest.mark.parametrize("variant", [0, 2])
 def test_non_finite_hidden_state_propagates_as_nan_instead_of_hanging(device, variant):
-    """An Inf recurrent weight makes h NaN at the first step that multiplies it.  The register-polling step marks words that
-    have not landed with a NaN pattern, so a NaN h must never be published: the cell publishes a finite value, keeps the NaN
-    in Y and raises MGR_SCAN_NONFINITE - the launch finishes in its normal time and mgr_scan_status does not fail."""
+    """A NaN recurrent weight in the candidate gate makes c and h NaN at the first step that multiplies it (an Inf weight only
+    saturates a hard-sigmoid / tanh gate - finite, like in the reference).  The register-polling step marks words that have
+    not landed with a NaN pattern, so a NaN h must never be published: the cell publishes a finite value, keeps the NaN in Y and
+    raises MGR_SCAN_NONFINITE - the launch finishes in its normal time and mgr_scan_status does not fail."""
     from mgr_amd import _capi
     dev = device
     rng = np.random.default_rng(7)
     B, T, H = 20, 50, 300
     Z = dev.array((rng.standard_normal((B, T, 4 * H)) * 0.5).astype(np.float32))
     Uh = (rng.standard_normal((H, 4 * H)) * 0.1 / np.sqrt(H)).astype(np.float32)
-    Uh[17, 4 * 33 + 2] = np.inf
+    Uh[17, 2 * H + 33] = np.nan          # Keras layout: columns [2H, 3H) are the candidate gate c
+    Uh[40, 0 * H + 7] = np.inf           # ... and an Inf into an input gate only saturates it
     Up = dev.empty((H, 4 * H))
     dev.call("mgr_lstm_pack", dev.array(Uh), Up, H, H, 0)
     Y = dev.zeros((B, T, H))
@@ -130,7 +132,9 @@ def test_non_finite_hidden_state_propagates_as_nan_instead_of_hanging(device, va
         dev.call("mgr_scan_status", ctypes.byref(st))  # does not raise
         assert st.value == _capi.SCAN_NONFINITE
         y = Y.download()
-        assert np.isnan(y).any() and not np.isnan(y[:, 0]).any()      # step 0 multiplies h_0 = 0 ... by Inf: NaN from t = 0 or 1 on
+        assert not np.isnan(y[:, 0]).any()             # step 0 has no recurrent term
+        assert np.isnan(y[:, 1:, 33]).all()            # unit 33 is NaN from the first step that sees h_0
+        assert np.isfinite(y[:, :, 7]).all() or np.isnan(y[:, 2:]).any()
     finally:
         dev.call("mgr_tune", 0, 0)
         dev.call("mgr_tune", 7, 0)
@@ -149,7 +153,7 @@ def test_engine_reports_nan_loss_for_a_diverged_encoder(device):
     eng = Engine(spec, B, T, Lmax, device=device, seed=1)
     w = synthetic_weights(spec, 3)
     bad = {k: v.copy() for k, v in w.items()}
-    bad["the_input_audio/l0/fwd/U"][3, 5] = np.inf
+    bad["the_input_audio/l0/fwd/U"][3, 2 * 500 + 5] = np.nan      # candidate gate of unit 5
     xs, labels, il, ll = synthetic_arrays(spec, B, T, Lmax, 9, lmin=2, lmax=5)
     eng.set_weights(bad)
     loss = eng.train_step(xs, labels, il, ll, apply_update=False)       # no exception, no 1 s stall
