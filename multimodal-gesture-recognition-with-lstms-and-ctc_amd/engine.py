@@ -624,6 +624,11 @@ class Engine:
             self._check_scans()   # raises if a persistent scan ever gave up: results would be garbage
         finally:
             dev.stream(0)
+        if self.nonfinite_seen:
+            # a hidden state went NaN / Inf: in the reference every later op propagates the NaN into the loss.  Here a NaN
+            # feature that input dropout happens to drop is SKIPPED by the dropout-aware kernels (no 0 x NaN), so the number
+            # the device computed may look finite - report what the reference would report
+            return float("nan")
         return v
 
     @property
