@@ -1,3 +1,7 @@
+"""Forward cluster scan variants at the config-F shapes (B = 64, T = 1900), audio alone and audio + skeletal in one launch:
+  tune7 = 0  paired form (two batch groups per 8-wave workgroup, lstm_cluster_pair.hip); tune10 = 1 + issue point in eighths
+  tune7 = 3  one-group K-split step, permuted unit order      tune7 = 2  same, identity unit order      tune7 = 1  LDS-image step
+Prints ms per launch, us per time step, the launch's give-up word and the largest difference to the first variant."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np
@@ -6,6 +10,9 @@ from mgr_amd import _capi
 dev = _capi.Device(0); lib = dev.lib
 B, T = 64, 1900
 rng = np.random.default_rng(0)
+variants = [(0, 0)] + [(0, k) for k in (1, 3, 5, 7, 8, 9)] + [(3, 0), (2, 0), (1, 0)]
+if len(sys.argv) > 1 and sys.argv[1] == "short":
+    variants = [(0, 0), (3, 0)]
 for hs in ((500,), (500, 300)):
     jobs, keep = [], []
     for H in hs:
@@ -17,16 +24,19 @@ for hs in ((500,), (500, 300)):
     arr = _capi.make_scan_jobs(jobs)
     ws = dev.bytes(lib.mgr_lstm_scan_multi_ws_bytes(len(jobs), arr))
     ref = None
-    for xl in (0, 2, 1):   # K-split (permuted unit order) | K-split (identity order) | LDS-image step
-        dev.call("mgr_tune", 7, xl); dev.call("mgr_tune", 1, 1)
-        _capi.check(lib.mgr_lstm_scan_fwd_multi(dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes)); dev.sync()
-        dev.record(0)
-        for _ in range(3):
-            _capi.check(lib.mgr_lstm_scan_fwd_multi(dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes))
-        dev.record(1); dev.sync()
+    for t7, t10 in variants:
+        dev.call("mgr_tune", 7, t7); dev.call("mgr_tune", 10, t10); dev.call("mgr_tune", 1, 1)
+        try:
+            _capi.check(lib.mgr_lstm_scan_fwd_multi(dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes)); dev.sync()
+            dev.record(0)
+            for _ in range(3):
+                _capi.check(lib.mgr_lstm_scan_fwd_multi(dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes))
+            dev.record(1); dev.sync()
+        except _capi.MgrError as e:
+            print("H=%-10s tune7=%d tune10=%d : FAILED %s" % (hs, t7, t10, e)); continue
         ms = dev.elapsed_ms(0, 1) / 3
         y = keep[2].download()
         if ref is None: ref = y
-        print("H=%-10s tune7=%d : %7.3f ms  %5.2f us/step  status=%d  same=%s" % (hs, xl, ms, ms * 1e3 / T, int(ws.download().view(np.uint32)[0]), float(np.abs(y - ref).max())))
-    dev.call("mgr_tune", 7, 0)
+        print("H=%-10s tune7=%d tune10=%d : %7.3f ms  %5.2f us/step  status=%d  maxdiff=%.2e" % (hs, t7, t10, ms, ms * 1e3 / T, int(ws.download().view(np.uint32)[0]), float(np.abs(y - ref).max())), flush=True)
+    dev.call("mgr_tune", 7, 0); dev.call("mgr_tune", 10, 0); dev.call("mgr_tune", 1, 0)
     for a in keep + [ws]: a.free()
