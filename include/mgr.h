@@ -131,10 +131,8 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
  * 2 force one workgroup per batch group (no inter-CU exchange) where it fits, 3 force clusters with 4 tiles per
  * workgroup, 4 same with 8 tiles per workgroup.  key 1: !=0 makes scan_fwd check the give-up word synchronously.
  * key 2: print the scan plan.
- * key 7: multi-CU forward scans: 0 = automatic (paired form - two batch groups per 8-wave workgroup, lstm_cluster_pair.hip -
- *        where every job has an exchange, two batch groups to pair and the launch fits one workgroup per CU; else the one-group
- *        K-split step), 3 = never pair, 1 = LDS-image step, 2 = one-group K-split step with hidden units in identity order.
- * key 10: paired form: 1 + the point (in eighths of a group's MFMA chain) at which the other group's gather is issued; 0 = default.
+ * key 7: one-tile-per-wave clusters: 0 = K-split / register-direct gather step, 1 = LDS-image step, 2 = K-split step with
+ *        hidden units in identity order (cross-check of the kernel's private unit permutation).
  * key 8: 1 = the multi-CU BPTT keeps its 4-wave kernel instead of the split-role (4 compute + 4 gather waves) one, 2 = always split.
  * key 9: 1 = mgr_lstm_input_proj_dropout always takes the dense kernel. */
 enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 12 };

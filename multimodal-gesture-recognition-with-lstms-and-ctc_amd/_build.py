@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmgr.so")
 SOURCES = ["ctx.hip", "elementwise.hip", "ctc.hip", "dense.hip", "gemm.hip", "lstm_simple.hip", "lstm_mfma.hip",
-           "lstm_cluster.hip", "lstm_cluster_pair.hip", "lstm_cluster_bwd.hip", "lstm.hip", "comm.hip", "beam.hip", "skeletal.hip"]
+           "lstm_cluster.hip", "lstm_cluster_bwd.hip", "lstm.hip", "comm.hip", "beam.hip", "skeletal.hip"]
 ARCH = "gfx950"
 
 

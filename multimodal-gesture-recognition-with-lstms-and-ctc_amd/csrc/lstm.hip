@@ -238,34 +238,11 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     status = reinterpret_cast<unsigned*>(w);
     char* base = w;
     w += kScanHdrBytes;
-    // Paired form (two batch groups per 8-wave workgroup, one workgroup per CU): when every cluster job of the call has an
-    // exchange to hide, at least one of them has two batch groups to pair, and the whole launch fits one workgroup per CU.
-    // tune key 7: 0 = automatic, 3 = never pair (one-group K-split step), 1 / 2 see below.
-    bool pair = c->tune[7] == 0 && c->tune[MGR_TUNE_SCAN_PATH] == 0;
-    {
-      int tot = 0, most = 0;
-      for (int i = 0; i < njobs && pair; ++i) {
-        if (!P.cluster[i]) continue;
-        const int ks = jobs[i].H / 4, G = (ks + 3) / 4;
-        pair = G > 1 && mgr_cluster_pair_supported(ks);
-        most = std::max(most, P.nbg[i]);
-        tot += (G * ((P.nbg[i] + 1) / 2) + 7) / 8 * 8;
-      }
-      pair = pair && most >= 2 && tot <= c->cu_count;
-    }
-    int npair[MGR_MAX_SCAN_JOBS];
-    for (int i = 0; i < njobs; ++i) {
-      npair[i] = (P.nbg[i] + 1) / 2;
-      if (pair && P.cluster[i]) {
-        P.cfg[i] = kCfgs[0];
-        P.G[i] = (jobs[i].H / 4 + 3) / 4;
-      }
-    }
     int cb[MGR_MAX_SCAN_JOBS], cn[MGR_MAX_SCAN_JOBS], c0[MGR_MAX_SCAN_JOBS];
     P.total = layout_classes(
         njobs, P.cluster,
         [&](int a, int b) { return jobs[a].H == jobs[b].H && P.cfg[a].nw == P.cfg[b].nw && P.cfg[a].tpw == P.cfg[b].tpw; },
-        [&](int a) { return P.G[a]; }, pair ? npair : P.nbg, cb, cn, c0);
+        [&](int a) { return P.G[a]; }, P.nbg, cb, cn, c0);
     for (int i = 0; i < njobs; ++i) {
       if (!P.cluster[i]) continue;
       const mgr_scan_job& j = jobs[i];
@@ -280,19 +257,17 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
       cj.xbuf = reinterpret_cast<float*>(w);
       w += mgr_align_up((size_t)P.nbg[i] * 2 * img * sizeof(float), 256);
     }
-    // tune key 7: 0 / 3 = K-split step (register-direct gather, permuted unit order), 1 = LDS-image step for every cluster,
+    // tune key 7: 0 = K-split step (register-direct gather, permuted unit order), 1 = LDS-image step for every cluster,
     // 2 = K-split step with the identity unit order
-    L.ksplit = (c->tune[7] == 0 || c->tune[7] == 3) ? 1 : (c->tune[7] == 2 ? 2 : 0);
-    L.issue_at = c->tune[10] > 0 ? c->tune[10] - 1 : 5;   // tune key 10: 1 + eighths of the MFMA chain (paired form)
+    L.ksplit = c->tune[7] == 0 ? 1 : (c->tune[7] == 2 ? 2 : 0);
     if (c->tune[2]) {  // tune key 2: print the plan
       for (int i = 0; i < L.njobs; ++i)
         fprintf(stderr, "[mgr scan plan] job %d: H=%d ks=%d nw=%d tpw=%d G=%d nbg=%d wg_begin=%d\n", i, L.job[i].H,
                 L.job[i].ks, L.job[i].nw, L.job[i].tpw, L.job[i].G_, L.job[i].nbg, L.job[i].cls_begin);
-      fprintf(stderr, "[mgr scan plan] total %d workgroups, exchange=%d, paired=%d\n", P.total, (int)P.exchange, (int)pair);
+      fprintf(stderr, "[mgr scan plan] total %d workgroups, exchange=%d\n", P.total, (int)P.exchange);
     }
     int waves, per_cu;
     mgr_cluster_geometry(L, P.exchange, &waves, &per_cu);
-    if (pair) waves = 8, per_cu = 1;
     L.cm.status = status;
     L.cm.sticky = c->sticky_status;
     L.cm.total_wgs = P.total;
@@ -300,7 +275,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     if (r) return r;
     // exchange slots + status must be zero at every launch (epochs count from 1 within the call)
     MGR_HIP(hipMemsetAsync(base, 0, (size_t)(w - base), mgr_stream(c)));
-    r = pair ? mgr_cluster_pair_launch(c, L, P.total) : mgr_cluster_launch(c, L, P.total, P.exchange);
+    r = mgr_cluster_launch(c, L, P.total, P.exchange);
     if (r) return r;
     r = mgr_persist_commit(c, P.total, waves, per_cu);
     if (r) return r;

@@ -46,7 +46,6 @@ struct ClusterLaunch {
   ClusterCommon cm;
   int njobs;
   int ksplit;        // one-tile-per-wave clusters use the K-split step (cluster_run_ks): register-direct gather
-  int issue_at;      // paired form: the other group's gather leaves after this many EIGHTHS of a group's MFMA chain (0..8)
   ClusterJob job[MGR_MAX_SCAN_JOBS];
 };
 
@@ -55,9 +54,6 @@ bool mgr_cluster_supported(int ks, int tpw);
 // geometry of the launch that mgr_cluster_launch would issue: waves per workgroup, workgroups per CU
 void mgr_cluster_geometry(const ClusterLaunch& L, bool any_exchange, int* waves, int* per_cu);
 int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool any_exchange);
-// paired form (lstm_cluster_pair.hip): 8-wave workgroups, one per CU, two batch groups each; clusters of a class are PAIRS
-bool mgr_cluster_pair_supported(int ks);
-int mgr_cluster_pair_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs);
 
 // ---- backward (lstm_cluster_bwd.hip)
 struct ClusterBwdJob {
