@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the next step's frozen-encoder pass")
     ap.add_argument("--scan-path", type=int, default=0, help="0 auto, 3/4 clusters of 4/8 tiles per workgroup")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-transposed", action="store_true", help="dropout-aware projections gather columns of the row-major input")
     ap.add_argument("--cpu-T", type=int, default=400)
     ap.add_argument("--cpu-B", type=int, default=64)
     ap.add_argument("--comm", choices=("rccl", "host"), default="rccl",
@@ -137,7 +138,9 @@ def main():
             from mgr_amd.parallel import tcp_bootstrap
             comm = RcclComm(dev, rank, world, tcp_bootstrap(rank, world))
 
-    eng = Engine(spec, B, T, Lmax, device=dev, seed=1000 + rank, comm=comm, world=world)
+    from mgr_amd.engine import Schedule
+    eng = Engine(spec, B, T, Lmax, device=dev, seed=1000 + rank, comm=comm, world=world,
+                 schedule=Schedule(transposed_inputs=not args.no_transposed))
     eng.set_weights(synthetic_weights(spec, 20131900 + 3))
     xs, labels, il, ll = synthetic_arrays(spec, B, T, Lmax, 20131900 + 3 + 17 * rank)
     eng._upload_inputs(xs, None, True)

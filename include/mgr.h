@@ -104,6 +104,15 @@ size_t mgr_lstm_input_proj_dropout_ws_bytes(int B, int F, int H);
 int mgr_lstm_input_proj_dropout(mgr_ctx* ctx, const float* X, int ldx, const float* mask4, float drop_rate,
                                 const float* Wp, const float* bp, float* Z, int B, int T, int F, int H, void* ws,
                                 size_t ws_bytes);
+/* The same projection from a TRANSPOSED copy of the layer input, XT[b][f][t] with row stride ldt (T padded to a multiple of
+ * 128, zeros behind T; mgr_transpose_bt writes it): a kept feature is then a contiguous row, and the kernel's A operand is
+ * staged with coalesced 16-byte loads instead of one scattered 4-byte load per element.  Only for shapes the dropout-aware
+ * kernel handles - mgr_lstm_input_proj_dropout_wants_transposed says whether a copy is worth making for (drop_rate, F). */
+int mgr_lstm_input_proj_dropout_wants_transposed(mgr_ctx* ctx, float drop_rate, int F);
+int mgr_lstm_input_proj_dropout_t(mgr_ctx* ctx, const float* XT, int ldt, const float* mask4, float drop_rate,
+                                  const float* Wp, const float* bp, float* Z, int B, int T, int F, int H, void* ws,
+                                  size_t ws_bytes);
+int mgr_transpose_bt(mgr_ctx* ctx, const float* X, int ldx, float* XT, int ldt, int B, int T, int F);
 /* Recurrence. reverse=1 walks t = T-1..0 and writes outputs at their original t (Bidirectional backward
  * sub-layer).  Y[b,t,0:H] with row stride ldy gets h_t (+ R[b,t,0:H] with stride ldr when R != NULL: the
  * residual add / concat fusion of multimodal.py:111,117,155).  gates [B,T,H,4] (i,f,g,o after activation) and

@@ -393,7 +393,10 @@ constexpr int SP_TM = 128, SP_SK = 16;   // tile: 128 rows x (32 WC) units x 4 g
 // 4-byte global load.
 // WC = waves along the units: 2 (256 threads, 64 units, two workgroups per CU) or 4 (512 threads, 128 units, one per CU:
 // the X tile is shared by twice the units, i.e. half the A-operand traffic per FLOP).
-template <int WC>
+// TR: X is the TRANSPOSED activation copy XT[b][f][t] (row stride ldx = padded T, mgr_transpose_bt): a kept feature is then a
+// contiguous ROW of 128 time steps and the A stage is two coalesced float4 loads per thread that go to LDS as they are (the LDS
+// image is k-major already), instead of eight scattered 4-byte loads that fetch a 128-byte line for 64 useful bytes.
+template <int WC, bool TR>
 __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_gemm_nn_sparse(const float* __restrict__ X, int ldx, const int* __restrict__ kidx,
                                                         const float* __restrict__ kval, const int* __restrict__ kcnt,
                                                         const float* __restrict__ Wp, const float* __restrict__ bp,
@@ -403,13 +406,15 @@ __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_gemm_nn_sparse(co
   constexpr int ARS = NT / 16;        // rows covered by one pass of the threads over the A stage
   constexpr int BPT = SK * TU / NT;   // B elements per thread and stage
   constexpr int BKS = NT / TU;        // k rows covered by one pass of the threads over the B stage
-  __shared__ float As[2][SK][TM + 4];
+  __shared__ __attribute__((aligned(16))) float As[2][SK][TM + 4];
   __shared__ float Bs[2][SK][TU + 4];
   __shared__ int Ls[SP_MAXF];
   __shared__ float Vs[SP_MAXF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave / WC, wc = wave % WC;
   const int N = 4 * H;
-  const int ak = tid & 15, ar = tid >> 4;   // A staging: this thread's k within the stage, its first row (then +ARS, ...)
+  const int ak = TR ? tid / (TM / 8) : tid & 15;   // A staging: this thread's k within the stage ...
+  const int ar = TR ? (tid % (TM / 8)) * 4 : tid >> 4;   // ... and its first row (TR: rows ar..ar+3 and 64+ar..; else ar, ar+ARS, ...)
+  static_assert(!TR || (NT / (TM / 8) == SK && APT == 8), "transposed A stage: 16 k x (2 float4 per thread)");
   const int bu = tid % TU, bk = tid / TU;   // B staging: this thread's unit, its first k (then +BKS, ...)
   const int l31 = lane & 31, lh = lane >> 5;
   const int ncol = (H + TU - 1) / TU, nrow = (T + TM - 1) / TM;
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_gemm_nn_sparse(co
     const int rt = (jj / ncol) * 8 + x;   // linear (sample, row tile)
     if (rt >= nrow * B) return;
     const int u0 = (jj % ncol) * TU, r0 = (rt % nrow) * TM, b = rt / nrow;
-    const float* Xb = X + (size_t)b * T * ldx;
+    const float* Xb = TR ? X + (size_t)b * F * ldx + r0 + ar : X + (size_t)b * T * ldx;
     const int ucl = (u0 + bu < H) ? u0 + bu : H - 1;
     f32x16 acc[4][2];
 #pragma unroll
@@ -453,9 +458,16 @@ __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_gemm_nn_sparse(co
       __syncthreads();
       const float* Wg = Wp + (size_t)g * F * H + ucl;   // (Wp: the gate-major copy [4][F][H])
       auto fetch = [&](Regs& r, int st) {
-        const float* xp = Xb + Ls[st * SK + ak];
+        if constexpr (TR) {
+          const float* xp = Xb + (size_t)Ls[st * SK + ak] * ldx;   // (rows beyond T: the copy is padded to whole row tiles)
+          const float4 v0 = *reinterpret_cast<const float4*>(xp), v1 = *reinterpret_cast<const float4*>(xp + 64);
+          r.a[0] = v0.x; r.a[1] = v0.y; r.a[2] = v0.z; r.a[3] = v0.w;
+          r.a[4] = v1.x; r.a[5] = v1.y; r.a[6] = v1.z; r.a[7] = v1.w;
+        } else {
+          const float* xp = Xb + Ls[st * SK + ak];
 #pragma unroll
-        for (int i = 0; i < APT; ++i) r.a[i] = xp[arow[i]];
+          for (int i = 0; i < APT; ++i) r.a[i] = xp[arow[i]];
+        }
 #pragma unroll
         for (int j = 0; j < BPT; ++j) {
           const int q = st * SK + bk + BKS * j;
@@ -464,8 +476,13 @@ __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_gemm_nn_sparse(co
         }
       };
       auto stash = [&](const Regs& r, int buf) {
+        if constexpr (TR) {
+          *reinterpret_cast<float4*>(&As[buf][ak][ar]) = make_float4(r.a[0], r.a[1], r.a[2], r.a[3]);
+          *reinterpret_cast<float4*>(&As[buf][ak][64 + ar]) = make_float4(r.a[4], r.a[5], r.a[6], r.a[7]);
+        } else {
 #pragma unroll
-        for (int i = 0; i < APT; ++i) As[buf][ak][ar + ARS * i] = r.a[i];
+          for (int i = 0; i < APT; ++i) As[buf][ak][ar + ARS * i] = r.a[i];
+        }
 #pragma unroll
         for (int j = 0; j < BPT; ++j) Bs[buf][bk + BKS * j][bu] = r.w[j] * r.v[j];
       };
@@ -897,16 +914,19 @@ size_t mgr_lstm_input_proj_dropout_ws_bytes(int B, int F, int H) {
          mgr_align_up((size_t)F * 4 * H * sizeof(float), 256);
 }
 
-int mgr_lstm_input_proj_dropout(mgr_ctx* c, const float* X, int ldx, const float* mask4, float drop_rate, const float* Wp,
-                                const float* bp, float* Z, int B, int T, int F, int H, void* ws, size_t ws_bytes) {
-  MGR_REQUIRE(c && X && Wp && bp && Z, "null argument");
-  MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0 && ldx >= F, "bad shape");
+static bool sparse_proj_shape(const mgr_ctx* c, float drop_rate, int F) {
   // the per-gate K loops pay when enough features are dropped; at small F (depth-1 layers, F = 39 / 20) the GEMM is bound
   // by the Z stores and the float4 epilogue of this kernel is what helps (0.39 / 0.18 ms against 0.47 / 0.24)
-  const bool sparse = mask4 && drop_rate >= 0.3f && F >= 16 && F <= SP_MAXF && (size_t)T * ldx < (1u << 31) &&
-                      c->tune[9] == 0 && aligned16(bp) && aligned16(Z) && aligned16(Wp);
-  if (!sparse) return mgr_lstm_input_proj(c, X, ldx, mask4, Wp, bp, Z, B, T, F, H);
-  MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_input_proj_dropout_ws_bytes(B, F, H), "workspace too small");
+  return drop_rate >= 0.3f && F >= 16 && F <= SP_MAXF && c->tune[9] == 0;
+}
+
+int mgr_lstm_input_proj_dropout_wants_transposed(mgr_ctx* c, float drop_rate, int F) {
+  // the transposed copy pays where the A operand dominates the staging traffic: wide inputs (depth-2 / fusion layers)
+  return (c && sparse_proj_shape(c, drop_rate, F) && F >= 128) ? 1 : 0;
+}
+
+static int input_proj_dropout_impl(mgr_ctx* c, const float* X, int ldx, bool transposed, const float* mask4, float drop_rate,
+                                   const float* Wp, const float* bp, float* Z, int B, int T, int F, int H, void* ws, size_t ws_bytes) {
   const int Fp = (F + SP_SK - 1) / SP_SK * SP_SK;
   const size_t lbytes = mgr_align_up((size_t)4 * B * Fp * sizeof(int), 256);
   char* w = reinterpret_cast<char*>(ws);
@@ -925,15 +945,72 @@ int mgr_lstm_input_proj_dropout(mgr_ctx* c, const float* X, int ldx, const float
   // 128-unit tiles (tune key 11 = 2) are faster alone (audio L2 2.77 against 3.03 ms) but slower in the training step
   // (39.7 against 38.5 ms/step): a 512-thread workgroup needs two free wave slots on all four SIMDs of a CU at once and
   // gets in the way of the BPTT scan and the small kernels of the other stream
-  const bool wide = c->tune[11] == 2;
+  const bool wide = c->tune[11] == 2 && !transposed;
   const int tu = wide ? 128 : 64;
   const int ntiles = ((H + tu - 1) / tu) * ((((T + SP_TM - 1) / SP_TM) * B + 7) / 8) * 8;   // (row tiles padded to the 8 XCDs)
-  if (wide)
-    hipLaunchKernelGGL(k_gemm_nn_sparse<4>, dim3(ntiles), dim3(512), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H);
+  if (transposed)
+    hipLaunchKernelGGL((k_gemm_nn_sparse<2, true>), dim3(ntiles), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H);
+  else if (wide)
+    hipLaunchKernelGGL((k_gemm_nn_sparse<4, false>), dim3(ntiles), dim3(512), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H);
   else
-    hipLaunchKernelGGL(k_gemm_nn_sparse<2>, dim3(ntiles), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H);
+    hipLaunchKernelGGL((k_gemm_nn_sparse<2, false>), dim3(ntiles), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H);
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_GEMM_NN);
+  return 0;
+}
+
+int mgr_lstm_input_proj_dropout(mgr_ctx* c, const float* X, int ldx, const float* mask4, float drop_rate, const float* Wp,
+                                const float* bp, float* Z, int B, int T, int F, int H, void* ws, size_t ws_bytes) {
+  MGR_REQUIRE(c && X && Wp && bp && Z, "null argument");
+  MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0 && ldx >= F, "bad shape");
+  const bool sparse = mask4 && sparse_proj_shape(c, drop_rate, F) && (size_t)T * ldx < (1u << 31) && aligned16(bp) && aligned16(Z) &&
+                      aligned16(Wp);
+  if (!sparse) return mgr_lstm_input_proj(c, X, ldx, mask4, Wp, bp, Z, B, T, F, H);
+  MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_input_proj_dropout_ws_bytes(B, F, H), "workspace too small");
+  return input_proj_dropout_impl(c, X, ldx, false, mask4, drop_rate, Wp, bp, Z, B, T, F, H, ws, ws_bytes);
+}
+
+int mgr_lstm_input_proj_dropout_t(mgr_ctx* c, const float* XT, int ldt, const float* mask4, float drop_rate, const float* Wp,
+                                  const float* bp, float* Z, int B, int T, int F, int H, void* ws, size_t ws_bytes) {
+  MGR_REQUIRE(c && XT && mask4 && Wp && bp && Z, "null argument");
+  MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0, "bad shape");
+  MGR_REQUIRE(ldt % 4 == 0 && ldt >= (T + SP_TM - 1) / SP_TM * SP_TM, "the transposed copy must be padded to whole row tiles of %d (ldt %d, T %d)", SP_TM, ldt, T);
+  MGR_REQUIRE(sparse_proj_shape(c, drop_rate, F), "shape / drop rate not handled by the dropout-aware kernel (ask mgr_lstm_input_proj_dropout_wants_transposed)");
+  MGR_REQUIRE(aligned16(XT) && aligned16(bp) && aligned16(Z) && aligned16(Wp), "XT / bp / Z / Wp must be 16-byte aligned");
+  MGR_REQUIRE((size_t)F * ldt < (1u << 31), "sample block too large");
+  MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_input_proj_dropout_ws_bytes(B, F, H), "workspace too small");
+  return input_proj_dropout_impl(c, XT, ldt, true, mask4, drop_rate, Wp, bp, Z, B, T, F, H, ws, ws_bytes);
+}
+
+// XT[b][f][0..ldt) = X[b][0..T)[f], zero for t >= T (ldt: T padded to whole row tiles of the dropout-aware projection)
+namespace {
+__global__ __launch_bounds__(256) void k_transpose_bt(const float* __restrict__ X, int ldx, float* __restrict__ XT, int ldt, int T, int F) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, t0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+  const float* Xb = X + (size_t)b * T * ldx;
+  float* XTb = XT + (size_t)b * F * ldt;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int t = t0 + ty + 4 * i, f = f0 + tx;
+    tile[ty + 4 * i][tx] = (t < T && f < F) ? Xb[(size_t)t * ldx + f] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int f = f0 + ty + 4 * i, t = t0 + tx;
+    if (f < F && t < ldt) XTb[(size_t)f * ldt + t] = tile[tx][ty + 4 * i];
+  }
+}
+}  // namespace
+
+int mgr_transpose_bt(mgr_ctx* c, const float* X, int ldx, float* XT, int ldt, int B, int T, int F) {
+  MGR_REQUIRE(c && X && XT, "null argument");
+  MGR_REQUIRE(B > 0 && T > 0 && F > 0 && ldx >= F && ldt >= T, "bad shape");
+  mgr_prof_begin(c, MGR_K_MISC);
+  hipLaunchKernelGGL(k_transpose_bt, dim3((ldt + 63) / 64, (F + 63) / 64, B), dim3(256), 0, mgr_stream(c), X, ldx, XT, ldt, T, F);
+  MGR_LAUNCH_CHECK();
+  mgr_prof_end(c, MGR_K_MISC);
   return 0;
 }
 

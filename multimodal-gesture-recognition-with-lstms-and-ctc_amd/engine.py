@@ -78,11 +78,14 @@ class Schedule:
                         step n+1 are done and then run beside its deepest encoder scan (GEMM beside GEMM gains nothing)
     encoders_run_ahead  the encoder stream does not wait for the previous step as a whole: only the scan that overwrites
                         the FEAT buffer that step's dW GEMMs read waits for it
+    transposed_inputs   keep a transposed copy of the inputs of the wide dropout layers for the dropout-aware projection GEMMs
     resident_wait_us    upper bound of the device-side wait that lets the deepest encoder scan become resident before the
                         deferred GEMMs are released (mgr_stream_wait_next_resident); 0 = no wait
     """
 
-    def __init__(self, pipeline=True, defer_param_grads=True, encoders_run_ahead=True, resident_wait_us=2000):
+    def __init__(self, pipeline=True, defer_param_grads=True, encoders_run_ahead=True, resident_wait_us=2000,
+                 transposed_inputs=True):
+        self.transposed_inputs = bool(transposed_inputs)
         self.pipeline = bool(pipeline)
         self.defer_param_grads = bool(defer_param_grads)
         self.encoders_run_ahead = bool(encoders_run_ahead)
@@ -197,6 +200,20 @@ class Engine:
         self._feat_ring = [self.FEAT]
         if train and self.can_pipeline:
             self._feat_ring.append(dev.empty((B, T, W)))   # second FEAT buffer for cross-step pipelining
+        # Transposed copies [B, features, T padded to 128] of the inputs of the WIDE dropout layers (depth-2 encoder layers, the
+        # fusion layer): the dropout-aware projection gathers kept FEATURES, which are contiguous rows there (gemm.hip,
+        # k_gemm_nn_sparse<.., true>).  Row-major stays what everything else reads (dW GEMMs, residual adds, dense layer).
+        self.ldt = (T + 127) // 128 * 128
+        self.Y1T = {}
+        self._featT = {}
+        if train and self.schedule.transposed_inputs:
+            want = lambda p, F: bool(self.lib.mgr_lstm_input_proj_dropout_wants_transposed(self.dev.ctx, C.c_float(float(p)), int(F)))
+            for s in sp.streams:
+                if len(s["layers"]) == 2 and want(s["layers"][1]["dropout"], 2 * s["layers"][0]["H"]):
+                    self.Y1T[s["name"]] = dev.zeros((B, 2 * s["layers"][0]["H"], self.ldt))
+            if sp.fusion and want(sp.fusion["dropout"], W):
+                for fb in self._feat_ring:
+                    self._featT[fb.ptr] = dev.zeros((B, W, self.ldt))
         self._feat_idx = 0
         self._prefetched = None
         self._prefetched_for = None
@@ -339,15 +356,22 @@ class Engine:
         self.Xin = self._xin_ring[slot]
         dev.stream(stream)
 
-    def _project_pair(self, X, ldx, pair, Ls, B, T, fin, H):
+    def _project_pair(self, X, ldx, pair, Ls, B, T, fin, H, XT=None):
         """Input projections of the two directions of one Bidirectional layer (pair = [mask, Wp, bp, Z] x 2).  With input
-        dropout active the library runs each direction's K loops over the kept features only (from p >= 0.3 on);
-        otherwise both directions go through one call that fuses them into one GEMM where that saves tiles."""
+        dropout active the library runs each direction's K loops over the kept features only (from p >= 0.3 on) - from the
+        transposed copy XT of the input where the engine keeps one; otherwise both directions go through one call that fuses
+        them into one GEMM where that saves tiles."""
         if pair[0] and Ls[0].ws_sp is not None:
+            if XT is not None:
+                self.dev.call("mgr_transpose_bt", X, ldx, XT, self.ldt, B, T, fin)
             for d in range(2):
                 m, Wp, bp, Z = pair[4 * d:4 * d + 4]
                 ws = Ls[d].ws_sp
-                self.dev.call("mgr_lstm_input_proj_dropout", X, ldx, m, float(Ls[d].p), Wp, bp, Z, B, T, fin, H, ws, ws.nbytes)
+                if XT is not None:
+                    self.dev.call("mgr_lstm_input_proj_dropout_t", XT, self.ldt, m, float(Ls[d].p), Wp, bp, Z, B, T, fin, H,
+                                  ws, ws.nbytes)
+                else:
+                    self.dev.call("mgr_lstm_input_proj_dropout", X, ldx, m, float(Ls[d].p), Wp, bp, Z, B, T, fin, H, ws, ws.nbytes)
         else:
             self.dev.call("mgr_lstm_input_proj_pair", X, ldx, *pair, B, T, fin, H)
 
@@ -438,7 +462,7 @@ class Engine:
                     mptr = self._prep_mask(L, train, rand, slot)
                     self._masks[(L.prefix, L.d)] = mptr
                     pair += [mptr, L.Wp, L.bp, self.Zbuf[name][di]]
-                self._project_pair(cur, ldcur, pair, Ls_pair, B, T, fin, H)
+                self._project_pair(cur, ldcur, pair, Ls_pair, B, T, fin, H, XT=self.Y1T.get(name) if k == 1 else None)
                 for di, dname in enumerate(("fwd", "bwd")):
                     L = self.dirs["%s/l%d/%s" % (name, k, dname)]
                     Z = self.Zbuf[name][di]
@@ -493,7 +517,7 @@ class Engine:
                 mptr = self._prep_mask(L, train, rand, 500 + di)
                 self._masks[(L.prefix, L.d)] = mptr
                 pair += [mptr, L.Wp, L.bp, self.ZF[di]]
-            self._project_pair(feat_buf, W, pair, Ls_pair, B, T, W, Hf)
+            self._project_pair(feat_buf, W, pair, Ls_pair, B, T, W, Hf, XT=self._featT.get(feat_buf.ptr))
             dev.record(self.EV_FPROJ)   # (the next step's depth-1 scan is launched after these GEMMs, _enqueue_next_encoders)
             for di, dname in enumerate(("fwd", "bwd")):
                 L = self.dirs["fusion/%s" % dname]

@@ -460,6 +460,21 @@ def test_input_proj_dropout_sparse_equals_dense(device, B, T, F, H, p):
     tol = 2e-5 * max(1.0, np.abs(ref).max())
     assert np.abs(sparse.download() - ref).max() <= tol
     assert np.abs(sparse.download() - dense.download()).max() <= tol
+    # the same kernel fed from the TRANSPOSED copy of X (rows of 128 time steps instead of gathered columns): mgr_transpose_bt
+    # writes XT[b][f][t] padded to whole row tiles; the LDS images - hence every sum - are the same, bit for bit
+    if 0.3 <= p and 16 <= F:
+        ldt = (T + 127) // 128 * 128
+        XT = dev.empty((B, F, ldt))
+        XT.upload(np.full((B, F, ldt), np.nan, f32))     # the transpose must write the padding too
+        dev.call("mgr_transpose_bt", dX, F, XT, ldt, B, T, F)
+        xt = XT.download()
+        assert np.array_equal(xt[:, :, :T], X.transpose(0, 2, 1)) and np.all(xt[:, :, T:] == 0)
+        tr = dev.empty((B, T, N))
+        dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, dM, 0.5, dW, db, tr, B, T, F, H, ws, ws.nbytes)
+        assert np.array_equal(tr.download(), sparse.download())
+    assert dev.lib.mgr_lstm_input_proj_dropout_wants_transposed(dev.ctx, 0.5, 1000) == 1
+    assert dev.lib.mgr_lstm_input_proj_dropout_wants_transposed(dev.ctx, 0.5, 39) == 0
+    assert dev.lib.mgr_lstm_input_proj_dropout_wants_transposed(dev.ctx, 0.1, 1000) == 0
 
 
 @pytest.mark.parametrize("B,T,F,H,p,reverse", [(3, 130, 128, 100, 0.5, 0), (2, 300, 1600, 100, 0.5, 1), (2, 77, 1000, 130, 0.5, 0),

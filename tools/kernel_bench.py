@@ -32,6 +32,17 @@ def gemm(dev, B, T, F, H, mask=True):
     ms = timeit(dev, lambda: dev.call("mgr_lstm_input_proj", X, F, m, Wp, bp, Z, B, T, F, H))
     fl = 2.0 * B * T * F * 4 * H
     print("gemm_nn  B=%d T=%d F=%4d H=%3d mask=%d : %7.3f ms  %6.1f TF" % (B, T, F, H, mask, ms, fl / ms / 1e9))
+    if mask and F >= 16:
+        wsd = dev.bytes(dev.lib.mgr_lstm_input_proj_dropout_ws_bytes(B, F, H))
+        ms = timeit(dev, lambda: dev.call("mgr_lstm_input_proj_dropout", X, F, m, 0.5, Wp, bp, Z, B, T, F, H, wsd, wsd.nbytes))
+        print("  dropout-aware (gathered columns)        : %7.3f ms  %6.1f TF executed" % (ms, 0.5 * fl / ms / 1e9))
+        ldt = (T + 127) // 128 * 128
+        XT = dev.zeros((B, F, ldt))
+        mt = timeit(dev, lambda: dev.call("mgr_transpose_bt", X, F, XT, ldt, B, T, F))
+        ms = timeit(dev, lambda: dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, m, 0.5, Wp, bp, Z, B, T, F, H, wsd, wsd.nbytes))
+        print("  dropout-aware (transposed copy)         : %7.3f ms  %6.1f TF executed  (+ transpose %.3f ms, %.0f GB/s)"
+              % (ms, 0.5 * fl / ms / 1e9, mt, 2.0 * B * T * F * 4 / mt / 1e6))
+        XT.free(); wsd.free()
     dZ = Z
     gW, gU, gb = dev.empty((F, 4 * H)), dev.empty((H, 4 * H)), dev.empty((4 * H,))
     Y = dev.array(rng.standard_normal((B, T, H)).astype(np.float32))

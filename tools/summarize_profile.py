@@ -75,8 +75,11 @@ if fam_n:
         head = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
     except OSError:
         head = None
-    # src_sha ties the numbers to the tree they were measured on: bench.py reports `traffic` only when its own tree hashes the same
-    json.dump({"tag": tag, "src_sha": source_hash(), "head_at_summary": head, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1",
+    # src_sha ties the numbers to the tree they were measured on (written on the GPU box by profile_round.sh): bench.py reports
+    # `traffic` only when its own tree hashes the same
+    sha_file = "%s/%s_src_sha.txt" % (G, tag)
+    src_sha = open(sha_file).read().strip() if os.path.exists(sha_file) else source_hash()
+    json.dump({"tag": tag, "src_sha": src_sha, "head_at_summary": head, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1",
                "bytes_per_launch": {k: fam_bytes[k] / fam_n[k] for k in fam_n}},
               open("profiles/pmc_traffic.json", "w"), indent=1)
 s, sc = pmc("SQ_VALU_MFMA_BUSY_CYCLES")
