@@ -882,10 +882,11 @@ class Engine:
         lr_t = lr_k * math.sqrt(1.0 - o["beta_2"] ** t) / (1.0 - o["beta_1"] ** t)
         dev.call("mgr_adam_step", self.params, self.grads, self.m, self.v, self.n_train, lr_t, o["beta_1"],
                  o["beta_2"], o["epsilon"], o["clipvalue"] or 0.0, gscale)
-        if o.get("maxnorm"):
-            for name, (off, n, shape, kind) in self.seg.items():
-                if kind == "kernel":
-                    dev.call("mgr_maxnorm_cols", self.params.view(off, (n,)), shape[0], shape[1], float(o["maxnorm"]), 1e-7)
+        for name, (off, n, shape, kind) in self.seg.items():
+            if kind == "kernel":
+                mv = self.spec.kernel_maxnorm(name.rsplit("/", 2)[0])   # "<prefix>/<fwd|bwd>/W" -> "<prefix>"
+                if mv > 0:
+                    dev.call("mgr_maxnorm_cols", self.params.view(off, (n,)), shape[0], shape[1], mv, 1e-7)
         self.iterations += 1
 
     def close(self):

@@ -62,6 +62,7 @@ def _walk_keras_graph(cfg):
             if float(inner.get("recurrent_dropout", 0.0)) != 0.0:
                 raise ValueError("recurrent_dropout is not used by the reference and not implemented (%s)" % name)
             t = _T("bilstm", ins, H=int(inner["units"]), dropout=float(inner.get("dropout", 0.0)),
+                   maxnorm=_kernel_maxnorm(inner, name),
                    # the reference renames the wrappers of the transplanted encoders (multimodal.py:123-130); an
                    # auto-named wrapper ("bidirectional_N") is identified by its inner LSTM's name instead
                    name=inner.get("name", name) if name.startswith("bidirectional_") else name, wrapper=name,
@@ -88,6 +89,25 @@ def _walk_keras_graph(cfg):
     if pending:
         raise ValueError("unresolvable inbound nodes for layers %s" % [l.get("name") for l in pending])
     return out
+
+
+def _kernel_maxnorm(inner, name):
+    """kernel_constraint of an LSTM config -> max-norm value (0.0 = unconstrained).  The reference constrains every LSTM input
+    kernel with maxnorm(3) over axis 0 (multimodal.py:162, speech_lstm_ctc_words.py:60); anything else is refused rather than
+    silently replaced."""
+    kc = inner.get("kernel_constraint")
+    if kc is None:
+        return 0.0
+    cls = kc.get("class_name") if isinstance(kc, dict) else kc
+    cfg = kc.get("config", {}) if isinstance(kc, dict) else {}
+    if cls not in ("MaxNorm", "max_norm", "maxnorm"):
+        raise ValueError("kernel_constraint %r of layer %s is not implemented (only MaxNorm)" % (cls, name))
+    if int(cfg.get("axis", 0)) != 0:
+        raise ValueError("MaxNorm over axis %r (layer %s) is not implemented (the reference uses axis 0)" % (cfg.get("axis"), name))
+    for other in ("recurrent_constraint", "bias_constraint"):
+        if inner.get(other) is not None:
+            raise ValueError("%s of layer %s is not implemented" % (other, name))
+    return float(cfg.get("max_value", 2))
 
 
 def _parse_stream(t):
@@ -128,7 +148,8 @@ def _parse_stream(t):
     else:
         raise ValueError("unsupported stream input %s" % base.op)
     s.update({"noise": noise, "residual": residual, "trainable": all(c.kw["trainable"] for c in chain),
-              "layers": [{"H": c.kw["H"], "dropout": c.kw["dropout"], "name": c.kw["name"]} for c in chain]})
+              "layers": [{"H": c.kw["H"], "dropout": c.kw["dropout"], "name": c.kw["name"], "maxnorm": c.kw["maxnorm"]}
+                         for c in chain]})
     return s
 
 
@@ -153,7 +174,7 @@ def spec_from_keras_json(text):
     fusion = None
     is_late = t.op == "bilstm" and t.args[0].op == "concat" and any(m.op in ("add", "bilstm") for m in t.args[0].args)
     if is_late:
-        fusion = {"H": t.kw["H"], "dropout": t.kw["dropout"], "name": t.kw["name"]}
+        fusion = {"H": t.kw["H"], "dropout": t.kw["dropout"], "name": t.kw["name"], "maxnorm": t.kw["maxnorm"]}
         streams = [_parse_stream(m) for m in t.args[0].args]
     else:
         streams = [_parse_stream(t)]

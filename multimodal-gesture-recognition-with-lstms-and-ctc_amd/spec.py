@@ -71,6 +71,17 @@ class NetworkSpec:
         if self.fusion:
             yield ("fusion", self.concat_width, self.fusion["H"], self.fusion["dropout"], True)
 
+    def kernel_maxnorm(self, prefix):
+        """Max-norm (over axis 0, per column) of the input kernel of the Bidirectional layer `prefix` ("<stream>/l<k>" or
+        "fusion"); 0.0 = unconstrained.  A layer's own "maxnorm" entry (set when the model came from a Keras JSON) wins over
+        the optimizer-wide default, which is what the reference's builders use for every LSTM (maxnorm(3))."""
+        lay = self.fusion if prefix == "fusion" else None
+        if lay is None:
+            sname, k = prefix.rsplit("/l", 1)
+            lay = next(s for s in self.streams if s["name"] == sname)["layers"][int(k)]
+        v = lay.get("maxnorm")
+        return float(self.optimizer.get("maxnorm") or 0.0) if v is None else float(v)
+
     def weight_table(self):
         """Ordered (name, keras_shape, trainable, kind) - Keras weight-list order: fwd W,U,b then bwd W,U,b."""
         out = []

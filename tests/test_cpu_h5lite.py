@@ -186,6 +186,8 @@ def _same_network(a, b):
     for d in (da, db):
         d.pop("name")
         d.pop("optimizer")              # the optimizer is not part of a Keras model JSON
+        for lay in [l for s in d["streams"] for l in s["layers"]] + ([d["fusion"]] if d.get("fusion") else []):
+            lay.pop("maxnorm", None)    # (a JSON carries the constraint per layer, the builders use the optimizer-wide default)
     return da == db
 
 
@@ -200,6 +202,19 @@ def test_keras_json_to_spec():
     assert _same_network(spec, configs.early_fusion_spec())
     with pytest.raises(ValueError, match="not on the reference"):
         keras_io.spec_from_keras_json(_wrap([_k_input("x", [10, 3]), _k_layer("Conv1D", "c", {}, ["x"])], ["x"]))
+    # kernel_constraint is read per layer (the reference: MaxNorm(3, axis 0) on every LSTM kernel), not assumed
+    spec, _, _ = keras_io.spec_from_keras_json(keras_json_fusion())
+    assert spec.kernel_maxnorm("fusion") == 3.0 and spec.kernel_maxnorm("the_input_audio/l1") == 3.0
+    d = json.loads(keras_json_unimodal(T=30, F=5, H=3, C=4, lab=6))
+    lstm_cfgs = [l["config"]["layer"]["config"] for l in d["config"]["layers"] if l["class_name"] == "Bidirectional"]
+    lstm_cfgs[0]["kernel_constraint"] = None
+    lstm_cfgs[1]["kernel_constraint"]["config"]["max_value"] = 1.5
+    spec, _, _ = keras_io.spec_from_keras_json(json.dumps(d))
+    assert spec.kernel_maxnorm("the_input/l0") == 0.0 and spec.kernel_maxnorm("the_input/l1") == 1.5
+    assert configs.audio_spec().kernel_maxnorm("the_input/l0") == 3.0          # builders: the optimizer-wide default
+    lstm_cfgs[1]["kernel_constraint"] = {"class_name": "UnitNorm", "config": {"axis": 0}}
+    with pytest.raises(ValueError, match="only MaxNorm"):
+        keras_io.spec_from_keras_json(json.dumps(d))
 
 
 def test_model_hdf5_checkpoint_round_trip(tmp_path):

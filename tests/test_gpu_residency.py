@@ -163,3 +163,62 @@ def test_engine_reports_nan_loss_for_a_diverged_encoder(device):
     loss = eng.train_step(xs, labels, il, ll, apply_update=False)
     assert np.isfinite(loss) and not eng.nonfinite_seen
     eng.close()
+
+
+def test_scan_speed_cannot_be_halved_by_launch_order(device):
+    """Provocation of the placement effect of round 1 (a persistent cluster scan launched while chip-filling GEMM waves of
+    another stream were resident got a lopsided CU set and ran at HALF speed for its whole life: 22.7 instead of 11.4 ms).
+    The four encoder scans of config F (408 workgroups, two per CU) are timed alone, then launched (b) 300 us after a short
+    burst of projection GEMMs became resident on another stream, (c) with that burst released behind
+    mgr_stream_wait_next_resident (the order engine.py uses).  The burst ends early, so a well-placed scan is back at full
+    speed for most of its life: its time may exceed the solo time by the burst it shared the chip with, never by its own length."""
+    from mgr_amd import _capi
+    dev = device
+    rng = np.random.default_rng(8)
+    B, T = 64, 1000
+    jobs, keep = [], []
+    for H in (500, 300):
+        j, _, k = _scan_jobs(dev, rng, B, T, H)
+        jobs += j
+        keep += k
+    arr = _capi.make_scan_jobs(jobs)
+    ws = dev.bytes(dev.lib.mgr_lstm_scan_multi_ws_bytes(len(jobs), arr))
+    Fg, Hg = 600, 300
+    Xg = dev.array(rng.standard_normal((B, T, Fg)).astype(np.float32))
+    Wg, bg, Zg = dev.zeros((Fg, 4 * Hg)), dev.zeros((4 * Hg,)), dev.empty((B, T, 4 * Hg))
+
+    def scan():
+        _capi.check(dev.lib.mgr_lstm_scan_fwd_multi(dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes))
+
+    def burst():
+        for _ in range(2):
+            dev.call("mgr_lstm_input_proj", Xg, Fg, 0, Wg, bg, Zg, B, T, Fg, Hg)
+
+    def run(order):
+        best = 1e9
+        for _ in range(3):
+            dev.sync()
+            if order == "alone":
+                dev.stream(1); dev.record(0); scan(); dev.record(1)
+            elif order == "gemms_first":
+                dev.stream(2); burst()
+                dev.stream(1); dev.call("mgr_stream_delay", 300); dev.record(0); scan(); dev.record(1)
+            else:   # gated: the burst waits on the device until the scan launched next is resident
+                dev.stream(2); dev.call("mgr_stream_wait_next_resident", 5000); burst()
+                dev.stream(1); dev.record(0); scan(); dev.record(1)
+            dev.stream(0)
+            dev.sync()
+            best = min(best, dev.elapsed_ms(0, 1))
+        return best
+
+    scan(); burst(); dev.sync()      # warm-up
+    dev.stream(2); dev.record(2); burst(); dev.record(3); dev.stream(0); dev.sync()
+    t_burst = dev.elapsed_ms(2, 3)
+    alone, first, gated = run("alone"), run("gemms_first"), run("gated")
+    print("scan alone %.2f ms | GEMM burst %.2f ms | GEMMs resident first: scan %.2f ms | gated: scan %.2f ms" % (alone, t_burst, first, gated))
+    assert t_burst < 0.6 * alone                      # the burst is short against the scan
+    assert first < alone + 1.5 * t_burst + 0.15 * alone, (alone, t_burst, first)
+    assert gated < alone + 1.5 * t_burst + 0.15 * alone, (alone, t_burst, gated)
+    st = ctypes.c_uint(7)
+    dev.call("mgr_scan_status", ctypes.byref(st))
+    assert st.value == 0
