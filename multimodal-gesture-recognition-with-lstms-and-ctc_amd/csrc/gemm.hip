@@ -384,9 +384,7 @@ __global__ __launch_bounds__(256) void k_gate_major(const float* __restrict__ Wp
   }
 }
 
-constexpr int SP_MAXF = 2048;   // feature-count limit of the sparse kernel (index + factor lists of the four gates live in LDS)
-// list length per (gate, sample): F rounded up to TWO stages of the projection kernel (its gate passes have even stage counts)
-static inline int sp_fp(int F) { return (F + 2 * 16 - 1) / (2 * 16) * (2 * 16); }
+constexpr int SP_MAXF = 2048;   // feature-count limit of the sparse kernel (index + factor lists of one gate pass live in LDS)
 constexpr int SP_TM = 128, SP_SK = 16;   // tile: 128 rows x (32 WC) units x 4 gates, 16 k per stage
 
 // One workgroup per tile, units fastest (workgroups that hold a CU for the whole kernel were measured: no faster alone -
@@ -410,8 +408,8 @@ __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_gemm_nn_sparse(co
   constexpr int BKS = NT / TU;        // k rows covered by one pass of the threads over the B stage
   __shared__ __attribute__((aligned(16))) float As[2][SK][TM + 4];
   __shared__ float Bs[2][SK][TU + 4];
-  __shared__ unsigned short Ls[4][SP_MAXF];   // kept-feature lists of the four gates (F <= 2048)
-  __shared__ float Vs[4][SP_MAXF];
+  __shared__ int Ls[SP_MAXF];
+  __shared__ float Vs[SP_MAXF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave / WC, wc = wave % WC;
   const int N = 4 * H;
   const int ak = TR ? tid / (TM / 8) : tid & 15;   // A staging: this thread's k within the stage ...
@@ -446,87 +444,76 @@ __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_gemm_nn_sparse(co
       int row = r0 + ar + ARS * i;
       arow[i] = (row < T ? row : T - 1) * ldx;   // (one sample's [T, ldx] block stays below 2^31 elements)
     }
-    // The four gate passes form ONE stage pipeline: the kept-feature lists of all four gates sit in LDS, every gate's stage
-    // count is rounded up to an even number (list positions behind the kept ones carry factor 0), and the global loads of a
-    // gate's first stages are issued under the MFMAs of the previous gate's last ones.  Stage s of the flat sequence belongs to
-    // gate gs with cum[gs] <= s < cum[gs + 1]; only the MFMA accumulators depend on the gate at compile time.
-    int cum[5];
-    cum[0] = 0;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int nst = ((kcnt[g * B + b] + SK - 1) / SK + 1) & ~1;   // (<= Fp / 16, Fp a multiple of 32)
-      cum[g + 1] = cum[g] + nst;
-      const int* list = kidx + ((size_t)g * B + b) * Fp;
-      const float* lval = kval + ((size_t)g * B + b) * Fp;
-      for (int i = tid; i < nst * SK; i += NT) {
-        Ls[g][i] = (unsigned short)list[i];
-        Vs[g][i] = lval[i];
+      const int nst = (kcnt[g * B + b] + SK - 1) / SK;   // (<= Fp / 16)
+      {
+        const int* list = kidx + ((size_t)g * B + b) * Fp;
+        const float* lval = kval + ((size_t)g * B + b) * Fp;
+        for (int i = tid; i < nst * SK; i += NT) {
+          Ls[i] = list[i];
+          Vs[i] = lval[i];
+        }
       }
-    }
-    const int S = cum[4];
-    __syncthreads();
-    auto fetch = [&](Regs& r, int s) {
-      const int gs = (s >= cum[1]) + (s >= cum[2]) + (s >= cum[3]);   // (uniform)
-      const int st = s - (gs == 0 ? 0 : gs == 1 ? cum[1] : gs == 2 ? cum[2] : cum[3]);
-      const unsigned short* L = Ls[gs];
-      if constexpr (TR) {
-        const float* xp = Xb + (size_t)L[st * SK + ak] * ldx;   // (rows beyond T: the copy is padded to whole row tiles)
-        const float4 v0 = *reinterpret_cast<const float4*>(xp), v1 = *reinterpret_cast<const float4*>(xp + 64);
-        r.a[0] = v0.x; r.a[1] = v0.y; r.a[2] = v0.z; r.a[3] = v0.w;
-        r.a[4] = v1.x; r.a[5] = v1.y; r.a[6] = v1.z; r.a[7] = v1.w;
-      } else {
-        const float* xp = Xb + L[st * SK + ak];
-#pragma unroll
-        for (int i = 0; i < APT; ++i) r.a[i] = xp[arow[i]];
-      }
-      const float* Wg = Wp + (size_t)gs * F * H + ucl;   // (Wp: the gate-major copy [4][F][H])
-#pragma unroll
-      for (int j = 0; j < BPT; ++j) {
-        const int q = st * SK + bk + BKS * j;
-        r.w[j] = Wg[(size_t)L[q] * H];
-        r.v[j] = Vs[gs][q];
-      }
-    };
-    auto stash = [&](const Regs& r, int buf) {
-      if constexpr (TR) {
-        *reinterpret_cast<float4*>(&As[buf][ak][ar]) = make_float4(r.a[0], r.a[1], r.a[2], r.a[3]);
-        *reinterpret_cast<float4*>(&As[buf][ak][64 + ar]) = make_float4(r.a[4], r.a[5], r.a[6], r.a[7]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < APT; ++i) As[buf][ak][ar + ARS * i] = r.a[i];
-      }
-#pragma unroll
-      for (int j = 0; j < BPT; ++j) Bs[buf][bk + BKS * j][bu] = r.w[j] * r.v[j];
-    };
-    if (S > 0) {
-      Regs R0, R1;
-      fetch(R0, 0);
-      fetch(R1, 1);   // (S is even)
-      stash(R0, 0);
       __syncthreads();
-      int s = 0;
+      const float* Wg = Wp + (size_t)g * F * H + ucl;   // (Wp: the gate-major copy [4][F][H])
+      auto fetch = [&](Regs& r, int st) {
+        if constexpr (TR) {
+          const float* xp = Xb + (size_t)Ls[st * SK + ak] * ldx;   // (rows beyond T: the copy is padded to whole row tiles)
+          const float4 v0 = *reinterpret_cast<const float4*>(xp), v1 = *reinterpret_cast<const float4*>(xp + 64);
+          r.a[0] = v0.x; r.a[1] = v0.y; r.a[2] = v0.z; r.a[3] = v0.w;
+          r.a[4] = v1.x; r.a[5] = v1.y; r.a[6] = v1.z; r.a[7] = v1.w;
+        } else {
+          const float* xp = Xb + Ls[st * SK + ak];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        auto mma = [&](int buf) {
+          for (int i = 0; i < APT; ++i) r.a[i] = xp[arow[i]];
+        }
 #pragma unroll
-          for (int ks = 0; ks < SK / 2; ++ks) {
-            const float a0 = As[buf][ks * 2 + lh][wr * 64 + l31];
-            const float a1 = As[buf][ks * 2 + lh][wr * 64 + 32 + l31];
-            const float bb = Bs[buf][ks * 2 + lh][wc * 32 + l31];
-            acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb, acc[g][0], 0, 0, 0);
-            acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bb, acc[g][1], 0, 0, 0);
-          }
-        };
-        // stage s computes from LDS buffer s & 1; its data were fetched two stages ago and stashed in the previous one
-        for (; s < cum[g + 1]; s += 2) {
-          if (s + 2 < S) fetch(R0, s + 2);
+        for (int j = 0; j < BPT; ++j) {
+          const int q = st * SK + bk + BKS * j;
+          r.w[j] = Wg[(size_t)Ls[q] * H];
+          r.v[j] = Vs[q];
+        }
+      };
+      auto stash = [&](const Regs& r, int buf) {
+        if constexpr (TR) {
+          *reinterpret_cast<float4*>(&As[buf][ak][ar]) = make_float4(r.a[0], r.a[1], r.a[2], r.a[3]);
+          *reinterpret_cast<float4*>(&As[buf][ak][64 + ar]) = make_float4(r.a[4], r.a[5], r.a[6], r.a[7]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < APT; ++i) As[buf][ak][ar + ARS * i] = r.a[i];
+        }
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) Bs[buf][bk + BKS * j][bu] = r.w[j] * r.v[j];
+      };
+      auto mma = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < SK / 2; ++ks) {
+          const float a0 = As[buf][ks * 2 + lh][wr * 64 + l31];
+          const float a1 = As[buf][ks * 2 + lh][wr * 64 + 32 + l31];
+          const float bb = Bs[buf][ks * 2 + lh][wc * 32 + l31];
+          acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb, acc[g][0], 0, 0, 0);
+          acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bb, acc[g][1], 0, 0, 0);
+        }
+      };
+      if (nst > 0) {
+        Regs R0, R1;
+        fetch(R0, 0);
+        if (nst > 1) fetch(R1, 1);
+        stash(R0, 0);
+        __syncthreads();
+        // stage st computes from LDS buffer st & 1; its data were fetched two iterations ago and stashed in the previous one
+        for (int st = 0; st < nst; st += 2) {
+          if (st + 2 < nst) fetch(R0, st + 2);
           mma(0);
-          stash(R1, 1);
+          if (st + 1 < nst) stash(R1, 1);
           __syncthreads();
-          if (s + 3 < S) fetch(R1, s + 3);
-          mma(1);
-          if (s + 2 < S) stash(R0, 0);
-          __syncthreads();
+          if (st + 1 < nst) {
+            if (st + 3 < nst) fetch(R1, st + 3);
+            mma(1);
+            if (st + 2 < nst) stash(R0, 0);
+            __syncthreads();
+          }
         }
       }
     }
@@ -922,7 +909,7 @@ int mgr_lstm_input_proj_pair(mgr_ctx* c, const float* X, int ldx, const float* m
 }
 
 size_t mgr_lstm_input_proj_dropout_ws_bytes(int B, int F, int H) {
-  const size_t Fp = (size_t)sp_fp(F);
+  const size_t Fp = (size_t)(F + SP_SK - 1) / SP_SK * SP_SK;
   return 2 * mgr_align_up((size_t)4 * B * Fp * sizeof(int), 256) + mgr_align_up((size_t)4 * B * sizeof(int), 256) +
          mgr_align_up((size_t)F * 4 * H * sizeof(float), 256);
 }
@@ -940,7 +927,7 @@ int mgr_lstm_input_proj_dropout_wants_transposed(mgr_ctx* c, float drop_rate, in
 
 static int input_proj_dropout_impl(mgr_ctx* c, const float* X, int ldx, bool transposed, const float* mask4, float drop_rate,
                                    const float* Wp, const float* bp, float* Z, int B, int T, int F, int H, void* ws, size_t ws_bytes) {
-  const int Fp = sp_fp(F);
+  const int Fp = (F + SP_SK - 1) / SP_SK * SP_SK;
   const size_t lbytes = mgr_align_up((size_t)4 * B * Fp * sizeof(int), 256);
   char* w = reinterpret_cast<char*>(ws);
   int* kidx = reinterpret_cast<int*>(w);
@@ -1087,7 +1074,7 @@ int mgr_lstm_param_grads(mgr_ctx* c, const float* X, int ldx, const float* mask4
 }
 
 static size_t pg_dropout_extra(int B, int F, int H) {
-  const size_t Fp = (size_t)sp_fp(F);
+  const size_t Fp = (size_t)(F + SP_SK - 1) / SP_SK * SP_SK;
   return 2 * mgr_align_up((size_t)4 * B * Fp * sizeof(int), 256) + mgr_align_up((size_t)4 * B * sizeof(int), 256) +
          mgr_align_up((size_t)4 * B * F * sizeof(int), 256) + mgr_align_up((size_t)4 * B * Fp * H * sizeof(float), 256);
 }
@@ -1110,7 +1097,7 @@ int mgr_lstm_param_grads_dropout(mgr_ctx* c, const float* X, int ldx, const floa
   // runs these under an encoder scan; what is left over after the scan is exposed)
   param_grads_impl(c, X, ldx, mask4, Hs, ldh, dZ, dWp, dUp, dbp, B, T, F, H, reverse, ws, !sparse);
   if (sparse) {
-    const int Fp = sp_fp(F);
+    const int Fp = (F + SP_SK - 1) / SP_SK * SP_SK;
     const size_t lbytes = mgr_align_up((size_t)4 * B * Fp * sizeof(int), 256);
     char* w = reinterpret_cast<char*>(ws) + mgr_lstm_param_grads_ws_bytes(B, T, F, H);
     int* kidx = reinterpret_cast<int*>(w);
