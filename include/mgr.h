@@ -139,7 +139,8 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
 /* Tuning / test hooks.  key 0 (MGR_TUNE_SCAN_PATH): 0 auto, 1 force the L2-streaming fallback kernels,
  * 2 force one workgroup per batch group (no inter-CU exchange) where it fits, 3 force clusters with 4 tiles per
  * workgroup, 4 same with 8 tiles per workgroup.  key 1: !=0 makes scan_fwd check the give-up word synchronously.
- * key 2: print the scan plan.
+ * key 2: print the scan plan.  key 3: 1 = K-split scan launches keep contiguous cluster ids and write-through publishes (no
+ *        XCD-local exchange).
  * key 7: one-tile-per-wave clusters: 0 = K-split / register-direct gather step, 1 = LDS-image step, 2 = K-split step with
  *        hidden units in identity order (cross-check of the kernel's private unit permutation).
  * key 8: 1 = the multi-CU BPTT keeps its 4-wave kernel instead of the split-role (4 compute + 4 gather waves) one, 2 = always split.

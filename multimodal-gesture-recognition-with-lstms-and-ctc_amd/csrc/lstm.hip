@@ -131,7 +131,7 @@ void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
 // form a class that shares one contiguous range, every class starts on a multiple of 8 (the XCD round-robin).
 template <class SameFn, class SizeFn>
 static int layout_classes(int njobs, const bool* use, SameFn same, SizeFn G_of, const int* nbg, int* cls_begin_of, int* cls_clusters_of,
-                          int* cls_cluster0_of) {
+                          int* cls_cluster0_of, bool octets = false) {
   int cls_of[MGR_MAX_SCAN_JOBS], ncls = 0, cls_first[MGR_MAX_SCAN_JOBS], cls_clusters[MGR_MAX_SCAN_JOBS];
   for (int i = 0; i < njobs; ++i) {
     if (!use[i]) continue;
@@ -151,7 +151,7 @@ static int layout_classes(int njobs, const bool* use, SameFn same, SizeFn G_of, 
     begin = (begin + 7) / 8 * 8;
     cls_begin[k] = begin;
     cls_next[k] = 0;
-    begin += G_of(cls_first[k]) * cls_clusters[k];
+    begin += G_of(cls_first[k]) * (octets ? (cls_clusters[k] + 7) / 8 * 8 : cls_clusters[k]);
   }
   for (int i = 0; i < njobs; ++i) {
     if (!use[i]) continue;
@@ -238,11 +238,38 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     status = reinterpret_cast<unsigned*>(w);
     char* base = w;
     w += kScanHdrBytes;
+    // K-split launches (every job a 4-wave, one-tile-per-wave cluster with an exchange) lay their clusters out XCD-locally
+    // (tune key 3 = 1 turns that off); the table of workgroup XCD ids lives in the launch header
+    bool xcd = c->tune[3] == 0 && c->tune[7] == 0 && P.exchange;
+    {
+      int tot = 0;
+      for (int i = 0; i < njobs && xcd; ++i) {
+        if (!P.cluster[i]) continue;
+        xcd = P.cfg[i].nw == 4 && P.cfg[i].tpw == 1 && P.G[i] > 1 && mgr_cluster_ks_supported(jobs[i].H / 4);
+      }
+      // (octets of clusters: the grid may grow; it must still fit the chip and the header's table)
+      if (xcd) {
+        int h[MGR_MAX_SCAN_JOBS], n = 0;
+        for (int i = 0; i < njobs; ++i) {
+          if (!P.cluster[i]) continue;
+          bool seen = false;
+          for (int k = 0; k < n; ++k) seen = seen || h[k] == jobs[i].H;
+          if (seen) continue;
+          h[n++] = jobs[i].H;
+          int clusters = 0;
+          for (int k = i; k < njobs; ++k)
+            if (P.cluster[k] && jobs[k].H == jobs[i].H) clusters += P.nbg[k];
+          tot += P.G[i] * ((clusters + 7) / 8 * 8);
+        }
+        xcd = tot <= 2 * c->cu_count && (size_t)tot * sizeof(unsigned) <= kScanHdrBytes - 256;
+      }
+    }
     int cb[MGR_MAX_SCAN_JOBS], cn[MGR_MAX_SCAN_JOBS], c0[MGR_MAX_SCAN_JOBS];
     P.total = layout_classes(
         njobs, P.cluster,
         [&](int a, int b) { return jobs[a].H == jobs[b].H && P.cfg[a].nw == P.cfg[b].nw && P.cfg[a].tpw == P.cfg[b].tpw; },
-        [&](int a) { return P.G[a]; }, P.nbg, cb, cn, c0);
+        [&](int a) { return P.G[a]; }, P.nbg, cb, cn, c0, xcd);
+    L.xcd_local = xcd;
     for (int i = 0; i < njobs; ++i) {
       if (!P.cluster[i]) continue;
       const mgr_scan_job& j = jobs[i];

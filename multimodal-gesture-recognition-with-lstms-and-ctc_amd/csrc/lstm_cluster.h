@@ -7,7 +7,7 @@ constexpr int MGR_MAX_SCAN_JOBS = 8;
 
 // Header of every persistent launch's workspace (zeroed by a memset node ahead of the launch).
 //   [0] give-up code of THIS launch (a bounded spin expired)          [1] arrival counter (workgroups that have started)
-constexpr size_t kScanHdrBytes = 256;
+constexpr size_t kScanHdrBytes = 4096;   //   [64, 1024) XCC (XCD) id + 1 of every workgroup of the launch (XCD-local exchange)
 
 // Context-wide words (mgr_ctx::sticky_status, never cleared by a launch):
 //   [0] OR of every launch's status bits since the last mgr_scan_status_clear
@@ -46,11 +46,14 @@ struct ClusterLaunch {
   ClusterCommon cm;
   int njobs;
   int ksplit;        // one-tile-per-wave clusters use the K-split step (cluster_run_ks): register-direct gather
+  int xcd_local;     // K-split launches: clusters are laid out on workgroup ids congruent mod 8 (one XCD under the dispatcher's
+                     // round-robin); a cluster that FINDS all its members on one XCD publishes with plain stores into that L2
   ClusterJob job[MGR_MAX_SCAN_JOBS];
 };
 
-// true if (ks, tpw) has an instantiation
+// true if (ks, tpw) has an instantiation / if ks has a K-split instantiation
 bool mgr_cluster_supported(int ks, int tpw);
+bool mgr_cluster_ks_supported(int ks);
 // geometry of the launch that mgr_cluster_launch would issue: waves per workgroup, workgroups per CU
 void mgr_cluster_geometry(const ClusterLaunch& L, bool any_exchange, int* waves, int* per_cu);
 int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool any_exchange);

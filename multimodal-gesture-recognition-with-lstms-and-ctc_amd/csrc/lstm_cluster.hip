@@ -278,7 +278,7 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int bg, int ug
 //   * the four lanes r = 0..3 of a sample hold four CONSECUTIVE units: Z loads, Y / gate / c stores stay as coalesced as
 //     in the identity order.
 template <int KS, bool PERM>
-__device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const ClusterCommon& cm, int bg, int ug, float* smem) {
+__device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const ClusterCommon& cm, int bg, int ug, float* smem, bool fast = false) {
   constexpr int H = 4 * KS, N = 4 * H, QN = (KS + 3) / 4, IMG = QN * 256, NBW = (QN + 3) / 4;
   static_assert(NBW <= 8, "at most 8 image blocks per wave (H <= 512)");
   unsigned* status = cm.status;
@@ -471,7 +471,10 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
       if (PERM) {
         // lane (r, j) holds image word j*4 + r of the wave's 64-word segment: bring word l to lane l, one coalesced store
         const unsigned w = __builtin_amdgcn_ds_bpermute((((lane & 3) << 4) | (lane >> 2)) << 2, hbits);
-        __builtin_amdgcn_raw_buffer_store_b32(w, rs, ((step & 1) * IMG + (ug * 4 + wave) * 64 + lane) * 4, 0, 16);  // sc1
+        if (fast)   // whole cluster on one XCD (verified at start): the line stays in the L2 every peer's sc1 load is served from
+          __builtin_amdgcn_raw_buffer_store_b32(w, rs, ((step & 1) * IMG + (ug * 4 + wave) * 64 + lane) * 4, 0, 0);
+        else
+          __builtin_amdgcn_raw_buffer_store_b32(w, rs, ((step & 1) * IMG + (ug * 4 + wave) * 64 + lane) * 4, 0, 16);  // sc1
       } else {
         __builtin_amdgcn_raw_buffer_store_b32(hbits, rs, ((step & 1) * IMG + idx) * 4, 0, 16);  // sc1 write-through
       }
@@ -525,6 +528,51 @@ __global__ __launch_bounds__(CL_WAVES * 64) void k_scan_cluster(ClusterLaunch L)
 __global__ __launch_bounds__(256, 2) void k_scan_cluster_ks(ClusterLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   mgr_cluster_enter(L.cm);
+  if (L.xcd_local) {
+    // XCD-LOCAL EXCHANGE.  Workgroup ids are dealt round-robin over the 8 XCDs (observed, never relied upon), so the members of
+    // cluster 8o + x get the ids  cls_begin + o*8G + 8k + x  (k = 0..G-1): congruent mod 8, i.e. ONE XCD and one L2.  Every
+    // workgroup publishes the XCD it really runs on; a cluster whose members all read the same id exchanges h through that L2
+    // with PLAIN stores (a write-through store drops the line from the L2 and every peer's load goes out to the fabric:
+    // 3.56 instead of 3.91 us per step at H = 500, 9.7 instead of 10.3 ms for config F's four encoder scans); any other
+    // placement keeps the write-through stores.  The decision is a function of the published table only, so all members of a
+    // cluster agree, and every exchanged word is still validated by its epoch parity: placement is speed, never correctness.
+    unsigned* table = L.cm.status + 64;
+    unsigned xid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xid));
+    const unsigned mine = (xid & 0xFu) + 1u;
+    if (threadIdx.x == 0) __hip_atomic_store(table + blockIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k_ = 0; k_ < L.njobs; ++k_) {
+      const ClusterJob& jb = L.job[k_];
+      const int w_ = (int)blockIdx.x - jb.cls_begin, G = jb.G_;
+      const int noct = (jb.cls_nclusters + 7) / 8;
+      if (w_ < 0 || w_ >= noct * 8 * G) continue;
+      const int o = w_ / (8 * G), rem = w_ % (8 * G), ug = rem >> 3, cl = 8 * o + (rem & 7);
+      const int bg = cl - jb.cls_cluster0;
+      if (cl >= jb.cls_nclusters || bg < 0 || bg >= jb.nbg) continue;
+      const int lane = threadIdx.x & 63;
+      bool same = true;
+      unsigned spins = 0;
+      for (;;) {
+        unsigned v = mine;
+        if (lane < G) v = __hip_atomic_load(table + jb.cls_begin + o * 8 * G + 8 * lane + (rem & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(v != 0u)) {
+          same = __all(v == mine);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 18)) {
+          same = false;
+          break;
+        }
+      }
+#define CLKS_CASE(KS) \
+  if (jb.ks == KS) { cluster_run_ks<KS, true>(jb, L.cm, bg, ug, smem, same); return mgr_cluster_exit(L.cm); }
+      CLKS_FOREACH(CLKS_CASE)
+#undef CLKS_CASE
+      return;
+    }
+    return;
+  }
   MGR_FOR_MY_JOB(L, jb, bg, ug) {
 #define CLKS_CASE(KS) \
   if (jb.ks == KS) { cluster_run_ks<KS, true>(jb, L.cm, bg, ug, smem); return mgr_cluster_exit(L.cm); }
@@ -554,6 +602,14 @@ bool mgr_cluster_supported(int ks, int tpw) {
   if (ks == KS && tpw == TPW) return true;
   CL_FOREACH(CL_CASE)
 #undef CL_CASE
+  return false;
+}
+
+bool mgr_cluster_ks_supported(int ks) {
+#define CLKS_CASE(KS) \
+  if (ks == KS) return true;
+  CLKS_FOREACH(CLKS_CASE)
+#undef CLKS_CASE
   return false;
 }
 
@@ -605,6 +661,7 @@ int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool a
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_ks_id), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     c->attr_done |= 1u;
   }
+  MGR_REQUIRE(!L.xcd_local || (ks_eligible(L, any_exchange, waves) && L.ksplit == 1), "XCD-local layout is only understood by the K-split kernel");
   if (ks_eligible(L, any_exchange, waves)) {
     // partial-sum exchange only (no h image)
     size_t lds_ks = 2 * 16 * 64 * 4 * sizeof(float);

@@ -11,7 +11,7 @@ from mgr_amd import _capi
 dev = _capi.Device(0); lib = dev.lib
 B, T = 64, 1900
 rng = np.random.default_rng(0)
-variants = [(0, 0), (2, 0), (1, 0)]
+variants = [(0, 0), (0, 3), (2, 0), (1, 0)]   # (tune7, x): x = 3 turns the XCD-local exchange of the K-split step OFF
 for hs in ((500,), (500, 300)):
     jobs, keep = [], []
     for H in hs:
@@ -24,7 +24,7 @@ for hs in ((500,), (500, 300)):
     ws = dev.bytes(lib.mgr_lstm_scan_multi_ws_bytes(len(jobs), arr))
     ref = None
     for t7, t10 in variants:
-        dev.call("mgr_tune", 7, t7); dev.call("mgr_tune", 10, t10); dev.call("mgr_tune", 1, 1)
+        dev.call("mgr_tune", 7, t7); dev.call("mgr_tune", 3, 1 if t10 == 3 else 0); dev.call("mgr_tune", 1, 1)
         try:
             _capi.check(lib.mgr_lstm_scan_fwd_multi(dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes)); dev.sync()
             dev.record(0)
@@ -32,10 +32,10 @@ for hs in ((500,), (500, 300)):
                 _capi.check(lib.mgr_lstm_scan_fwd_multi(dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes))
             dev.record(1); dev.sync()
         except _capi.MgrError as e:
-            print("H=%-10s tune7=%d tune10=%d : FAILED %s" % (hs, t7, t10, e)); continue
+            print("H=%-10s tune7=%d tune3=%d : FAILED %s" % (hs, t7, t10, e)); continue
         ms = dev.elapsed_ms(0, 1) / 3
         y = keep[2].download()
         if ref is None: ref = y
-        print("H=%-10s tune7=%d tune10=%d : %7.3f ms  %5.2f us/step  status=%d  maxdiff=%.2e" % (hs, t7, t10, ms, ms * 1e3 / T, int(ws.download().view(np.uint32)[0]), float(np.abs(y - ref).max())), flush=True)
-    dev.call("mgr_tune", 7, 0); dev.call("mgr_tune", 10, 0); dev.call("mgr_tune", 1, 0)
+        print("H=%-10s tune7=%d tune3=%d : %7.3f ms  %5.2f us/step  status=%d  maxdiff=%.2e" % (hs, t7, t10, ms, ms * 1e3 / T, int(ws.download().view(np.uint32)[0]), float(np.abs(y - ref).max())), flush=True)
+    dev.call("mgr_tune", 7, 0); dev.call("mgr_tune", 3, 0); dev.call("mgr_tune", 1, 0)
     for a in keep + [ws]: a.free()
