@@ -362,9 +362,16 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
     w += bwd_job_ws(jobs[i]);
   }
   int cb[MGR_MAX_SCAN_JOBS], cn[MGR_MAX_SCAN_JOBS], c0[MGR_MAX_SCAN_JOBS];
-  const int grid = layout_classes(
-      njobs, use_cluster, [&](int a, int b) { return jobs[a].H == jobs[b].H; }, [&](int a) { return (jobs[a].H + 15) / 16; }, nbg,
-      cb, cn, c0);
+  auto same_h = [&](int a, int b) { return jobs[a].H == jobs[b].H; };
+  auto g_of = [&](int a) { return (jobs[a].H + 15) / 16; };
+  // XCD-local layout (octets of clusters) where the padded grid still fits the chip and the header's table; tune key 3 = 1: off
+  bool xcd = c->tune[3] == 0;
+  int grid = layout_classes(njobs, use_cluster, same_h, g_of, nbg, cb, cn, c0, xcd);
+  if (xcd && (grid > 2 * c->cu_count || (size_t)grid * sizeof(unsigned) > kScanHdrBytes - 256)) {
+    xcd = false;
+    grid = layout_classes(njobs, use_cluster, same_h, g_of, nbg, cb, cn, c0, false);
+  }
+  L.xcd_local = xcd;
   for (int i = 0; i < njobs; ++i) {
     if (!use_cluster[i]) continue;
     const mgr_scan_bwd_job& j = jobs[i];

@@ -73,6 +73,7 @@ struct ClusterBwdJob {
 struct ClusterBwdLaunch {
   ClusterCommon cm;
   int njobs;
+  int xcd_local;   // clusters laid out on workgroup ids congruent mod 8; plain-store exchange where a cluster finds itself on one XCD
   ClusterBwdJob job[MGR_MAX_SCAN_JOBS];
 };
 bool mgr_cluster_bwd_supported(int H);
@@ -91,6 +92,41 @@ __device__ __forceinline__ void mgr_cluster_enter(const ClusterCommon& cm) {
     const unsigned n = __hip_atomic_fetch_add(cm.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     if (n == (unsigned)cm.total_wgs) __hip_atomic_fetch_max(cm.sticky + 1, cm.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+// XCD-local exchange (forward K-split and BPTT cluster kernels).  Workgroup ids are dealt round-robin over the 8 XCDs (observed,
+// never relied upon), so with the octet layout the members of cluster 8o + x are the ids  cls_begin + o*8G + 8k + x  (k < G):
+// congruent mod 8, i.e. ONE XCD and one L2.  Every workgroup publishes the XCD it really runs on in the launch header
+// (status + 64 + blockIdx); a cluster whose members all show the same id exchanges through that L2 with PLAIN stores (a
+// write-through store drops the line from the L2 and every peer's load goes out to the fabric), any other placement keeps the
+// write-through stores.  The decision is a function of the published table only - all members agree - and every exchanged word
+// is still validated by its epoch parity: placement is speed, never correctness.  Returns the decision (wave-uniform);
+// decodes (cluster, unit group) of workgroup w_ within its class.
+__device__ __forceinline__ bool mgr_cluster_octet(const ClusterCommon& cm, int cls_begin, int G, int w_, int& cl, int& ug) {
+  unsigned* table = cm.status + 64;
+  unsigned xid;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xid));
+  const unsigned mine = (xid & 0xFu) + 1u;
+  if (threadIdx.x == 0) __hip_atomic_store(table + blockIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int o = w_ / (8 * G), rem = w_ % (8 * G);
+  ug = rem >> 3;
+  cl = 8 * o + (rem & 7);
+  const int lane = threadIdx.x & 63;
+  bool same = true;
+  unsigned spins = 0;
+  for (;;) {
+    unsigned v = mine;
+    if (lane < G) v = __hip_atomic_load(table + cls_begin + o * 8 * G + 8 * lane + (rem & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__all(v != 0u)) {
+      same = __all(v == mine);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(8);
+    if (++spins > (1u << 18)) {   // a member that never started: the bounded spins of the exchange will report it
+      same = false;
+      break;
+    }
+  }
+  return same;
 }
 // last thing: fold this launch's status bits into the context's sticky word
 __device__ __forceinline__ void mgr_cluster_exit(const ClusterCommon& cm) {

@@ -528,43 +528,15 @@ __global__ __launch_bounds__(CL_WAVES * 64) void k_scan_cluster(ClusterLaunch L)
 __global__ __launch_bounds__(256, 2) void k_scan_cluster_ks(ClusterLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   mgr_cluster_enter(L.cm);
-  if (L.xcd_local) {
-    // XCD-LOCAL EXCHANGE.  Workgroup ids are dealt round-robin over the 8 XCDs (observed, never relied upon), so the members of
-    // cluster 8o + x get the ids  cls_begin + o*8G + 8k + x  (k = 0..G-1): congruent mod 8, i.e. ONE XCD and one L2.  Every
-    // workgroup publishes the XCD it really runs on; a cluster whose members all read the same id exchanges h through that L2
-    // with PLAIN stores (a write-through store drops the line from the L2 and every peer's load goes out to the fabric:
-    // 3.56 instead of 3.91 us per step at H = 500, 9.7 instead of 10.3 ms for config F's four encoder scans); any other
-    // placement keeps the write-through stores.  The decision is a function of the published table only, so all members of a
-    // cluster agree, and every exchanged word is still validated by its epoch parity: placement is speed, never correctness.
-    unsigned* table = L.cm.status + 64;
-    unsigned xid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xid));
-    const unsigned mine = (xid & 0xFu) + 1u;
-    if (threadIdx.x == 0) __hip_atomic_store(table + blockIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (L.xcd_local) {   // XCD-local exchange: lstm_cluster.h, mgr_cluster_octet
     for (int k_ = 0; k_ < L.njobs; ++k_) {
       const ClusterJob& jb = L.job[k_];
       const int w_ = (int)blockIdx.x - jb.cls_begin, G = jb.G_;
-      const int noct = (jb.cls_nclusters + 7) / 8;
-      if (w_ < 0 || w_ >= noct * 8 * G) continue;
-      const int o = w_ / (8 * G), rem = w_ % (8 * G), ug = rem >> 3, cl = 8 * o + (rem & 7);
+      if (w_ < 0 || w_ >= (jb.cls_nclusters + 7) / 8 * 8 * G) continue;
+      int cl, ug;
+      const bool same = mgr_cluster_octet(L.cm, jb.cls_begin, G, w_, cl, ug);
       const int bg = cl - jb.cls_cluster0;
       if (cl >= jb.cls_nclusters || bg < 0 || bg >= jb.nbg) continue;
-      const int lane = threadIdx.x & 63;
-      bool same = true;
-      unsigned spins = 0;
-      for (;;) {
-        unsigned v = mine;
-        if (lane < G) v = __hip_atomic_load(table + jb.cls_begin + o * 8 * G + 8 * lane + (rem & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__all(v != 0u)) {
-          same = __all(v == mine);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1u << 18)) {
-          same = false;
-          break;
-        }
-      }
 #define CLKS_CASE(KS) \
   if (jb.ks == KS) { cluster_run_ks<KS, true>(jb, L.cm, bg, ug, smem, same); return mgr_cluster_exit(L.cm); }
       CLKS_FOREACH(CLKS_CASE)

@@ -30,7 +30,7 @@ constexpr int BW_WAVES = 4;
 //   loads share vmcnt; the acknowledgement of a wave's 8 x 16-byte stores per step was 2.7 of 7.8 us at H = 500), and the
 //   compute waves never wait on vmcnt for the exchange at all.  Plain compiler-managed loads - no register polling.
 template <int H, bool SPLIT>
-__device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg, int ug, float* smem, unsigned* status) {
+__device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg, int ug, float* smem, unsigned* status, bool fast) {
   constexpr int N = 4 * H;
   constexpr int GT = (H + 15) / 16;          // tiles of 16 units = workgroups per cluster
   constexpr int TPW = (GT + BW_WAVES - 1) / BW_WAVES;  // tiles per wave (tile m = wave + 4*i)
@@ -214,7 +214,10 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
             w.y = (__float_as_uint(a0[1]) & ~1u) | par;
             w.z = (__float_as_uint(a0[2]) & ~1u) | par;
             w.w = (__float_as_uint(a0[3]) & ~1u) | par;
-            __builtin_amdgcn_raw_buffer_store_b128(w, rs, (slot * SLOT + (m * GT + ug) * 256 + lane * 4) * 4, 0, 16);  // sc1
+            if (fast)   // whole cluster on one XCD (verified at start): plain store into the L2 the peers' sc1 loads are served from
+              __builtin_amdgcn_raw_buffer_store_b128(w, rs, (slot * SLOT + (m * GT + ug) * 256 + lane * 4) * 4, 0, 0);
+            else
+              __builtin_amdgcn_raw_buffer_store_b128(w, rs, (slot * SLOT + (m * GT + ug) * 256 + lane * 4) * 4, 0, 16);  // sc1
           }
         }
       }
@@ -237,14 +240,22 @@ __device__ __forceinline__ void scan_cluster_bwd_body(const ClusterBwdLaunch& L,
   for (int k = 0; k < L.njobs; ++k) {
     const ClusterBwdJob& jb = L.job[k];
     const int w = bid - jb.cls_begin;
-    if (w < 0 || w >= jb.cls_nclusters * jb.G_) continue;
-    // members of a cluster are CONTIGUOUS workgroup ids (the round-robin dispatcher then spreads them over all XCDs, which
-    // measured best for the write-through exchange)
-    const int ug = w % jb.G_;
-    const int bg = w / jb.G_ - jb.cls_cluster0;
+    int ug, cl;
+    bool fast = false;
+    if (L.xcd_local) {   // octet layout + same-XCD verification: lstm_cluster.h, mgr_cluster_octet
+      if (w < 0 || w >= (jb.cls_nclusters + 7) / 8 * 8 * jb.G_) continue;
+      fast = mgr_cluster_octet(L.cm, jb.cls_begin, jb.G_, w, cl, ug);
+      if (cl >= jb.cls_nclusters) continue;
+    } else {
+      // members of a cluster are CONTIGUOUS workgroup ids (the round-robin dispatcher then spreads them over all XCDs)
+      if (w < 0 || w >= jb.cls_nclusters * jb.G_) continue;
+      ug = w % jb.G_;
+      cl = w / jb.G_;
+    }
+    const int bg = cl - jb.cls_cluster0;
     if (bg < 0 || bg >= jb.nbg) continue;
 #define BW_CASE(HH) \
-  if (jb.H == HH) { cluster_bwd_run<HH, SPLIT>(jb, bg, ug, smem, L.cm.status); return mgr_cluster_exit(L.cm); }
+  if (jb.H == HH) { cluster_bwd_run<HH, SPLIT>(jb, bg, ug, smem, L.cm.status, fast); return mgr_cluster_exit(L.cm); }
     BW_FOREACH(BW_CASE)
 #undef BW_CASE
     return;

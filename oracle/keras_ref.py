@@ -11,6 +11,13 @@ weights, is Python-2 only, and its arithmetic lives in un-vendored third-party w
 This oracle therefore follows the reference *call sites* plus the published semantics of
 those libraries and is cross-checked, in the build container only,
 against finite differences and torch-CPU (``tests/golden/make_golden.py``).
+Since round 2 the CTC part is additionally held to THIRD-PARTY known-answer vectors
+(tests/golden/thirdparty_kat.json: TensorFlow's ctc_loss_op_test.testBasic, Keras'
+backend_test.test_ctc / test_ctc_decode_greedy / test_ctc_decode_beam - recalled, self-verifying,
+reproduced to the published precision: tests/test_cpu_kat.py) and to exhaustive path
+enumeration.  The LSTM cell, the optimizer and the network glue remain pinned by torch
+autograd / finite differences only: no vector of the reference itself exists, so the
+label "parity unpinned" stays.
 
 Every function cites the reference file:line whose behaviour it restates.
 All functions take a ``dtype`` (np.float64 for the fp64 oracle, np.float32 for the
