@@ -145,7 +145,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
  *        hidden units in identity order (cross-check of the kernel's private unit permutation).
  * key 8: 1 = the multi-CU BPTT keeps its 4-wave kernel instead of the split-role (4 compute + 4 gather waves) one, 2 = always split.
  * key 9: 1 = mgr_lstm_input_proj_dropout always takes the dense kernel. */
-enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 12 };
+enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 16 };
 int mgr_tune(mgr_ctx* ctx, int key, int value);
 /* Health of the persistent multi-CU scans launched on this context since the last mgr_scan_status_clear: *out receives the OR
  * of their status bits.  MGR_SCAN_GAVE_UP: a bounded spin expired (a dead-locked or lost peer) - the launch returned promptly

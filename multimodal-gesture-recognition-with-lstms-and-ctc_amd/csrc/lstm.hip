@@ -131,7 +131,7 @@ void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
 // form a class that shares one contiguous range, every class starts on a multiple of 8 (the XCD round-robin).
 template <class SameFn, class SizeFn>
 static int layout_classes(int njobs, const bool* use, SameFn same, SizeFn G_of, const int* nbg, int* cls_begin_of, int* cls_clusters_of,
-                          int* cls_cluster0_of, bool octets = false) {
+                          int* cls_cluster0_of, bool octets = false, int* cls_rot_of = nullptr) {
   int cls_of[MGR_MAX_SCAN_JOBS], ncls = 0, cls_first[MGR_MAX_SCAN_JOBS], cls_clusters[MGR_MAX_SCAN_JOBS];
   for (int i = 0; i < njobs; ++i) {
     if (!use[i]) continue;
@@ -146,11 +146,13 @@ static int layout_classes(int njobs, const bool* use, SameFn same, SizeFn G_of, 
     cls_of[i] = found;
     cls_clusters[found] += nbg[i];
   }
-  int cls_begin[MGR_MAX_SCAN_JOBS], cls_next[MGR_MAX_SCAN_JOBS], begin = 0;
+  int cls_begin[MGR_MAX_SCAN_JOBS], cls_next[MGR_MAX_SCAN_JOBS], cls_rot[MGR_MAX_SCAN_JOBS], begin = 0, lanes = 0;
   for (int k = 0; k < ncls; ++k) {
     begin = (begin + 7) / 8 * 8;
     cls_begin[k] = begin;
     cls_next[k] = 0;
+    cls_rot[k] = lanes & 7;   // (XCD-local layout) this class's first cluster takes the lane after the previous class's last
+    lanes += cls_clusters[k];
     begin += G_of(cls_first[k]) * (octets ? (cls_clusters[k] + 7) / 8 * 8 : cls_clusters[k]);
   }
   for (int i = 0; i < njobs; ++i) {
@@ -159,6 +161,7 @@ static int layout_classes(int njobs, const bool* use, SameFn same, SizeFn G_of, 
     cls_begin_of[i] = cls_begin[k];
     cls_clusters_of[i] = cls_clusters[k];
     cls_cluster0_of[i] = cls_next[k];
+    if (cls_rot_of) cls_rot_of[i] = octets ? cls_rot[k] : 0;
     cls_next[k] += nbg[i];
   }
   return begin;   // grid size
@@ -264,11 +267,11 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
         xcd = tot <= 2 * c->cu_count && (size_t)tot * sizeof(unsigned) <= kScanHdrBytes - 256;
       }
     }
-    int cb[MGR_MAX_SCAN_JOBS], cn[MGR_MAX_SCAN_JOBS], c0[MGR_MAX_SCAN_JOBS];
+    int cb[MGR_MAX_SCAN_JOBS], cn[MGR_MAX_SCAN_JOBS], c0[MGR_MAX_SCAN_JOBS], cr[MGR_MAX_SCAN_JOBS];
     P.total = layout_classes(
         njobs, P.cluster,
         [&](int a, int b) { return jobs[a].H == jobs[b].H && P.cfg[a].nw == P.cfg[b].nw && P.cfg[a].tpw == P.cfg[b].tpw; },
-        [&](int a) { return P.G[a]; }, P.nbg, cb, cn, c0, xcd);
+        [&](int a) { return P.G[a]; }, P.nbg, cb, cn, c0, xcd, cr);
     L.xcd_local = xcd;
     for (int i = 0; i < njobs; ++i) {
       if (!P.cluster[i]) continue;
@@ -280,7 +283,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
       cj.ldy = j.ldy; cj.ldr = j.ldr; cj.B = j.B; cj.T = j.T; cj.H = j.H; cj.reverse = j.reverse;
       cj.ks = ks; cj.tpw = P.cfg[i].tpw; cj.nw = P.cfg[i].nw;
       cj.G_ = P.G[i]; cj.nbg = P.nbg[i];
-      cj.cls_begin = cb[i]; cj.cls_nclusters = cn[i]; cj.cls_cluster0 = c0[i];
+      cj.cls_begin = cb[i]; cj.cls_nclusters = cn[i]; cj.cls_cluster0 = c0[i]; cj.cls_rot = cr[i];
       cj.xbuf = reinterpret_cast<float*>(w);
       w += mgr_align_up((size_t)P.nbg[i] * 2 * img * sizeof(float), 256);
     }
@@ -361,15 +364,15 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
     wj[i] = w;
     w += bwd_job_ws(jobs[i]);
   }
-  int cb[MGR_MAX_SCAN_JOBS], cn[MGR_MAX_SCAN_JOBS], c0[MGR_MAX_SCAN_JOBS];
+  int cb[MGR_MAX_SCAN_JOBS], cn[MGR_MAX_SCAN_JOBS], c0[MGR_MAX_SCAN_JOBS], cr[MGR_MAX_SCAN_JOBS];
   auto same_h = [&](int a, int b) { return jobs[a].H == jobs[b].H; };
   auto g_of = [&](int a) { return (jobs[a].H + 15) / 16; };
   // XCD-local layout (octets of clusters) where the padded grid still fits the chip and the header's table; tune key 3 = 1: off
   bool xcd = c->tune[3] == 0;
-  int grid = layout_classes(njobs, use_cluster, same_h, g_of, nbg, cb, cn, c0, xcd);
+  int grid = layout_classes(njobs, use_cluster, same_h, g_of, nbg, cb, cn, c0, xcd, cr);
   if (xcd && (grid > 2 * c->cu_count || (size_t)grid * sizeof(unsigned) > kScanHdrBytes - 256)) {
     xcd = false;
-    grid = layout_classes(njobs, use_cluster, same_h, g_of, nbg, cb, cn, c0, false);
+    grid = layout_classes(njobs, use_cluster, same_h, g_of, nbg, cb, cn, c0, false, cr);
   }
   L.xcd_local = xcd;
   for (int i = 0; i < njobs; ++i) {
@@ -379,7 +382,7 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
     cj.dY = j.dY; cj.gates = j.gates; cj.cs = j.cs; cj.Up = j.Up; cj.dZ = j.dZ;
     cj.lddy = j.lddy; cj.B = j.B; cj.T = j.T; cj.H = j.H; cj.reverse = j.reverse;
     cj.G_ = (j.H + 15) / 16; cj.nbg = nbg[i];
-    cj.cls_begin = cb[i]; cj.cls_nclusters = cn[i]; cj.cls_cluster0 = c0[i];
+    cj.cls_begin = cb[i]; cj.cls_nclusters = cn[i]; cj.cls_cluster0 = c0[i]; cj.cls_rot = cr[i];
     cj.xbuf = reinterpret_cast<float*>(wj[i]);
   }
   if (L.njobs > 0) {

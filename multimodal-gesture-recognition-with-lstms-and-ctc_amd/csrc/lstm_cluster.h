@@ -40,6 +40,7 @@ struct ClusterJob {
   // jobs with identical geometry form a CLASS that shares one contiguous workgroup range: cluster `cl` of the class
   // owns workgroups [cls_begin + cl*G_, +G_); a job's batch group bg is cluster cls_cluster0 + bg
   int cls_begin, cls_nclusters, cls_cluster0;
+  int cls_rot;   // XCD-local layout: cluster c of the class sits on lane (c + cls_rot) % 8 (classes continue where the previous one stopped)
 };
 
 struct ClusterLaunch {
@@ -68,7 +69,7 @@ struct ClusterBwdJob {
   float* xbuf;  // [nbg][2][IMG]
   int lddy, B, T, H, reverse;
   int G_, nbg;
-  int cls_begin, cls_nclusters, cls_cluster0;
+  int cls_begin, cls_nclusters, cls_cluster0, cls_rot;
 };
 struct ClusterBwdLaunch {
   ClusterCommon cm;
@@ -95,13 +96,14 @@ __device__ __forceinline__ void mgr_cluster_enter(const ClusterCommon& cm) {
 }
 // XCD-local exchange (forward K-split and BPTT cluster kernels).  Workgroup ids are dealt round-robin over the 8 XCDs (observed,
 // never relied upon), so with the octet layout the members of cluster 8o + x are the ids  cls_begin + o*8G + 8k + x  (k < G):
-// congruent mod 8, i.e. ONE XCD and one L2.  Every workgroup publishes the XCD it really runs on in the launch header
+// congruent mod 8, i.e. ONE XCD and one L2 (x = (c + rot) % 8 for cluster c: a class starts on the lane after the previous
+// class's last cluster, so that fewer than eight clusters per class still spread over all XCDs).  Every workgroup publishes the XCD it really runs on in the launch header
 // (status + 64 + blockIdx); a cluster whose members all show the same id exchanges through that L2 with PLAIN stores (a
 // write-through store drops the line from the L2 and every peer's load goes out to the fabric), any other placement keeps the
 // write-through stores.  The decision is a function of the published table only - all members agree - and every exchanged word
 // is still validated by its epoch parity: placement is speed, never correctness.  Returns the decision (wave-uniform);
 // decodes (cluster, unit group) of workgroup w_ within its class.
-__device__ __forceinline__ bool mgr_cluster_octet(const ClusterCommon& cm, int cls_begin, int G, int w_, int& cl, int& ug) {
+__device__ __forceinline__ bool mgr_cluster_octet(const ClusterCommon& cm, int cls_begin, int G, int rot, int w_, int& cl, int& ug) {
   unsigned* table = cm.status + 64;
   unsigned xid;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xid));
@@ -109,7 +111,7 @@ __device__ __forceinline__ bool mgr_cluster_octet(const ClusterCommon& cm, int c
   if (threadIdx.x == 0) __hip_atomic_store(table + blockIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int o = w_ / (8 * G), rem = w_ % (8 * G);
   ug = rem >> 3;
-  cl = 8 * o + (rem & 7);
+  cl = 8 * o + (((rem & 7) - rot) & 7);
   const int lane = threadIdx.x & 63;
   bool same = true;
   unsigned spins = 0;

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void k_scan_cluster_ks(ClusterLaunch L) {
       const int w_ = (int)blockIdx.x - jb.cls_begin, G = jb.G_;
       if (w_ < 0 || w_ >= (jb.cls_nclusters + 7) / 8 * 8 * G) continue;
       int cl, ug;
-      const bool same = mgr_cluster_octet(L.cm, jb.cls_begin, G, w_, cl, ug);
+      const bool same = mgr_cluster_octet(L.cm, jb.cls_begin, G, jb.cls_rot, w_, cl, ug);
       const int bg = cl - jb.cls_cluster0;
       if (cl >= jb.cls_nclusters || bg < 0 || bg >= jb.nbg) continue;
 #define CLKS_CASE(KS) \

@@ -244,7 +244,7 @@ __device__ __forceinline__ void scan_cluster_bwd_body(const ClusterBwdLaunch& L,
     bool fast = false;
     if (L.xcd_local) {   // octet layout + same-XCD verification: lstm_cluster.h, mgr_cluster_octet
       if (w < 0 || w >= (jb.cls_nclusters + 7) / 8 * 8 * jb.G_) continue;
-      fast = mgr_cluster_octet(L.cm, jb.cls_begin, jb.G_, w, cl, ug);
+      fast = mgr_cluster_octet(L.cm, jb.cls_begin, jb.G_, jb.cls_rot, w, cl, ug);
       if (cl >= jb.cls_nclusters) continue;
     } else {
       // members of a cluster are CONTIGUOUS workgroup ids (the round-robin dispatcher then spreads them over all XCDs)
