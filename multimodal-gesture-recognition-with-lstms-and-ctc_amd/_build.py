@@ -41,7 +41,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "mgr.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "mgr.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -82,14 +82,23 @@ def build(force=False, verbose=True, jobs=4):
     for s, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
+            if os.path.exists(LIB):
+                os.remove(LIB)
             raise RuntimeError("hipcc failed on %s:\n%s" % (s, out.decode(errors="replace")))
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
-    if verbose:
-        print("[mgr build]", " ".join(cmd), file=sys.stderr)
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    if r.returncode != 0:
-        raise RuntimeError("link failed:\n%s" % r.stdout.decode(errors="replace"))
-    check_hidden_loads(objdir)
+    # the ISA check comes BEFORE the link, and a library of an older build does not survive a failed build: nothing may
+    # load (or carry to the GPU box) a libmgr.so whose register-polling kernels were not checked
+    try:
+        check_hidden_loads(objdir)
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+        if verbose:
+            print("[mgr build]", " ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % r.stdout.decode(errors="replace"))
+    except Exception:
+        if os.path.exists(LIB):
+            os.remove(LIB)
+        raise
     # --save-temps leaves bitcode / preprocessed sources behind; only the device assembly is of further use
     for f in os.listdir(objdir):
         if f.endswith((".bc", ".hipi", ".hipfb", ".out", ".cui")) or (f.endswith(".s") and "amdgcn" not in f):
@@ -129,10 +138,15 @@ def check_hidden_loads(objdir):
             if start is None:
                 raise RuntimeError("ISA check: kernel %s not found in %s" % (kname, cands[0]))
             end = next(i for i in range(start, len(text)) if "s_endpgm" in text[i])
-            body = [l.split(";")[0].strip() for l in text[start:end]]
-            # a polling window runs from a group's first hidden load to the first MFMA that consumes the data
-            polled, nloads = set(), 0
-            for l in body:
+            # a polling window runs from a step's first hidden load to the statement that drains the loads (poll_end() in
+            # cluster_run_ks leaves the marker MGR_POLL_END in the assembly); MFMAs inside it read the registers in place
+            polled, nloads, nends = set(), 0, 0
+            for raw in text[start:end]:
+                if "MGR_POLL_END" in raw:
+                    polled = set()
+                    nends += 1
+                    continue
+                l = raw.split(";")[0].strip()
                 if not l or " " not in l:
                     continue
                 mnem, rest = l.split(None, 1)
@@ -140,9 +154,6 @@ def check_hidden_loads(objdir):
                 if mnem == "global_load_dwordx4" and " sc1" in l:
                     polled |= _regs(ops[0])
                     nloads += 1
-                    continue
-                if mnem.startswith("v_mfma"):
-                    polled = set()
                     continue
                 if not polled:
                     continue
@@ -152,8 +163,8 @@ def check_hidden_loads(objdir):
                                        "(register pressure?)" % (kname, l))
                 if mnem.startswith("scratch_store") and any(_regs(o) & polled for o in ops):
                     raise RuntimeError("ISA check (%s): '%s' spills a polled register" % (kname, l))
-            if nloads == 0:
-                raise RuntimeError("ISA check: no hidden gather loads found in %s" % kname)
+            if nloads == 0 or nends == 0:
+                raise RuntimeError("ISA check: no hidden gather loads / no MGR_POLL_END marker found in %s" % kname)
 
 
 if __name__ == "__main__":

@@ -218,6 +218,8 @@ def test_hidden_load_isa_check():
 _ZN12_GLOBAL__N_120k_scan_cluster_ks_idE13ClusterLaunch:
 \tglobal_load_dwordx4 v[54:57], v[102:103], off sc1
 \tv_mfma_f32_16x16x4_f32 v[0:3], v54, v4, v[0:3]
+\ts_waitcnt vmcnt(0) ; MGR_POLL_END
+\tv_mov_b32_e32 v9, v54
 \ts_endpgm
 """
     bad = """
@@ -227,18 +229,55 @@ _ZN12_GLOBAL__N_117k_scan_cluster_ksE13ClusterLaunch:
 \ts_nop 0
 \tv_mov_b64_e32 v[50:51], v[54:55]
 \tv_mfma_f32_16x16x4_f32 v[0:3], v50, v4, v[0:3]
+\ts_waitcnt vmcnt(0) ; MGR_POLL_END
 \ts_endpgm
 """ + good_id
+    name = "lstm_cluster-hip-amdgcn-amd-amdhsa-gfx950.s"
+    ok = bad.replace("\tv_mov_b64_e32 v[50:51], v[54:55]\n", "").replace("v50, v4", "v54, v4")
     with tempfile.TemporaryDirectory() as d:
         with pytest.raises(RuntimeError, match="no device assembly"):
             _build.check_hidden_loads(d)     # a build without the assembly must not pass unchecked
-        with open(os.path.join(d, "lstm_cluster-hip-amdgcn-amd-amdhsa-gfx950.s"), "w") as f:
+        with open(os.path.join(d, name), "w") as f:
             f.write(bad)
         with pytest.raises(RuntimeError, match="copies a register"):
             _build.check_hidden_loads(d)
-        with open(os.path.join(d, "lstm_cluster-hip-amdgcn-amd-amdhsa-gfx950.s"), "w") as f:
-            f.write(bad.replace("\tv_mov_b64_e32 v[50:51], v[54:55]\n", "").replace("v50, v4", "v54, v4"))
-        _build.check_hidden_loads(d)     # the copy BEFORE the load and the MFMA consuming the loaded register are fine
+        with open(os.path.join(d, name), "w") as f:
+            f.write(ok)
+        _build.check_hidden_loads(d)     # the copy BEFORE the load, the MFMA consuming the loaded register and a copy AFTER
+        #                                  the window's end marker are fine
+        # the window ends at the marker, not at the first MFMA: blocks consumed one by one still have loads in flight
+        with open(os.path.join(d, name), "w") as f:
+            f.write(ok.replace("v54, v4, v[0:3]\n\ts_waitcnt vmcnt(0) ; MGR_POLL_END\n\ts_endpgm\n\n_ZN12_GLOBAL__N_120",
+                               "v54, v4, v[0:3]\n\tv_mov_b32_e32 v8, v55\n\ts_waitcnt vmcnt(0) ; MGR_POLL_END\n\ts_endpgm\n\n_ZN12_GLOBAL__N_120"))
+        with pytest.raises(RuntimeError, match="copies a register"):
+            _build.check_hidden_loads(d)
+        # a select that rewrites a polled register with itself loses a load that lands between its read and its write
+        with open(os.path.join(d, name), "w") as f:
+            f.write(ok.replace("\ts_nop 0\n", "\tv_cndmask_b32_e32 v55, v11, v55, vcc\n"))
+        with pytest.raises(RuntimeError, match="copies a register"):
+            _build.check_hidden_loads(d)
+        # a kernel that never closes its polling window is not accepted
+        with open(os.path.join(d, name), "w") as f:
+            f.write(ok.replace("\ts_waitcnt vmcnt(0) ; MGR_POLL_END\n\ts_endpgm\n\n_ZN12_GLOBAL__N_120", "\ts_endpgm\n\n_ZN12_GLOBAL__N_120"))
+        with pytest.raises(RuntimeError, match="MGR_POLL_END"):
+            _build.check_hidden_loads(d)
+
+
+def test_failed_isa_check_leaves_no_library(tmp_path, monkeypatch):
+    """_build.build(): the ISA check runs before the link and a failed build removes a library of an older build - nothing
+    can load (or carry to the GPU box) a libmgr.so whose register-polling kernels were not checked."""
+    from mgr_amd import _build
+    lib = tmp_path / "libmgr.so"
+    lib.write_bytes(b"old")
+    os.utime(lib, (1, 1))                                   # older than every source: build() has work to do
+    monkeypatch.setattr(_build, "LIB", str(lib))
+    monkeypatch.setattr(_build, "ISA_CHECKED", {"lstm_cluster.hip": ["k_no_such_kernel"]})
+    objdir = os.path.join(os.path.dirname(_build.__file__), "build")
+    if not any(f.endswith(".s") and "amdgcn" in f for f in os.listdir(objdir)):
+        pytest.skip("no device assembly in the tree (the build has not run here)")
+    with pytest.raises(RuntimeError, match="not found"):
+        _build.build(force=False, verbose=False)      # objects are up to date: only the check and the link would run
+    assert not lib.exists()
 
 
 def test_train_on_batch_with_fresh_temporaries_never_reuses_a_stale_split():
