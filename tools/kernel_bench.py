@@ -74,7 +74,9 @@ if __name__ == "__main__":
     a = ap.parse_args()
     dev = _capi.Device(0)
     print(dev.name, dev.cu_count, "CUs")
-    if "gemm" in a.what:
+    if a.what == "gemm1":
+        gemm(dev, 64, 1900, 1000, 500)
+    elif "gemm" in a.what:
         gemm(dev, 64, 1900, 1000, 500)
         gemm(dev, 64, 1900, 1000, 500, mask=False)
         gemm(dev, 64, 1900, 600, 300)

@@ -1,4 +1,5 @@
-"""In-order block consumption (mgr_tune 7 = 3) vs all-at-once polling (7 = 0) of the K-split scan: alone and as the 4-scan
+"""In-order block consumption (mgr_tune 7 = 3 / 4, only with tools/probes/lstm_cluster_inorder.hip.txt built in place of
+csrc/lstm_cluster.hip + the dispatch lines quoted in it) vs all-at-once polling (7 = 0) of the K-split scan: alone and as the 4-scan
 encoder launch of config F (two workgroups per CU)."""
 import os, sys
 sys.path.insert(0, os.getcwd())
