@@ -198,6 +198,16 @@ size_t mgr_lstm_param_grads_dropout_ws_bytes(int B, int T, int F, int H);
 int mgr_lstm_param_grads_dropout(mgr_ctx* ctx, const float* X, int ldx, const float* mask4, float drop_rate,
                                  const float* Hs, int ldh, const float* dZ, float* dWp, float* dUp, float* dbp, int B,
                                  int T, int F, int H, int reverse, void* ws, size_t ws_bytes);
+/* The dropout-aware dW from the TRANSPOSED activation copy XT[b][f][0..ldt) (mgr_transpose_bt - the copy the forward
+ * projection mgr_lstm_input_proj_dropout_t was fed): the K dimension of dW is time, so both operands (XT rows of the kept
+ * features; dZ transposed into the workspace by this call) are read as contiguous float4 along t.  Results bit-identical
+ * to mgr_lstm_param_grads_dropout.  Only for shapes where ..._wants_transposed() says 1; ldt % 4 == 0, ldt >= T rounded
+ * up to 16, the pad zero. */
+int mgr_lstm_param_grads_dropout_wants_transposed(mgr_ctx* ctx, float drop_rate, int F);
+size_t mgr_lstm_param_grads_dropout_t_ws_bytes(int B, int T, int F, int H, int ldt);
+int mgr_lstm_param_grads_dropout_t(mgr_ctx* ctx, const float* XT, int ldt, const float* mask4, float drop_rate,
+                                   const float* Hs, int ldh, const float* dZ, float* dWp, float* dUp, float* dbp, int B,
+                                   int T, int F, int H, int reverse, void* ws, size_t ws_bytes);
 /* dX[b,t,0:F] (stride lddx) (+)= sum_g mask4[g] (.) (dZ_g . W_g^T); accumulate=1 adds into dX. */
 int mgr_lstm_input_grad(mgr_ctx* ctx, const float* dZ, const float* Wp, const float* mask4, float* dX,
                         int lddx, int accumulate, int B, int T, int F, int H);

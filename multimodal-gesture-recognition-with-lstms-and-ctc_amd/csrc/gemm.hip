@@ -627,10 +627,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const float* __restrict__ A,
 // dropout factor, to P[(gate, sample)][list position][unit].  k_dw_gather then sums, per (feature, unit, gate), the samples
 // that kept the feature, in sample order (deterministic).  Half the MFMA work of the dense kernel at p = 0.5.
 // grid: 8 * ceil(B/8) * 4 * ceil(Fp/128) * ceil(H/128) workgroups, decoded below
+// TR: both operands come from TRANSPOSED copies - X is XT[b][f][t] (row stride ldx = padded T, the copy the forward projection
+// made) and dZ is dZT[b][4u+g][t] (row stride ldz, zero for t >= T like XT): the K dimension of this product is TIME, so a
+// thread's 8 values per stage are two float4 of one row instead of 8 scattered 4-byte loads with strides of a whole frame
+// (X: 64 useful bytes per 128-byte line; dZ: every fourth float).  Same stage layout in LDS, same MFMA order: bit-identical.
+template <bool TR>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn_sparse(const float* __restrict__ X, int ldx, const int* __restrict__ kidx,
                                                         const float* __restrict__ kval, const int* __restrict__ kcnt,
-                                                        const float* __restrict__ dZ, float* __restrict__ P, int B, int T, int Fp,
-                                                        int H) {
+                                                        const float* __restrict__ dZ, int ldz, float* __restrict__ P, int B, int T,
+                                                        int Fp, int F, int H) {
   __shared__ __attribute__((aligned(16))) float As2[NBUF][BK][LDS_LD];
   __shared__ __attribute__((aligned(16))) float Bs2[NBUF][BK][LDS_LD];
   __shared__ float rowf[BM];
@@ -647,31 +652,39 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_sparse(const float* __restri
   const int cnt = kcnt[gb];
   if (q0 >= cnt) return;   // (uniform) no kept feature in this row tile
   const int N = 4 * H;
-  const int m = tid & 127, kb = tid >> 7;   // staging: this thread's row (feature) / column (unit) and first k (then +2, ...)
+  const int m = tid & 127, kb = tid >> 7;   // staging: this thread's row (feature) / column (unit) and first k (then +2, ...; TR: 8 kb ..)
   const int q = q0 + m < Fp ? q0 + m : Fp - 1;
-  const float* xcol = X + (size_t)b * T * ldx + kidx[(size_t)gb * Fp + q];
   const int un = u0 + m < H ? u0 + m : H - 1;
-  const float* zcol = dZ + (size_t)b * T * N + 4 * un + g;
+  const float* xcol = TR ? X + ((size_t)b * F + kidx[(size_t)gb * Fp + q]) * ldx + 8 * kb : X + (size_t)b * T * ldx + kidx[(size_t)gb * Fp + q];
+  const float* zcol = TR ? dZ + ((size_t)b * N + 4 * un + g) * ldz + 8 * kb : dZ + (size_t)b * T * N + 4 * un + g;
   if (tid < BM) rowf[tid] = (q0 + tid < cnt) ? kval[(size_t)gb * Fp + q0 + tid] : 0.f;
   f32x16 acc[2][2];
   zero_acc(acc);
   float ra[8], rb[8];
   auto fetch = [&](int t0) {
+    if constexpr (TR) {   // (t0 + 16 <= the padded row length; the pad is zero)
+      const float4 a0 = *reinterpret_cast<const float4*>(xcol + t0), a1 = *reinterpret_cast<const float4*>(xcol + t0 + 4);
+      const float4 z0 = *reinterpret_cast<const float4*>(zcol + t0), z1 = *reinterpret_cast<const float4*>(zcol + t0 + 4);
+      ra[0] = a0.x; ra[1] = a0.y; ra[2] = a0.z; ra[3] = a0.w; ra[4] = a1.x; ra[5] = a1.y; ra[6] = a1.z; ra[7] = a1.w;
+      rb[0] = z0.x; rb[1] = z0.y; rb[2] = z0.z; rb[3] = z0.w; rb[4] = z1.x; rb[5] = z1.y; rb[6] = z1.z; rb[7] = z1.w;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int t = t0 + kb + 2 * i;
-      const bool ok = t < T;
-      t = ok ? t : T - 1;
-      const float a = xcol[(size_t)t * ldx], z = zcol[(size_t)t * N];
-      ra[i] = ok ? a : 0.f;
-      rb[i] = ok ? z : 0.f;
+      for (int i = 0; i < 8; ++i) {
+        int t = t0 + kb + 2 * i;
+        const bool ok = t < T;
+        t = ok ? t : T - 1;
+        const float a = xcol[(size_t)t * ldx], z = zcol[(size_t)t * N];
+        ra[i] = ok ? a : 0.f;
+        rb[i] = ok ? z : 0.f;
+      }
     }
   };
   auto stash = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      As2[buf][kb + 2 * i][m] = ra[i];
-      Bs2[buf][kb + 2 * i][m] = rb[i];
+      const int k = TR ? 8 * kb + i : kb + 2 * i;
+      As2[buf][k][m] = ra[i];
+      Bs2[buf][k][m] = rb[i];
     }
   };
   const int nst = (T + BK - 1) / BK;
@@ -1083,15 +1096,11 @@ size_t mgr_lstm_param_grads_dropout_ws_bytes(int B, int T, int F, int H) {
   return mgr_lstm_param_grads_ws_bytes(B, T, F, H) + pg_dropout_extra(B, F, H);
 }
 
-int mgr_lstm_param_grads_dropout(mgr_ctx* c, const float* X, int ldx, const float* mask4, float drop_rate, const float* Hs,
-                                 int ldh, const float* dZ, float* dWp, float* dUp, float* dbp, int B, int T, int F, int H,
-                                 int reverse, void* ws, size_t ws_bytes) {
-  MGR_REQUIRE(c && X && Hs && dZ && dWp && dUp && dbp, "null argument");
-  MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0 && ldx >= F && ldh >= H, "bad shape");
-  MGR_REQUIRE(aligned16(dZ), "dZ must be 16-byte aligned");
-  const bool sparse = mask4 && drop_rate >= 0.3f && F >= 128 && c->tune[9] == 0;
-  MGR_REQUIRE(ws && ws_bytes >= (sparse ? mgr_lstm_param_grads_dropout_ws_bytes(B, T, F, H) : mgr_lstm_param_grads_ws_bytes(B, T, F, H)),
-              "workspace too small");
+// dU / db (and the dense dW when the shape is not sparse) + the dropout-aware dW; XT / ldt != 0: operands of the dW product
+// from transposed copies (XT given by the caller, dZT made here)
+static int param_grads_dropout_impl(mgr_ctx* c, const float* X, int ldx, const float* XT, int ldt, const float* mask4, float drop_rate,
+                                    const float* Hs, int ldh, const float* dZ, float* dWp, float* dUp, float* dbp, int B, int T, int F,
+                                    int H, int reverse, void* ws, bool sparse) {
   mgr_prof_begin(c, MGR_K_GEMM_TN);
   // dU / db first: they are short, and in the training step the long dW kernel then ends this direction's work (the step
   // runs these under an encoder scan; what is left over after the scan is exposed)
@@ -1107,16 +1116,59 @@ int mgr_lstm_param_grads_dropout(mgr_ctx* c, const float* X, int ldx, const floa
     int* kpos = reinterpret_cast<int*>(w);
     w += mgr_align_up((size_t)4 * B * F * sizeof(int), 256);
     float* P = reinterpret_cast<float*>(w);
+    w += mgr_align_up((size_t)4 * B * Fp * H * sizeof(float), 256);
     hipStream_t s = mgr_stream(c);
     hipLaunchKernelGGL(k_mask_compact, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp, kidx, kval, kcnt, kpos);
     const int grid = 8 * ((B + 7) / 8) * 4 * ((Fp + BM - 1) / BM) * ((H + BN - 1) / BN);
-    hipLaunchKernelGGL(k_gemm_tn_sparse, dim3(grid), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, dZ, P, B, T, Fp, H);
+    if (XT) {
+      float* dZT = reinterpret_cast<float*>(w);   // [B][4H][ldt]
+      hipLaunchKernelGGL(k_transpose_bt, dim3((ldt + 63) / 64, (4 * H + 63) / 64, B), dim3(256), 0, s, dZ, 4 * H, dZT, ldt, T, 4 * H);
+      hipLaunchKernelGGL((k_gemm_tn_sparse<true>), dim3(grid), dim3(256), 0, s, XT, ldt, kidx, kval, kcnt, dZT, ldt, P, B, T, Fp, F, H);
+    } else {
+      hipLaunchKernelGGL((k_gemm_tn_sparse<false>), dim3(grid), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, dZ, 0, P, B, T, Fp, F, H);
+    }
     const size_t n = (size_t)4 * F * H;
     hipLaunchKernelGGL(k_dw_gather, dim3((int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, P, kpos, dWp, B, F, Fp, H);
   }
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_GEMM_TN);
   return 0;
+}
+
+static bool sparse_dw_shape(mgr_ctx* c, const float* mask4, float drop_rate, int F) {
+  return mask4 && drop_rate >= 0.3f && F >= 128 && c->tune[9] == 0;
+}
+
+int mgr_lstm_param_grads_dropout(mgr_ctx* c, const float* X, int ldx, const float* mask4, float drop_rate, const float* Hs,
+                                 int ldh, const float* dZ, float* dWp, float* dUp, float* dbp, int B, int T, int F, int H,
+                                 int reverse, void* ws, size_t ws_bytes) {
+  MGR_REQUIRE(c && X && Hs && dZ && dWp && dUp && dbp, "null argument");
+  MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0 && ldx >= F && ldh >= H, "bad shape");
+  MGR_REQUIRE(aligned16(dZ), "dZ must be 16-byte aligned");
+  const bool sparse = sparse_dw_shape(c, mask4, drop_rate, F);
+  MGR_REQUIRE(ws && ws_bytes >= (sparse ? mgr_lstm_param_grads_dropout_ws_bytes(B, T, F, H) : mgr_lstm_param_grads_ws_bytes(B, T, F, H)),
+              "workspace too small");
+  return param_grads_dropout_impl(c, X, ldx, nullptr, 0, mask4, drop_rate, Hs, ldh, dZ, dWp, dUp, dbp, B, T, F, H, reverse, ws, sparse);
+}
+
+int mgr_lstm_param_grads_dropout_wants_transposed(mgr_ctx* c, float drop_rate, int F) {
+  return (c && drop_rate >= 0.3f && F >= 128 && c->tune[9] == 0) ? 1 : 0;
+}
+
+size_t mgr_lstm_param_grads_dropout_t_ws_bytes(int B, int T, int F, int H, int ldt) {
+  return mgr_lstm_param_grads_dropout_ws_bytes(B, T, F, H) + mgr_align_up((size_t)B * 4 * H * ldt * sizeof(float), 256);
+}
+
+int mgr_lstm_param_grads_dropout_t(mgr_ctx* c, const float* XT, int ldt, const float* mask4, float drop_rate, const float* Hs, int ldh,
+                                   const float* dZ, float* dWp, float* dUp, float* dbp, int B, int T, int F, int H, int reverse,
+                                   void* ws, size_t ws_bytes) {
+  MGR_REQUIRE(c && XT && mask4 && Hs && dZ && dWp && dUp && dbp, "null argument");
+  MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0 && ldh >= H, "bad shape");
+  MGR_REQUIRE(ldt % 4 == 0 && ldt >= (T + BK - 1) / BK * BK, "the transposed copy must be padded to whole stages of %d time steps (ldt %d, T %d)", BK, ldt, T);
+  MGR_REQUIRE(aligned16(dZ) && aligned16(XT), "dZ / XT must be 16-byte aligned");
+  MGR_REQUIRE(sparse_dw_shape(c, mask4, drop_rate, F), "shape / drop rate not handled by the dropout-aware kernel (ask mgr_lstm_param_grads_dropout_wants_transposed)");
+  MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_param_grads_dropout_t_ws_bytes(B, T, F, H, ldt), "workspace too small");
+  return param_grads_dropout_impl(c, nullptr, 0, XT, ldt, mask4, drop_rate, Hs, ldh, dZ, dWp, dUp, dbp, B, T, F, H, reverse, ws, true);
 }
 
 int mgr_lstm_input_grad(mgr_ctx* c, const float* dZ, const float* Wp, const float* mask4, float* dX, int lddx,

@@ -740,7 +740,8 @@ class Engine:
         if sp.fusion:
             Hf = sp.fusion["H"]
             deferred = self._bilstm_backward("fusion", self.dYF, 2 * Hf, self._featin, W, W, self.YF, 2 * Hf,
-                                             self.dFEAT if any_tr_stream else None, W, defer_param_grads=defer)
+                                             self.dFEAT if any_tr_stream else None, W, defer_param_grads=defer,
+                                             XinT=self._featT.get(self._featin.ptr))
         if any_tr_stream:
             col = 0
             for s in sp.streams:
@@ -807,9 +808,11 @@ class Engine:
                         dev.wait_event(ES, self.EV_PREV)
         self._prefetched = nxt
 
-    def _bilstm_backward(self, prefix, dY, lddy, Xin, ldx, fin, Hbuf, ldh, dX, lddx, defer_param_grads=False):
+    def _bilstm_backward(self, prefix, dY, lddy, Xin, ldx, fin, Hbuf, ldh, dX, lddx, defer_param_grads=False, XinT=None):
         """BPTT + parameter grads of one Bidirectional layer (both directions in one persistent launch).
-        defer_param_grads: return the dW/dU/db GEMM launches as a closure instead of enqueuing them now."""
+        defer_param_grads: return the dW/dU/db GEMM launches as a closure instead of enqueuing them now.
+        XinT: the transposed copy of Xin the forward projection was fed (same step), if the engine keeps one - the
+        dropout-aware dW then reads both of its operands along time."""
         dev, B, T = self.dev, self.B, self.T
         jobs = []
         for di, dname in enumerate(("fwd", "bwd")):
@@ -830,7 +833,14 @@ class Engine:
                 L = self.dirs["%s/%s" % (prefix, dname)]
                 H = L.H
                 mptr = self._masks.get((L.prefix, L.d), 0)
-                if mptr:   # input dropout was applied: dW only has rows for the kept features of each (gate, sample)
+                if mptr and XinT is not None and self.lib.mgr_lstm_param_grads_dropout_wants_transposed(
+                        dev.ctx, C.c_float(float(L.p)), int(fin)):
+                    need = self.lib.mgr_lstm_param_grads_dropout_t_ws_bytes(B, T, fin, H, self.ldt)
+                    if L.ws_pg.nbytes < need:          # (+ the transposed dZ; first use only)
+                        L.ws_pg = self.mem.bytes(need)
+                    dev.call("mgr_lstm_param_grads_dropout_t", XinT, self.ldt, mptr, float(L.p), Hbuf.view(di * H, (1,)), ldh, L.dZ,
+                             L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes)
+                elif mptr:   # input dropout was applied: dW only has rows for the kept features of each (gate, sample)
                     dev.call("mgr_lstm_param_grads_dropout", Xin, ldx, mptr, float(L.p), Hbuf.view(di * H, (1,)), ldh, L.dZ,
                              L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes)
                 else:
@@ -858,7 +868,7 @@ class Engine:
             else:
                 Hbuf, ldh = self.FEAT.view(col, (1,)), W
             self._bilstm_backward("%s/l1" % name, dout, W, self.Y1[name], 2 * H1, 2 * H1, Hbuf, ldh,
-                                  self.dY1[name], 2 * H1)
+                                  self.dY1[name], 2 * H1, XinT=self.Y1T.get(name))
             if s["residual"]:
                 dev.call("mgr_add2d", self.dY1[name], 2 * H1, dout, W, self.dY1[name], 2 * H1, B * T, 2 * H1)
             self._bilstm_backward("%s/l0" % name, self.dY1[name], 2 * H1, self._xcur[name], s["F"], s["F"],

@@ -511,3 +511,14 @@ def test_param_grads_dropout_sparse_equals_dense(device, B, T, F, H, p, reverse)
     assert np.abs(outs[1][0] - ref).max() <= tol
     assert np.abs(outs[1][0] - outs[0][0]).max() <= tol
     assert np.array_equal(outs[1][1], outs[0][1]) and np.array_equal(outs[1][2], outs[0][2])
+    # both operands from transposed copies (time is the K dimension of dW): bit-identical to the gathered form
+    if dev.lib.mgr_lstm_param_grads_dropout_wants_transposed(dev.ctx, 0.5, F):
+        for ldt in ((T + 15) // 16 * 16, (T + 127) // 128 * 128):
+            XT = dev.zeros((B, F, ldt))
+            dev.call("mgr_transpose_bt", dX, F, XT, ldt, B, T, F)
+            ws = dev.bytes(dev.lib.mgr_lstm_param_grads_dropout_t_ws_bytes(B, T, F, H, ldt))
+            dev.call("mgr_memset", ws, 0xFF, ws.nbytes)        # the workspace arrives dirty (all-ones words are NaNs)
+            gW, gU, gb = dev.empty((F, N)), dev.empty((H, N)), dev.empty((N,))
+            dev.call("mgr_lstm_param_grads_dropout_t", XT, ldt, dM, 0.5, dH, H, ddZ, gW, gU, gb, B, T, F, H, reverse, ws, ws.nbytes)
+            assert np.array_equal(gW.download(), outs[1][0])
+            assert np.array_equal(gU.download(), outs[1][1]) and np.array_equal(gb.download(), outs[1][2])

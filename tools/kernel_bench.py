@@ -50,6 +50,19 @@ def gemm(dev, B, T, F, H, mask=True):
     ms = timeit(dev, lambda: dev.call("mgr_lstm_param_grads", X, F, m, Y, H, dZ, gW, gU, gb, B, T, F, H, 0, ws, ws.nbytes))
     fl = 2.0 * B * T * (F + H) * 4 * H
     print("gemm_tn  (dW,dU,db)                       : %7.3f ms  %6.1f TF" % (ms, fl / ms / 1e9))
+    if mask and F >= 128:
+        ldt = (T + 127) // 128 * 128
+        XT = dev.zeros((B, F, ldt))
+        dev.call("mgr_transpose_bt", X, F, XT, ldt, B, T, F)
+        wsd = dev.bytes(dev.lib.mgr_lstm_param_grads_dropout_t_ws_bytes(B, T, F, H, ldt))
+        gW2 = dev.empty((F, 4 * H))
+        ms = timeit(dev, lambda: dev.call("mgr_lstm_param_grads_dropout", X, F, m, 0.5, Y, H, dZ, gW, gU, gb, B, T, F, H, 0, wsd, wsd.nbytes))
+        ms2 = timeit(dev, lambda: dev.call("mgr_lstm_param_grads_dropout_t", XT, ldt, m, 0.5, Y, H, dZ, gW2, gU, gb, B, T, F, H, 0, wsd, wsd.nbytes))
+        same = np.array_equal(gW.download(), gW2.download())
+        fx = 2.0 * B * T * (0.5 * F + H) * 4 * H
+        print("  dropout-aware dW: gathered %7.3f ms (%5.1f TF executed) | transposed operands %7.3f ms (%5.1f TF)  bit-identical=%s"
+              % (ms, fx / ms / 1e9, ms2, fx / ms2 / 1e9, same))
+        XT.free(); wsd.free(); gW2.free()
     for a in (X, Wp, bp, Z, gW, gU, gb, Y, ws):
         a.free()
 
