@@ -34,9 +34,16 @@ def shard_batch(batch, rank, world):
 
 
 class RcclComm:
-    def __init__(self, dev, rank, world, bootstrap):
-        """bootstrap(bytes_or_None) -> bytes : rank 0 passes the id, every rank gets it back."""
+    def __init__(self, dev, rank, world, bootstrap, max_channels=8):
+        """bootstrap(bytes_or_None) -> bytes : rank 0 passes the id, every rank gets it back.
+        max_channels: upper bound of RCCL channels (= workgroups of its all-reduce kernel) unless the environment already
+        says NCCL_MAX_NCHANNELS: the gradient vector is a few MB, and the kernel has to find room on CUs that persistent
+        scans of this context occupy - 8 workgroups do, RCCL's default of dozens may have to wait for a scan
+        to end.  None leaves RCCL's default."""
+        import os
         self.dev, self.rank, self.world = dev, rank, world
+        if max_channels and "NCCL_MAX_NCHANNELS" not in os.environ:
+            os.environ["NCCL_MAX_NCHANNELS"] = str(int(max_channels))     # read by RCCL when the communicator is created
         lib = dev.lib
         uid = None
         if rank == 0:
