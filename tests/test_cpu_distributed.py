@@ -165,3 +165,37 @@ def test_hostcomm_sums_in_rank_order_and_every_rank_gets_the_same_bits():
         assert np.array_equal(got[r][1], expect)
         assert np.array_equal(got[r][2], expect.reshape(7, 143))
         assert got[r][3] == 2.5
+
+
+def test_hostcomm_fails_loudly_when_a_peer_dies_or_never_shows_up():
+    """A rank that goes away must surface as an error on the others (a closed connection / a timeout), never as a hang:
+    rank 1 connects and closes before contributing; a second communicator waits for a rank that never connects."""
+    import socket
+    import threading
+    from mgr_amd.parallel import HostComm
+    port = _free_port()
+    err = {}
+
+    def rank0():
+        try:
+            c = HostComm(None, 0, 2, addr="127.0.0.1", port=port, timeout=10.0)
+            try:
+                c.allreduce_sum_host(np.ones(5, np.float32))
+            finally:
+                c.close()
+        except Exception as e:      # noqa: BLE001 - the test inspects it
+            err[0] = e
+
+    t = threading.Thread(target=rank0)
+    t.start()
+    c1 = HostComm(None, 1, 2, addr="127.0.0.1", port=port, timeout=10.0)
+    c1.close()                                   # dies before its first all-reduce
+    t.join(20)
+    assert not t.is_alive()
+    assert isinstance(err.get(0), RuntimeError) and "closed" in str(err[0])
+    # nobody connects: the accept times out instead of blocking for good
+    with pytest.raises((socket.timeout, TimeoutError, OSError)):
+        HostComm(None, 0, 2, addr="127.0.0.1", port=_free_port(), timeout=0.5)
+    # rank 0 is not there: the client gives up with a message that names the address
+    with pytest.raises(RuntimeError, match="not reachable"):
+        HostComm(None, 1, 2, addr="127.0.0.1", port=_free_port(), timeout=0.5)
