@@ -133,6 +133,14 @@ typedef struct mgr_scan_job {
   float* gates;
   float* cs;
   int ldy, ldr, B, T, H, reverse;
+  /* optional transposed copy of the output, written by the scan itself (the K-split multi-CU kernel stages 32 steps per lane
+   * in LDS and stores 128-byte row segments; any other kernel family is followed by a transpose inside the call):
+   * YT[b * ytb + u * ldt + t] = what Y[b, t, u] gets, u < H; t in [T, T rounded up to 32) is written as zero.  ldt % 4 == 0,
+   * ldt >= T rounded up to 32.  NULL: none.  This is the layout mgr_lstm_input_proj_dropout_t / mgr_lstm_param_grads_dropout_t
+   * read; with ytb > H * ldt several jobs fill column ranges of one wider [B][F][ldt] copy. */
+  float* YT;
+  long long ytb;
+  int ldt, reserved_;
 } mgr_scan_job;
 size_t mgr_lstm_scan_multi_ws_bytes(int njobs, const mgr_scan_job* jobs);
 int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, void* ws, size_t ws_bytes);

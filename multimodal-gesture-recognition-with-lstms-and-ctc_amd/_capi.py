@@ -103,7 +103,8 @@ KERNEL_FAMILIES = ["gemm_nn", "gemm_tn", "gemm_nt", "scan_fwd", "scan_bwd", "den
 class ScanJob(C.Structure):
     """struct mgr_scan_job"""
     _fields_ = [("Z", vp), ("Up", vp), ("Y", vp), ("R", vp), ("gates", vp), ("cs", vp),
-                ("ldy", i32), ("ldr", i32), ("B", i32), ("T", i32), ("H", i32), ("reverse", i32)]
+                ("ldy", i32), ("ldr", i32), ("B", i32), ("T", i32), ("H", i32), ("reverse", i32),
+                ("YT", vp), ("ytb", C.c_longlong), ("ldt", i32), ("reserved_", i32)]
 
 
 class ScanBwdJob(C.Structure):
@@ -127,10 +128,10 @@ def make_scan_jobs(jobs):
     """jobs: list of dicts with the mgr_scan_job fields (DeviceArray or int pointers)."""
     arr = (ScanJob * len(jobs))()
     for a, j in zip(arr, jobs):
-        for k in ("Z", "Up", "Y", "R", "gates", "cs"):
+        for k in ("Z", "Up", "Y", "R", "gates", "cs", "YT"):
             v = j.get(k, 0)
             setattr(a, k, v.ptr if isinstance(v, DeviceArray) else (v or 0))
-        for k in ("ldy", "ldr", "B", "T", "H", "reverse"):
+        for k in ("ldy", "ldr", "B", "T", "H", "reverse", "ytb", "ldt"):
             setattr(a, k, int(j.get(k, 0)))
     return arr
 

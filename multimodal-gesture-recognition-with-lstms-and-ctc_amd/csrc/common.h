@@ -83,3 +83,5 @@ __host__ __device__ static inline float mgr_drop_scale(uint64_t seed, uint64_t i
   float u = (float)(mgr_rand_u32(seed, idx) >> 8) * (1.0f / 16777216.0f);
   return (u >= p) ? inv_keep : 0.0f;
 }
+// XT[b * xtb + f * ldt + t] = X[(b * T + t) * ldx + f], zero for T <= t < ldt_fill (gemm.hip)
+int mgr_transpose_bt_strided(mgr_ctx* c, const float* X, int ldx, float* XT, int ldt, long long xtb, int ldt_fill, int B, int T, int F);

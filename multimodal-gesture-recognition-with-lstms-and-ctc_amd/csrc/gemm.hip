@@ -997,12 +997,13 @@ int mgr_lstm_input_proj_dropout_t(mgr_ctx* c, const float* XT, int ldt, const fl
 
 // XT[b][f][0..ldt) = X[b][0..T)[f], zero for t >= T (ldt: T padded to whole row tiles of the dropout-aware projection)
 namespace {
-__global__ __launch_bounds__(256) void k_transpose_bt(const float* __restrict__ X, int ldx, float* __restrict__ XT, int ldt, int T, int F) {
+__global__ __launch_bounds__(256) void k_transpose_bt(const float* __restrict__ X, int ldx, float* __restrict__ XT, int ldt, int T, int F,
+                                                      long long xtb /* batch stride of XT; 0: F * ldt */, int fill /* columns written: ldt or less */) {
   __shared__ float tile[64][65];
   const int b = blockIdx.z, t0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
   const float* Xb = X + (size_t)b * T * ldx;
-  float* XTb = XT + (size_t)b * F * ldt;
+  float* XTb = XT + (size_t)b * (xtb ? (size_t)xtb : (size_t)F * ldt);
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int t = t0 + ty + 4 * i, f = f0 + tx;
@@ -1012,7 +1013,7 @@ __global__ __launch_bounds__(256) void k_transpose_bt(const float* __restrict__ 
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int f = f0 + ty + 4 * i, t = t0 + tx;
-    if (f < F && t < ldt) XTb[(size_t)f * ldt + t] = tile[tx][ty + 4 * i];
+    if (f < F && t < fill) XTb[(size_t)f * ldt + t] = tile[tx][ty + 4 * i];
   }
 }
 }  // namespace
@@ -1021,7 +1022,7 @@ int mgr_transpose_bt(mgr_ctx* c, const float* X, int ldx, float* XT, int ldt, in
   MGR_REQUIRE(c && X && XT, "null argument");
   MGR_REQUIRE(B > 0 && T > 0 && F > 0 && ldx >= F && ldt >= T, "bad shape");
   mgr_prof_begin(c, MGR_K_MISC);
-  hipLaunchKernelGGL(k_transpose_bt, dim3((ldt + 63) / 64, (F + 63) / 64, B), dim3(256), 0, mgr_stream(c), X, ldx, XT, ldt, T, F);
+  hipLaunchKernelGGL(k_transpose_bt, dim3((ldt + 63) / 64, (F + 63) / 64, B), dim3(256), 0, mgr_stream(c), X, ldx, XT, ldt, T, F, 0LL, ldt);
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_MISC);
   return 0;
@@ -1122,7 +1123,7 @@ static int param_grads_dropout_impl(mgr_ctx* c, const float* X, int ldx, const f
     const int grid = 8 * ((B + 7) / 8) * 4 * ((Fp + BM - 1) / BM) * ((H + BN - 1) / BN);
     if (XT) {
       float* dZT = reinterpret_cast<float*>(w);   // [B][4H][ldt]
-      hipLaunchKernelGGL(k_transpose_bt, dim3((ldt + 63) / 64, (4 * H + 63) / 64, B), dim3(256), 0, s, dZ, 4 * H, dZT, ldt, T, 4 * H);
+      hipLaunchKernelGGL(k_transpose_bt, dim3((ldt + 63) / 64, (4 * H + 63) / 64, B), dim3(256), 0, s, dZ, 4 * H, dZT, ldt, T, 4 * H, 0LL, ldt);
       hipLaunchKernelGGL((k_gemm_tn_sparse<true>), dim3(grid), dim3(256), 0, s, XT, ldt, kidx, kval, kcnt, dZT, ldt, P, B, T, Fp, F, H);
     } else {
       hipLaunchKernelGGL((k_gemm_tn_sparse<false>), dim3(grid), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, dZ, 0, P, B, T, Fp, F, H);
@@ -1186,3 +1187,10 @@ int mgr_lstm_input_grad(mgr_ctx* c, const float* dZ, const float* Wp, const floa
 }
 
 }  // extern "C"
+
+int mgr_transpose_bt_strided(mgr_ctx* c, const float* X, int ldx, float* XT, int ldt, long long xtb, int ldt_fill, int B, int T, int F) {
+  hipLaunchKernelGGL(k_transpose_bt, dim3((ldt_fill + 63) / 64, (F + 63) / 64, B), dim3(256), 0, mgr_stream(c), X, ldx, XT, ldt, T, F, xtb, ldt_fill);
+  MGR_LAUNCH_CHECK();
+  return 0;
+}
+

@@ -223,6 +223,8 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     MGR_REQUIRE(j.Z && j.Up && j.Y, "job %d: null argument", i);
     MGR_REQUIRE(j.B > 0 && j.T > 0 && j.H > 0 && j.ldy >= j.H && (!j.R || j.ldr >= j.H), "job %d: bad shape", i);
     MGR_REQUIRE(aligned16(j.Z) && aligned16(j.Up) && (!j.gates || aligned16(j.gates)), "job %d: Z/Up/gates must be 16-byte aligned", i);
+    MGR_REQUIRE(!j.YT || (aligned16(j.YT) && j.ldt % 4 == 0 && j.ldt >= (j.T + 31) / 32 * 32 && j.ytb % 4 == 0 && j.ytb >= (long long)j.H * j.ldt),
+                "job %d: transposed output needs a 16-byte aligned YT, ldt %% 4 == 0, ldt >= T rounded up to 32, ytb >= H * ldt", i);
   }
   int r = mgr_prof_begin(c, MGR_K_SCAN_FWD);
   if (r) return r;
@@ -234,6 +236,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     P.any = false;
   }
   unsigned* status = nullptr;
+  bool yt_done[MGR_MAX_SCAN_JOBS] = {};
   if (P.any) {
     ClusterLaunch L;
     memset(&L, 0, sizeof(L));
@@ -290,6 +293,16 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     // tune key 7: 0 = K-split step (register-direct gather, permuted unit order), 1 = LDS-image step for every cluster,
     // 2 = K-split step with the identity unit order
     L.ksplit = c->tune[7] == 0 ? 1 : (c->tune[7] == 2 ? 2 : 0);
+    // transposed outputs: the K-split kernel writes them itself; everything else gets a transpose behind the scans (below)
+    if (mgr_cluster_uses_ks(L, P.exchange)) {
+      int k = 0;
+      for (int i = 0; i < njobs; ++i) {
+        if (!P.cluster[i]) continue;
+        ClusterJob& cj = L.job[k++];
+        cj.YT = jobs[i].YT; cj.ytb = jobs[i].ytb; cj.ldt = jobs[i].ldt;
+        yt_done[i] = jobs[i].YT != nullptr;
+      }
+    }
     if (c->tune[2]) {  // tune key 2: print the plan
       for (int i = 0; i < L.njobs; ++i)
         fprintf(stderr, "[mgr scan plan] job %d: H=%d ks=%d nw=%d tpw=%d G=%d nbg=%d wg_begin=%d\n", i, L.job[i].H,
@@ -316,6 +329,12 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     r = mgr_scan_fwd_simple(c, j.Z, j.Up, j.Y, j.ldy, j.R, j.ldr, j.gates, j.cs, j.B, j.T, j.H, j.reverse);
     if (r < 0) return r;
   }
+  for (int i = 0; i < njobs; ++i) {   // transposed outputs the scan kernel did not write itself
+    const mgr_scan_job& j = jobs[i];
+    if (!j.YT || yt_done[i]) continue;
+    r = mgr_transpose_bt_strided(c, j.Y, j.ldy, j.YT, j.ldt, j.ytb, (j.T + 31) / 32 * 32, j.B, j.T, j.H);
+    if (r) return r;
+  }
   r = mgr_prof_end(c, MGR_K_SCAN_FWD);
   if (r) return r;
   if (status && c->tune[1]) return check_launch_status(c, status, "cluster scan");
@@ -325,6 +344,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
 int mgr_lstm_scan_fwd(mgr_ctx* c, const float* Z, const float* Up, float* Y, int ldy, const float* R, int ldr,
                       float* gates, float* cs, int B, int T, int H, int reverse, void* ws, size_t ws_bytes) {
   mgr_scan_job j;
+  memset(&j, 0, sizeof(j));
   j.Z = Z; j.Up = Up; j.Y = Y; j.R = R; j.gates = gates; j.cs = cs;
   j.ldy = ldy; j.ldr = ldr; j.B = B; j.T = T; j.H = H; j.reverse = reverse;
   return mgr_lstm_scan_fwd_multi(c, 1, &j, ws, ws_bytes);

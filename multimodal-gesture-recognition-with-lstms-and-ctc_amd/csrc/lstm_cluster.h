@@ -33,6 +33,9 @@ struct ClusterJob {
   float* G;
   float* Cs;
   float* xbuf;      // [nbg][2][IMG] exchange slots (B-operand image layout)
+  float* YT;        // optional transposed output: YT[b * ytb + unit * ldt + t] = what Y[b, t, unit] gets (K-split kernel; else null)
+  long long ytb;    // ... its batch stride in floats
+  int ldt;          // ... its row length (T padded; entries t >= T of a touched 32-step chunk are written as zero)
   int ldy, ldr, B, T, H, reverse;
   int ks, tpw, nw;  // k-steps (H/4), tiles per wave, active waves per workgroup
   int G_;           // workgroups per cluster (one cluster = one 16-sample batch group)
@@ -57,6 +60,7 @@ bool mgr_cluster_supported(int ks, int tpw);
 bool mgr_cluster_ks_supported(int ks);
 // geometry of the launch that mgr_cluster_launch would issue: waves per workgroup, workgroups per CU
 void mgr_cluster_geometry(const ClusterLaunch& L, bool any_exchange, int* waves, int* per_cu);
+bool mgr_cluster_uses_ks(const ClusterLaunch& L, bool any_exchange);   // the launch will run the K-split kernel (which honours ClusterJob::YT)
 int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool any_exchange);
 
 // ---- backward (lstm_cluster_bwd.hip)

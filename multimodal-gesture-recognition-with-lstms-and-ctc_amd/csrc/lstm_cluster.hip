@@ -42,6 +42,7 @@ namespace {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int CL_WAVES = 8;
 constexpr unsigned POLL_LIMIT = 1u << 20;
+constexpr int KS_STG_ROW = 36;   // floats per lane of the transposed-output staging rows (cluster_run_ks)
 constexpr unsigned KS_ROUND_LIMIT = 1u << 16;   // K-split step: ~0.1 s of re-polling a late producer, ~1 s of lost loads
 
 template <int KS, int TPW>
@@ -326,6 +327,16 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
   const int idx = PERM ? ((ug * 4 + wave) * 16 + j) * 4 + uq : ((ug * 4 + uq) * 16 + j) * 4 + wave;   // [q][kk][j][r]
 
   float* red = smem;  // [2][tile][src wave][lane] f32x4
+  // transposed output (jb.YT): this lane's last <= 32 outputs wait in LDS (row of 36 floats: 16-byte aligned, 8 banks apart)
+  // and leave as one 128-byte row segment YT[b][unit][32-step chunk] - the transposed copy the next layer's dropout-aware
+  // projection and dW read (gemm.hip) costs no kernel of its own and no second pass over Y
+  float* stg = smem + 2 * 16 * 64 * 4 + (wave * 64 + lane) * KS_STG_ROW;
+  float* ytrow = nullptr;
+  if (jb.YT && cvalid && bvalid) {
+    ytrow = jb.YT + (size_t)b * jb.ytb + (size_t)unit * jb.ldt;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(stg + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   float* xb = jb.xbuf + (size_t)bg * 2 * IMG;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, 2 * IMG * 4, 0x00020000);
 
@@ -490,6 +501,18 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
       jb.Y[row * jb.ldy + unit] = yo;
       if (jb.G) *reinterpret_cast<float4*>(jb.G + (row * H + unit) * 4) = g4;
       if (jb.Cs) jb.Cs[row * H + unit] = c;
+      if (ytrow) {
+        stg[t & 31] = yo;
+        // the chunk [t & ~31, +32) is complete when the walk leaves it (all lanes of the launch agree on t)
+        if (reverse ? (t & 31) == 0 : ((t & 31) == 31 || t == T - 1)) {
+          float* dst = ytrow + (t & ~31);
+#pragma unroll 1
+          for (int i = 0; i < 8; ++i) {
+            *reinterpret_cast<f32x4*>(dst + 4 * i) = *reinterpret_cast<const f32x4*>(stg + 4 * i);
+            *reinterpret_cast<f32x4*>(stg + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};   // (a partial last chunk pads with zeros)
+          }
+        }
+      }
     }
   };
 
@@ -620,6 +643,12 @@ void mgr_cluster_geometry(const ClusterLaunch& L, bool any_exchange, int* waves,
   *per_cu = (*waves == 4 && (ks_eligible(L, any_exchange, *waves) || image_lds(L) <= 80 * 1024)) ? 2 : 1;
 }
 
+bool mgr_cluster_uses_ks(const ClusterLaunch& L, bool any_exchange) {
+  int waves, per_cu;
+  mgr_cluster_geometry(L, any_exchange, &waves, &per_cu);
+  return ks_eligible(L, any_exchange, waves);
+}
+
 int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool any_exchange) {
   int waves, per_cu;
   mgr_cluster_geometry(L, any_exchange, &waves, &per_cu);
@@ -641,6 +670,8 @@ int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool a
   if (ks_eligible(L, any_exchange, waves)) {
     // partial-sum exchange only (no h image)
     size_t lds_ks = 2 * 16 * 64 * 4 * sizeof(float);
+    for (int i = 0; i < L.njobs; ++i)
+      if (L.job[i].YT) lds_ks = (2 * 16 * 64 * 4 + 256 * KS_STG_ROW) * sizeof(float);   // + staging rows of the transposed output
     if (L.ksplit == 2)
       hipLaunchKernelGGL(k_scan_cluster_ks_id, dim3(total_wgs), dim3(256), lds_ks, mgr_stream(c), L);
     else

@@ -206,6 +206,7 @@ class Engine:
         self.ldt = (T + 127) // 128 * 128
         self.Y1T = {}
         self._featT = {}
+        self._featT_ready = {}   # FEAT buffer -> its transposed copy was written by the scans of the current pass
         if train and self.schedule.transposed_inputs:
             want = lambda p, F: bool(self.lib.mgr_lstm_input_proj_dropout_wants_transposed(self.dev.ctx, C.c_float(float(p)), int(F)))
             for s in sp.streams:
@@ -356,13 +357,13 @@ class Engine:
         self.Xin = self._xin_ring[slot]
         dev.stream(stream)
 
-    def _project_pair(self, X, ldx, pair, Ls, B, T, fin, H, XT=None):
+    def _project_pair(self, X, ldx, pair, Ls, B, T, fin, H, XT=None, xt_ready=False):
         """Input projections of the two directions of one Bidirectional layer (pair = [mask, Wp, bp, Z] x 2).  With input
         dropout active the library runs each direction's K loops over the kept features only (from p >= 0.3 on) - from the
         transposed copy XT of the input where the engine keeps one; otherwise both directions go through one call that fuses
         them into one GEMM where that saves tiles."""
         if pair[0] and Ls[0].ws_sp is not None:
-            if XT is not None:
+            if XT is not None and not xt_ready:     # (xt_ready: the scans that produced X wrote XT themselves, mgr_scan_job.YT)
                 self.dev.call("mgr_transpose_bt", X, ldx, XT, self.ldt, B, T, fin)
             for d in range(2):
                 m, Wp, bp, Z = pair[4 * d:4 * d + 4]
@@ -439,6 +440,7 @@ class Engine:
                 X = self.X[name]
             self._xcur[name] = X
         depth = max(len(s["layers"]) for s in sp.streams)
+        feat_by_scans = True     # every stream's last layer writes FEAT (and its transposed copy) from its scan
         for k in range(depth):
             jobs = []
             for si, s in enumerate(sp.streams):
@@ -462,22 +464,30 @@ class Engine:
                     mptr = self._prep_mask(L, train, rand, slot)
                     self._masks[(L.prefix, L.d)] = mptr
                     pair += [mptr, L.Wp, L.bp, self.Zbuf[name][di]]
-                self._project_pair(cur, ldcur, pair, Ls_pair, B, T, fin, H, XT=self.Y1T.get(name) if k == 1 else None)
+                self._project_pair(cur, ldcur, pair, Ls_pair, B, T, fin, H, XT=self.Y1T.get(name) if k == 1 else None,
+                                   xt_ready=True)
                 for di, dname in enumerate(("fwd", "bwd")):
                     L = self.dirs["%s/l%d/%s" % (name, k, dname)]
                     Z = self.Zbuf[name][di]
                     R, ldr = 0, 0
+                    YT, ytb = 0, 0      # transposed copy written by the scan itself (what the next dropout layer's GEMMs read)
                     if not last:
                         Y, ldy = self.Y1[name].view(di * H, (1,)), 2 * H
+                        if name in self.Y1T:
+                            YT, ytb = self.Y1T[name].ptr + di * H * self.ldt * 4, 2 * H * self.ldt
                     elif nl == 2 and s["residual"] and name in self.Y2 and save:
                         Y, ldy = self.Y2[name].view(di * H, (1,)), 2 * H
+                        feat_by_scans = False
                     else:
                         Y, ldy = feat_buf.view(col + di * H, (1,)), W
                         if nl == 2 and s["residual"]:
                             R, ldr = self.Y1[name].view(di * H, (1,)), 2 * H
+                        if feat_buf.ptr in self._featT:
+                            YT, ytb = self._featT[feat_buf.ptr].ptr + (col + di * H) * self.ldt * 4, W * self.ldt
                     keep = save and L.trainable
                     jobs.append(dict(Z=Z, Up=L.Up, Y=Y, ldy=ldy, R=R, ldr=ldr, gates=L.gates if keep else 0,
-                                     cs=L.cs if keep else 0, B=B, T=T, H=H, reverse=L.reverse))
+                                     cs=L.cs if keep else 0, B=B, T=T, H=H, reverse=L.reverse, YT=YT, ytb=ytb,
+                                     ldt=self.ldt if YT else 0))
             if k == 0:
                 dev.record(self.EV_IN[self._xin_slot])   # the inputs have been read (noise kernel / depth-1 projections)
             self.rng_step = saved_step
@@ -490,6 +500,7 @@ class Engine:
             yield ("scanned", k)
             saved_step, self.rng_step = self.rng_step, rng_step
             dev.stream(es)
+        self._featT_ready[feat_buf.ptr] = feat_by_scans
         for si, s in enumerate(sp.streams):
             name = s["name"]
             if len(s["layers"]) == 2 and s["residual"] and name in self.Y2 and save:
@@ -517,7 +528,8 @@ class Engine:
                 mptr = self._prep_mask(L, train, rand, 500 + di)
                 self._masks[(L.prefix, L.d)] = mptr
                 pair += [mptr, L.Wp, L.bp, self.ZF[di]]
-            self._project_pair(feat_buf, W, pair, Ls_pair, B, T, W, Hf, XT=self._featT.get(feat_buf.ptr))
+            self._project_pair(feat_buf, W, pair, Ls_pair, B, T, W, Hf, XT=self._featT.get(feat_buf.ptr),
+                               xt_ready=self._featT_ready.get(feat_buf.ptr, False))
             dev.record(self.EV_FPROJ)   # (the next step's depth-1 scan is launched after these GEMMs, _enqueue_next_encoders)
             for di, dname in enumerate(("fwd", "bwd")):
                 L = self.dirs["fusion/%s" % dname]

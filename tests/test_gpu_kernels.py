@@ -522,3 +522,52 @@ def test_param_grads_dropout_sparse_equals_dense(device, B, T, F, H, p, reverse)
             dev.call("mgr_lstm_param_grads_dropout_t", XT, ldt, dM, 0.5, dH, H, ddZ, gW, gU, gb, B, T, F, H, reverse, ws, ws.nbytes)
             assert np.array_equal(gW.download(), outs[1][0])
             assert np.array_equal(gU.download(), outs[1][1]) and np.array_equal(gb.download(), outs[1][2])
+
+
+@pytest.mark.parametrize("H,B,T,path", [(300, 20, 75, 0), (500, 33, 70, 0), (100, 16, 64, 0), (128, 5, 33, 0), (300, 20, 75, 1),
+                                        (60, 7, 40, 0), (300, 18, 50, 7)])
+def test_scan_writes_the_transposed_output_itself(device, H, B, T, path):
+    """mgr_scan_job.YT: the scans leave YT[b][col0 + u][t] = Y[b, t, u] (+ residual) with zeros behind T up to the next multiple
+    of 32, two directions into column ranges of ONE wider copy - from inside the K-split multi-CU kernel (LDS-staged rows) or,
+    for every other kernel family (path 1: fallback kernels; 7: LDS-image cluster step; small H), through the transpose
+    the call appends.  Y itself is unchanged by the option."""
+    from mgr_amd import _capi
+    dev = device
+    rng = np.random.default_rng(H + B + T)
+    ldt = (T + 127) // 128 * 128
+    W = 2 * H
+    Y = dev.zeros((B, T, W))
+    R = dev.array(rng.standard_normal((B, T, W)).astype(np.float32))
+    YT = dev.array(np.full((B, W, ldt), 7.0, np.float32))        # dirty: what is not written must be recognisable
+    jobs, keep = [], []
+    for d in range(2):
+        Z = dev.array((rng.standard_normal((B, T, 4 * H)) * 0.5).astype(np.float32))
+        U = dev.array((rng.standard_normal((H, 4 * H)) * 0.1 / np.sqrt(H)).astype(np.float32))
+        Up = dev.empty((H, 4 * H))
+        dev.call("mgr_lstm_pack", U, Up, H, H, 0)
+        keep += [Z, U, Up]
+        jobs.append(dict(Z=Z, Up=Up, Y=Y.view(d * H, (1,)), ldy=W, R=R.view(d * H, (1,)), ldr=W, gates=0, cs=0, B=B, T=T, H=H,
+                         reverse=d, YT=YT.ptr + d * H * ldt * 4, ytb=W * ldt, ldt=ldt))
+    if path == 7:
+        dev.call("mgr_tune", 7, 1)
+    else:
+        dev.call("mgr_tune", 0, path)
+    try:
+        arr = _capi.make_scan_jobs(jobs)
+        ws = dev.bytes(dev.lib.mgr_lstm_scan_multi_ws_bytes(len(jobs), arr))
+        _capi.check(dev.lib.mgr_lstm_scan_fwd_multi(dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes))
+        y, yt = Y.download(), YT.download()
+        # the same scans without the option give the same Y
+        Y2 = dev.zeros((B, T, W))
+        for d, j in enumerate(jobs):
+            j.update(Y=Y2.view(d * H, (1,)), YT=0, ytb=0, ldt=0)
+        arr2 = _capi.make_scan_jobs(jobs)
+        _capi.check(dev.lib.mgr_lstm_scan_fwd_multi(dev.ctx, len(jobs), arr2, ws.ptr, ws.nbytes))
+        assert np.array_equal(Y2.download(), y)
+    finally:
+        dev.call("mgr_tune", 0, 0)
+        dev.call("mgr_tune", 7, 0)
+    T32 = (T + 31) // 32 * 32
+    assert np.array_equal(yt[:, :, :T], y.transpose(0, 2, 1))
+    assert not yt[:, :, T:T32].any()
+    assert (yt[:, :, T32:] == 7.0).all()
