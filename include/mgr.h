@@ -135,8 +135,8 @@ typedef struct mgr_scan_job {
   int ldy, ldr, B, T, H, reverse;
   /* optional transposed copy of the output, written by the scan itself (the K-split multi-CU kernel stages 32 steps per lane
    * in LDS and stores 128-byte row segments; any other kernel family is followed by a transpose inside the call):
-   * YT[b * ytb + u * ldt + t] = what Y[b, t, u] gets, u < H; t in [T, T rounded up to 32) is written as zero.  ldt % 4 == 0,
-   * ldt >= T rounded up to 32.  NULL: none.  This is the layout mgr_lstm_input_proj_dropout_t / mgr_lstm_param_grads_dropout_t
+   * YT[b * ytb + u * ldt + t] = what Y[b, t, u] gets, u < H; t in [T, ldt) is written as zero (the buffer may arrive dirty).
+   * ldt % 4 == 0, ldt >= T rounded up to 32.  NULL: none.  This is the layout mgr_lstm_input_proj_dropout_t / mgr_lstm_param_grads_dropout_t
    * read; with ytb > H * ldt several jobs fill column ranges of one wider [B][F][ldt] copy. */
   float* YT;
   long long ytb;
@@ -149,8 +149,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
  * workgroup, 4 same with 8 tiles per workgroup.  key 1: !=0 makes scan_fwd check the give-up word synchronously.
  * key 2: print the scan plan.  key 3: 1 = K-split scan launches keep contiguous cluster ids and write-through publishes (no
  *        XCD-local exchange).
- * key 7: one-tile-per-wave clusters: 0 = K-split / register-direct gather step, 1 = LDS-image step, 2 = K-split step with
- *        hidden units in identity order (cross-check of the kernel's private unit permutation).
+ * key 7: one-tile-per-wave clusters: 0 = K-split step (register-direct gather), 1 = LDS-image step.
  * key 8: 1 = the multi-CU BPTT keeps its 4-wave kernel instead of the split-role (4 compute + 4 gather waves) one, 2 = always split.
  * key 9: 1 = mgr_lstm_input_proj_dropout always takes the dense kernel. */
 enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 16 };
@@ -158,12 +157,33 @@ int mgr_tune(mgr_ctx* ctx, int key, int value);
 /* Health of the persistent multi-CU scans launched on this context since the last mgr_scan_status_clear: *out receives the OR
  * of their status bits.  MGR_SCAN_GAVE_UP: a bounded spin expired (a dead-locked or lost peer) - the launch returned promptly
  * but its outputs are garbage; the call FAILS (mgr_last_error).  MGR_SCAN_NONFINITE: a hidden state became NaN / Inf (diverged
- * weights, bad checkpoint); the outputs carry NaN from that step on exactly as the reference's would, the call succeeds.
- * Ordered on the current stream; cheap (one 4-byte read back) - call it where results are consumed, e.g. with the loss. */
+ * weights, bad checkpoint): the output Y of that (sample, unit) is NaN from that time step on (the multi-CU exchange feeds 0 back
+ * in its place - a NaN word cannot travel through the hand-off - so the OTHER units of the sample stay finite where the
+ * reference's would turn NaN one step later; whoever consumes the outputs must treat the whole pass as NaN, as Engine.read_loss
+ * does); the call succeeds.  Ordered on the current stream; cheap (one 4-byte read back) - call it where results are consumed,
+ * e.g. with the loss. */
 enum { MGR_SCAN_GAVE_UP = 1, MGR_SCAN_NONFINITE = 8 };
 int mgr_scan_status(mgr_ctx* ctx, unsigned* out);
-/* Forget the recorded status bits (enqueued on the current stream), e.g. after restoring a good checkpoint. */
+/* The same read without the failure: out[0] = status bits, out[2] = optimizer updates skipped by the update gate (below) since
+ * the last clear, out[1] = out[3] = 0. */
+int mgr_scan_status_ex(mgr_ctx* ctx, unsigned out[4]);
+/* Forget the recorded status bits and the skipped-update count (enqueued on the current stream), e.g. after restoring a good
+ * checkpoint. */
 int mgr_scan_status_clear(mgr_ctx* ctx);
+/* Several engines may share one context: each binds its OWN status block (>= 64 zeroed bytes from mgr_alloc, 16-byte aligned)
+ * before it enqueues work; scans launched while a block is bound report into it and mgr_scan_status* / the update gate read
+ * it.  NULL binds the context's own block again.  Host-side state only (no stream order). */
+int mgr_scan_status_bind(mgr_ctx* ctx, void* block);
+/* Test hook: OR `bits` into the bound status block on the current stream, as a scan that gave up would. */
+int mgr_scan_status_inject(mgr_ctx* ctx, unsigned bits);
+/* Update gate: keeps a bad step away from the weights WITHOUT a host round trip (the host reads the status with the loss, by
+ * which time the optimizer kernels of the same step are already queued).  mgr_update_gate_eval writes flag[0] = 1.0f if
+ * (status bits & mask) else 0.0f on the current stream - put flag behind the gradient buffer and it travels with the gradient
+ * all-reduce, so that every replica takes the same decision (sum > 0 on all ranks if any rank raised it).  While a flag is set
+ * with mgr_update_gate_set (host-side state; NULL = gate open), mgr_adam_step and mgr_maxnorm_cols read it on the device and
+ * leave parameters and moments untouched when it is non-zero; each skipped mgr_adam_step is counted (mgr_scan_status_ex). */
+int mgr_update_gate_eval(mgr_ctx* ctx, unsigned mask, float* flag);
+int mgr_update_gate_set(mgr_ctx* ctx, const float* flag);
 /* Placement aid (never a correctness dependency): the current stream waits, on the device, until every workgroup of the NEXT
  * persistent scan launched on this context (on any stream) has started, or timeout_us (<= 100000) has passed.  Chip-filling
  * GEMMs enqueued behind it therefore arrive when the scan is resident instead of racing its workgroups for the CUs. */
@@ -174,6 +194,12 @@ int mgr_stream_wait_next_resident(mgr_ctx* ctx, int timeout_us);
 int mgr_persist_stats(mgr_ctx* ctx, int* launches, int* serialised);
 /* Diagnostic: out[b] = XCC (XCD) id the workgroup b of a (nblocks, threads, lds_bytes) launch ran on. */
 int mgr_probe_xcc(mgr_ctx* ctx, int nblocks, int threads, int lds_bytes, int32_t* out);
+/* Diagnostic: what a guest kernel of the shape of a collective (RCCL all-reduce: a few workgroups, tens of KiB of LDS, ~100 us)
+ * experiences on the current stream, e.g. beside resident persistent scans: a 1-block marker launch followed by the guest
+ * (nblocks x threads, lds_bytes of dynamic LDS, every block busy for ~us microseconds).  out[0], out[1] = the marker's start /
+ * end, out[2 + 2b], out[3 + 2b] = start / end of guest block b, all in ticks of the 100 MHz device wall clock.  out: device,
+ * 2 + 2 * nblocks int64. */
+int mgr_probe_guest(mgr_ctx* ctx, int nblocks, int threads, int lds_bytes, int us, int64_t* out);
 /* Diagnostic (tools/overlap_probe.py): hold the current stream for ~us microseconds on the device (bounded; 0 <= us <= 100000). */
 int mgr_stream_delay(mgr_ctx* ctx, int us);
 /* BPTT: dY[b,t,0:H] (row stride lddy) is dLoss/dh_t from above; Y (stride ldy) is the layer's own output as

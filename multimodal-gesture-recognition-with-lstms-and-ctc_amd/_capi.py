@@ -55,11 +55,17 @@ SIGNATURES = {
     "mgr_tune": (i32, [vp, i32, i32]),
     "mgr_probe_xcc": (i32, [vp, i32, i32, i32, vp]),
     "mgr_stream_delay": (i32, [vp, i32]),
+    "mgr_probe_guest": (i32, [vp, i32, i32, i32, i32, vp]),
     "mgr_host_alloc": (i32, [vp, sz, C.POINTER(vp)]),
     "mgr_host_free": (i32, [vp, vp]),
     "mgr_h2d_async": (i32, [vp, vp, vp, sz]),
     "mgr_scan_status": (i32, [vp, vp]),
     "mgr_scan_status_clear": (i32, [vp]),
+    "mgr_scan_status_ex": (i32, [vp, vp]),
+    "mgr_scan_status_bind": (i32, [vp, vp]),
+    "mgr_scan_status_inject": (i32, [vp, C.c_uint]),
+    "mgr_update_gate_eval": (i32, [vp, C.c_uint, vp]),
+    "mgr_update_gate_set": (i32, [vp, vp]),
     "mgr_stream_wait_next_resident": (i32, [vp, i32]),
     "mgr_persist_stats": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
     "mgr_skeletal_features": (i32, [vp, vp, sz, vp]),

@@ -31,7 +31,10 @@ struct mgr_ctx {
   float prof_ms[MGR_K_COUNT];
   int prof_launches[MGR_K_COUNT];
   int tune[MGR_TUNE_COUNT];
-  unsigned* sticky_status;  // device words: [0] status bits of every persistent launch since the last clear, [1] resident seq
+  unsigned* sticky_status;  // device words: [0] status bits of every persistent launch since the last clear, [1] resident seq,
+                            // [2] optimizer updates skipped by the update gate (mgr_update_gate_*)
+  unsigned* status_bound;   // mgr_scan_status_bind: the block [0] and [2] live in instead (one per engine sharing the context)
+  const float* gate_flag;   // mgr_update_gate_set: device flag that turns mgr_adam_step / mgr_maxnorm_cols into no-ops when != 0
   // persistent launches that may still be running (lstm.hip: mgr_persist_admit / mgr_persist_commit)
   struct Persist {
     hipEvent_t done;
@@ -60,6 +63,8 @@ int mgr_fail(int code, const char* fmt, ...);
 #define MGR_LAUNCH_CHECK() MGR_HIP(hipGetLastError())
 
 static inline hipStream_t mgr_stream(mgr_ctx* c) { return c->streams[c->cur]; }
+// the status block persistent scans report into and the update gate reads: the bound one, else the context's own
+static inline unsigned* mgr_status_block(mgr_ctx* c) { return c->status_bound ? c->status_bound : c->sticky_status; }
 
 // RAII-less profiling bracket: call mgr_prof_begin before and mgr_prof_end after the launches of a family.
 int mgr_prof_begin(mgr_ctx* c, int family);

@@ -175,7 +175,7 @@ int mgr_stream_wait_event(mgr_ctx* c, int waiter, int ev) {
 int mgr_scan_status(mgr_ctx* c, unsigned* out) {
   MGR_REQUIRE(c && out, "null argument");
   // on the CURRENT stream: the caller decides what it is ordered after
-  MGR_HIP(hipMemcpyAsync(out, c->sticky_status, sizeof(unsigned), hipMemcpyDeviceToHost, mgr_stream(c)));
+  MGR_HIP(hipMemcpyAsync(out, mgr_status_block(c), sizeof(unsigned), hipMemcpyDeviceToHost, mgr_stream(c)));
   MGR_HIP(hipStreamSynchronize(mgr_stream(c)));
   // MGR_SCAN_NONFINITE alone is not an error of the library: the outputs carry the NaN, like the reference's would
   MGR_REQUIRE((*out & ~(unsigned)MGR_SCAN_NONFINITE) == 0,
@@ -183,9 +183,52 @@ int mgr_scan_status(mgr_ctx* c, unsigned* out) {
   return 0;
 }
 
+int mgr_scan_status_ex(mgr_ctx* c, unsigned out[4]) {
+  MGR_REQUIRE(c && out, "null argument");
+  MGR_HIP(hipMemcpyAsync(out, mgr_status_block(c), 4 * sizeof(unsigned), hipMemcpyDeviceToHost, mgr_stream(c)));
+  MGR_HIP(hipStreamSynchronize(mgr_stream(c)));
+  out[1] = 0;   // (the resident word of the context's own block is not part of this interface)
+  out[3] = 0;
+  return 0;
+}
+
 int mgr_scan_status_clear(mgr_ctx* c) {
   MGR_REQUIRE(c, "null ctx");
-  MGR_HIP(hipMemsetAsync(c->sticky_status, 0, sizeof(unsigned), mgr_stream(c)));
+  unsigned* blk = mgr_status_block(c);
+  MGR_HIP(hipMemsetAsync(blk, 0, sizeof(unsigned), mgr_stream(c)));
+  MGR_HIP(hipMemsetAsync(blk + 2, 0, sizeof(unsigned), mgr_stream(c)));
+  return 0;
+}
+
+int mgr_scan_status_bind(mgr_ctx* c, void* block) {
+  MGR_REQUIRE(c, "null ctx");
+  MGR_REQUIRE((reinterpret_cast<uintptr_t>(block) & 15) == 0, "status block must be 16-byte aligned");
+  c->status_bound = reinterpret_cast<unsigned*>(block);
+  return 0;
+}
+
+namespace {
+__global__ void k_gate_eval(const unsigned* status, unsigned mask, float* flag) { flag[0] = (status[0] & mask) ? 1.f : 0.f; }
+__global__ void k_status_or(unsigned* status, unsigned bits) { atomicOr(status, bits); }
+}  // namespace
+
+int mgr_update_gate_eval(mgr_ctx* c, unsigned mask, float* flag) {
+  MGR_REQUIRE(c && flag, "null argument");
+  hipLaunchKernelGGL(k_gate_eval, dim3(1), dim3(1), 0, mgr_stream(c), mgr_status_block(c), mask, flag);
+  MGR_LAUNCH_CHECK();
+  return 0;
+}
+
+int mgr_update_gate_set(mgr_ctx* c, const float* flag) {
+  MGR_REQUIRE(c, "null ctx");
+  c->gate_flag = flag;
+  return 0;
+}
+
+int mgr_scan_status_inject(mgr_ctx* c, unsigned bits) {
+  MGR_REQUIRE(c, "null ctx");
+  hipLaunchKernelGGL(k_status_or, dim3(1), dim3(1), 0, mgr_stream(c), mgr_status_block(c), bits);
+  MGR_LAUNCH_CHECK();
   return 0;
 }
 

@@ -66,8 +66,16 @@ __global__ void k_transpose(const float* __restrict__ src, float* __restrict__ d
   }
 }
 
+// `gate` (may be null): device flag of the update gate (mgr_update_gate_set) - non-zero means a scan of this step reported a
+// give-up / non-finite state (on any rank: the flag travels with the gradient all-reduce), the update is skipped as a whole and
+// counted in the status block
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                       size_t n, float lr_t, float b1, float b2, float eps, float clipvalue, float gscale) {
+                       size_t n, float lr_t, float b1, float b2, float eps, float clipvalue, float gscale,
+                       const float* __restrict__ gate, unsigned* __restrict__ skipped) {
+  if (gate && gate[0] != 0.f) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1u);
+    return;
+  }
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float gi = g[i] * gscale;
     if (clipvalue > 0.f) gi = fminf(fmaxf(gi, -clipvalue), clipvalue);
@@ -83,8 +91,10 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
 // layer), the kernel sits on the critical chain between the optimizer and the next step's projections and runs beside
 // chip-filling GEMMs there, so what counts is the length of each thread's dependent load chain
 constexpr int MN_RG = 32;
-__global__ __launch_bounds__(32 * MN_RG) void k_maxnorm(float* __restrict__ W, int rows, int cols, float maxv, float eps) {
+__global__ __launch_bounds__(32 * MN_RG) void k_maxnorm(float* __restrict__ W, int rows, int cols, float maxv, float eps,
+                                                         const float* __restrict__ gate) {
   __shared__ float part[MN_RG][32];
+  if (gate && gate[0] != 0.f) return;   // update gate closed (k_adam): the weights stay exactly as they were
   int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   int c = blockIdx.x * 32 + tx;
   float s = 0.f;
@@ -159,6 +169,25 @@ __global__ void k_probe_xcc(int32_t* out) {
   if (threadIdx.x == 0) out[blockIdx.x] = (int32_t)(x & 0xF);
 }
 
+// Guest probe: what a collective's kernel (RCCL all-reduce: a few workgroups with tens of KiB of LDS that wait for other GPUs)
+// experiences when it is launched beside resident persistent scans.  Block 0 of a 1-block launch is the MARKER (records when
+// the stream reached this point); every block of the guest records when it started and when it left.  100 MHz wall clock.
+__global__ void k_guest(long long* __restrict__ out, int us) {
+  extern __shared__ float dummy[];
+  const unsigned long long t0 = wall_clock64();
+  if (us > 0) {
+    const unsigned long long ticks = (unsigned long long)us * 100ull;
+    for (int i = 0; i < (1 << 22); ++i) {
+      if (wall_clock64() - t0 >= ticks) break;
+      __builtin_amdgcn_s_sleep(16);
+    }
+  }
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = (long long)t0;
+    out[2 * blockIdx.x + 1] = (long long)wall_clock64();
+  }
+}
+
 }  // namespace
 
 // Holds the stream for ~`us` microseconds (constant 100 MHz counter), bounded.  Used to order the PLACEMENT of two launches
@@ -179,6 +208,16 @@ int mgr_stream_delay(mgr_ctx* c, int us) {
   MGR_REQUIRE(c && us >= 0 && us <= 100000, "bad argument");
   if (us == 0) return 0;
   hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, mgr_stream(c), us);
+  MGR_LAUNCH_CHECK();
+  return 0;
+}
+
+int mgr_probe_guest(mgr_ctx* c, int nblocks, int threads, int lds_bytes, int us, int64_t* out) {
+  MGR_REQUIRE(c && out && nblocks > 0 && threads > 0 && threads <= 1024 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && us >= 0 && us <= 100000,
+              "bad argument");
+  MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_guest), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipLaunchKernelGGL(k_guest, dim3(1), dim3(64), 0, mgr_stream(c), reinterpret_cast<long long*>(out), 0);   // marker
+  hipLaunchKernelGGL(k_guest, dim3(nblocks), dim3(threads), lds_bytes, mgr_stream(c), reinterpret_cast<long long*>(out) + 2, us);
   MGR_LAUNCH_CHECK();
   return 0;
 }
@@ -232,7 +271,8 @@ int mgr_adam_step(mgr_ctx* c, float* p, const float* g, float* m, float* v, size
   MGR_REQUIRE(c && p && g && m && v, "null argument");
   if (n == 0) return 0;
   mgr_prof_begin(c, MGR_K_ADAM);
-  hipLaunchKernelGGL(k_adam, dim3(grid_for(n)), dim3(kBlock), 0, mgr_stream(c), p, g, m, v, n, lr_t, b1, b2, eps, clipvalue, gscale);
+  hipLaunchKernelGGL(k_adam, dim3(grid_for(n)), dim3(kBlock), 0, mgr_stream(c), p, g, m, v, n, lr_t, b1, b2, eps, clipvalue, gscale,
+                     c->gate_flag, mgr_status_block(c) + 2);
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_ADAM);
   return 0;
@@ -241,7 +281,7 @@ int mgr_adam_step(mgr_ctx* c, float* p, const float* g, float* m, float* v, size
 int mgr_maxnorm_cols(mgr_ctx* c, float* W, int rows, int cols, float maxv, float eps) {
   MGR_REQUIRE(c && W, "null argument");
   MGR_REQUIRE(rows > 0 && cols > 0, "bad shape");
-  hipLaunchKernelGGL(k_maxnorm, dim3((cols + 31) / 32), dim3(32 * MN_RG), 0, mgr_stream(c), W, rows, cols, maxv, eps);
+  hipLaunchKernelGGL(k_maxnorm, dim3((cols + 31) / 32), dim3(32 * MN_RG), 0, mgr_stream(c), W, rows, cols, maxv, eps, c->gate_flag);
   MGR_LAUNCH_CHECK();
   return 0;
 }

@@ -246,7 +246,16 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     w += kScanHdrBytes;
     // K-split launches (every job a 4-wave, one-tile-per-wave cluster with an exchange) lay their clusters out XCD-locally
     // (tune key 3 = 1 turns that off); the table of workgroup XCD ids lives in the launch header
-    bool xcd = c->tune[3] == 0 && c->tune[7] == 0 && P.exchange;
+    // the K-split step addresses Z and the residual input with 32-bit byte offsets per lane (LDS-DMA prefetch): launches with a
+    // larger tensor take the LDS-image step
+    bool ks_ok = c->tune[7] == 0;
+    for (int i = 0; i < njobs && ks_ok; ++i) {
+      if (!P.cluster[i]) continue;
+      const mgr_scan_job& j = jobs[i];
+      const size_t zb = (size_t)j.B * j.T * 4 * j.H * sizeof(float), rb = j.R ? (size_t)j.B * j.T * j.ldr * sizeof(float) : 0;
+      ks_ok = zb < ((size_t)1 << 32) && rb < ((size_t)1 << 32);
+    }
+    bool xcd = c->tune[3] == 0 && ks_ok && P.exchange;
     {
       int tot = 0;
       for (int i = 0; i < njobs && xcd; ++i) {
@@ -290,9 +299,8 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
       cj.xbuf = reinterpret_cast<float*>(w);
       w += mgr_align_up((size_t)P.nbg[i] * 2 * img * sizeof(float), 256);
     }
-    // tune key 7: 0 = K-split step (register-direct gather, permuted unit order), 1 = LDS-image step for every cluster,
-    // 2 = K-split step with the identity unit order
-    L.ksplit = c->tune[7] == 0 ? 1 : (c->tune[7] == 2 ? 2 : 0);
+    // tune key 7: 0 = K-split step for one-tile-per-wave clusters, 1 = LDS-image step for every cluster
+    L.ksplit = ks_ok ? 1 : 0;
     // transposed outputs: the K-split kernel writes them itself; everything else gets a transpose behind the scans (below)
     if (mgr_cluster_uses_ks(L, P.exchange)) {
       int k = 0;
@@ -312,7 +320,8 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     int waves, per_cu;
     mgr_cluster_geometry(L, P.exchange, &waves, &per_cu);
     L.cm.status = status;
-    L.cm.sticky = c->sticky_status;
+    L.cm.sticky = mgr_status_block(c);
+    L.cm.resident = c->sticky_status + 1;
     L.cm.total_wgs = P.total;
     r = mgr_persist_admit(c, P.total, waves, per_cu, &L.cm.seq);
     if (r) return r;
@@ -332,7 +341,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
   for (int i = 0; i < njobs; ++i) {   // transposed outputs the scan kernel did not write itself
     const mgr_scan_job& j = jobs[i];
     if (!j.YT || yt_done[i]) continue;
-    r = mgr_transpose_bt_strided(c, j.Y, j.ldy, j.YT, j.ldt, j.ytb, (j.T + 31) / 32 * 32, j.B, j.T, j.H);
+    r = mgr_transpose_bt_strided(c, j.Y, j.ldy, j.YT, j.ldt, j.ytb, j.ldt, j.B, j.T, j.H);
     if (r) return r;
   }
   r = mgr_prof_end(c, MGR_K_SCAN_FWD);
@@ -409,7 +418,8 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
     int waves, per_cu;
     mgr_cluster_bwd_geometry(c, L, grid, &waves, &per_cu);
     L.cm.status = status;
-    L.cm.sticky = c->sticky_status;
+    L.cm.sticky = mgr_status_block(c);
+    L.cm.resident = c->sticky_status + 1;
     L.cm.total_wgs = grid;
     r = mgr_persist_admit(c, grid, waves, per_cu, &L.cm.seq);
     if (r) return r;
@@ -529,7 +539,7 @@ __global__ void k_wait_resident(const unsigned* resident, unsigned seq, unsigned
 extern "C" {
 
 int mgr_stream_wait_next_resident(mgr_ctx* c, int timeout_us) {
-  MGR_REQUIRE(c && timeout_us >= 0, "bad argument");
+  MGR_REQUIRE(c && timeout_us >= 0 && timeout_us <= 100000, "timeout_us must be in [0, 100000]");
   hipLaunchKernelGGL(k_wait_resident, dim3(1), dim3(1), 0, mgr_stream(c), c->sticky_status + 1, c->persist_seq + 1, (unsigned)timeout_us);
   MGR_LAUNCH_CHECK();
   return 0;

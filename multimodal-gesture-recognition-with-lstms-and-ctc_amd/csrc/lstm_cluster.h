@@ -9,9 +9,10 @@ constexpr int MGR_MAX_SCAN_JOBS = 8;
 //   [0] give-up code of THIS launch (a bounded spin expired)          [1] arrival counter (workgroups that have started)
 constexpr size_t kScanHdrBytes = 4096;   //   [64, 1024) XCC (XCD) id + 1 of every workgroup of the launch (XCD-local exchange)
 
-// Context-wide words (mgr_ctx::sticky_status, never cleared by a launch):
+// Status block (mgr_ctx::sticky_status, or the block bound with mgr_scan_status_bind; never cleared by a launch):
 //   [0] OR of every launch's status bits since the last mgr_scan_status_clear
-//   [1] highest launch sequence number whose workgroups have ALL started (mgr_stream_wait_next_resident polls it)
+//   [1] (context's own block only) highest launch sequence number whose workgroups have ALL started (mgr_stream_wait_next_resident)
+//   [2] optimizer updates skipped by the update gate since the last clear
 enum : unsigned {
   MGR_ST_GAVE_UP = MGR_SCAN_GAVE_UP,       // a bounded spin expired: a peer workgroup never showed up / never published
   MGR_ST_NONFINITE = MGR_SCAN_NONFINITE,   // a hidden state became NaN / Inf: outputs carry NaN from that step on (not a hang)
@@ -20,7 +21,8 @@ enum : unsigned {
 // What every persistent launch carries besides its jobs.
 struct ClusterCommon {
   unsigned* status;   // launch header (see kScanHdrBytes)
-  unsigned* sticky;   // context-wide words
+  unsigned* sticky;   // status block the launch reports into (mgr_scan_status_bind; the context's own by default)
+  unsigned* resident; // context-wide word: highest launch sequence number whose workgroups have all started
   unsigned seq;       // launch sequence number of this context (1, 2, ...)
   int total_wgs;      // grid size: the arrival that makes the counter reach it publishes `seq` as resident
 };
@@ -35,7 +37,7 @@ struct ClusterJob {
   float* xbuf;      // [nbg][2][IMG] exchange slots (B-operand image layout)
   float* YT;        // optional transposed output: YT[b * ytb + unit * ldt + t] = what Y[b, t, unit] gets (K-split kernel; else null)
   long long ytb;    // ... its batch stride in floats
-  int ldt;          // ... its row length (T padded; entries t >= T of a touched 32-step chunk are written as zero)
+  int ldt;          // ... its row length (T padded; entries t in [T, ldt) are written as zero)
   int ldy, ldr, B, T, H, reverse;
   int ks, tpw, nw;  // k-steps (H/4), tiles per wave, active waves per workgroup
   int G_;           // workgroups per cluster (one cluster = one 16-sample batch group)
@@ -49,7 +51,7 @@ struct ClusterJob {
 struct ClusterLaunch {
   ClusterCommon cm;
   int njobs;
-  int ksplit;        // one-tile-per-wave clusters use the K-split step (cluster_run_ks): register-direct gather
+  int ksplit;        // one-tile-per-wave clusters use the K-split step (cluster_run_ks: register-direct gather); 0 = LDS-image step
   int xcd_local;     // K-split launches: clusters are laid out on workgroup ids congruent mod 8 (one XCD under the dispatcher's
                      // round-robin); a cluster that FINDS all its members on one XCD publishes with plain stores into that L2
   ClusterJob job[MGR_MAX_SCAN_JOBS];
@@ -95,7 +97,7 @@ int mgr_persist_commit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu);
 __device__ __forceinline__ void mgr_cluster_enter(const ClusterCommon& cm) {
   if (threadIdx.x == 0) {
     const unsigned n = __hip_atomic_fetch_add(cm.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    if (n == (unsigned)cm.total_wgs) __hip_atomic_fetch_max(cm.sticky + 1, cm.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n == (unsigned)cm.total_wgs) __hip_atomic_fetch_max(cm.resident, cm.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 // XCD-local exchange (forward K-split and BPTT cluster kernels).  Workgroup ids are dealt round-robin over the 8 XCDs (observed,

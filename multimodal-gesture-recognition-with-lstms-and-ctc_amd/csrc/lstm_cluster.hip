@@ -32,6 +32,7 @@
 // lstm.hip::mgr_persist_admit, which serialises a launch that would not fit beside the persistent launches in flight.
 // Every workgroup counts itself in at start (mgr_cluster_enter); the last arrival publishes the launch as resident, which is
 // what mgr_stream_wait_next_resident lets another stream wait for before it sends chip-filling GEMMs.
+#include <algorithm>
 #include <type_traits>
 
 #include "lstm_cluster.h"
@@ -42,8 +43,6 @@ namespace {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int CL_WAVES = 8;
 constexpr unsigned POLL_LIMIT = 1u << 20;
-constexpr int KS_STG_ROW = 36;   // floats per lane of the transposed-output staging rows (cluster_run_ks)
-constexpr unsigned KS_ROUND_LIMIT = 1u << 16;   // K-split step: ~0.1 s of re-polling a late producer, ~1 s of lost loads
 
 template <int KS, int TPW>
 __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int bg, int ug, float* smem, unsigned* status) {
@@ -258,30 +257,79 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int bg, int ug
   }
 }
 // ---------------------------------------------------------------------------------------------------------------
-// K-split variant of the one-tile-per-wave cluster step (4 waves, 4 tiles = ONE 1 KiB image block per workgroup).
+// K-split variant of the one-tile-per-wave cluster step (4 waves, 4 tiles = ONE 1 KiB image block per workgroup; the default
+// for every cluster with an exchange that the planner gives one tile per wave).
 // Instead of gathering the whole h_{t-1} image into LDS, joining at a barrier and then letting every wave run the full
 // K loop for its own tile, wave w here owns a QUARTER OF K for ALL FOUR tiles of the workgroup:
-//   * it polls only the image blocks of its K range and takes them STRAIGHT INTO REGISTERS as MFMA B operands (the
+//   * it fetches only the image blocks of its K range and takes them STRAIGHT INTO REGISTERS as MFMA B operands (the
 //     block layout [kk][sample][r] is exactly the B fragment of four consecutive k-steps) - no LDS image, no B-operand
-//     ds_reads under the MFMAs, no barrier between gather and MFMA; blocks still showing the previous epoch are polled again.
+//     ds_reads under the MFMAs, no barrier between gather and MFMA.  The loads are ordinary sc1 buffer loads that hipcc
+//     sees and waits for; every word is validated by its epoch parity (the data is the flag), and a wave that finds a
+//     word of the previous epoch fetches its blocks again.
 //   * the four partial sums per tile are exchanged through 16 KiB of LDS (double-buffered on the step parity: ONE
 //     barrier per step), then every wave finishes a quarter of the workgroup's 16 x 16 (unit, sample) cells: adds Z_t,
-//     runs the cell, publishes h_t (same data-is-the-flag parity words as cluster_run) and streams Y / gates / c out.
+//     runs the cell, publishes h_t (same parity words as cluster_run) and streams Y / gates / c out.
 //
 // Which hidden unit sits in which MFMA slot is this kernel's private choice (U rows / columns, Z, Y, gates and c are
 // addressed through it; nothing outside sees it).  Block q of the image holds the nv = min(4, KS - 4q) tiles 4q .. 4q+nv-1;
-//   slot (tile 4q + r, unit-in-tile u)  <->  hidden unit 16q + nv*u + r        (PERM; identity order 4*(4q+r) + u otherwise)
+//   slot (tile 4q + r, unit-in-tile u)  <->  hidden unit 16q + nv*u + r
 // and the finishing lane (r = lane>>4, sample j = lane&15) of wave u owns exactly that slot.  With this order
 //   * a wave's 64 h words of one step are the 256 CONTIGUOUS bytes [q][kk = u][j][r] of the image: after one ds_bpermute the
 //     wave publishes them as ONE coalesced store instruction = two whole 128-byte lines (the identity order makes every wave
 //     write one dword of every 16-byte chunk of the block: 32 quarter-filled line writes per workgroup and step, and a
-//     reader that sees a line between two of them polls again);
-//   * the four lanes r = 0..3 of a sample hold four CONSECUTIVE units: Z loads, Y / gate / c stores stay as coalesced as
-//     in the identity order.
-template <int KS, bool PERM>
-__device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const ClusterCommon& cm, int bg, int ug, float* smem, bool fast = false) {
+//     reader that sees a line between two of them fetches again);
+//   * the four lanes r = 0..3 of a sample hold four CONSECUTIVE units: Y / gate / c stores stay coalesced.
+//
+// What keeps the dependent chain of a step short (round 3; the register-polling form it replaces - gather loads hidden from
+// hipcc in inline asm, destination registers polled - was 3.5 / 5.1 us per step at H = 500 alone / with the skeletal clusters
+// beside it, this form 2.9 / 4.6, and it needs no check of the generated assembly):
+//   * NO load in the time loop that hipcc can see EXCEPT the gather itself.  hipcc merges its wait-count scoreboard
+//     conservatively across the time loop: any load that may still be pending at the loop head (a Z prefetch, a status poll,
+//     the weight loads of the prologue) turns into an s_waitcnt vmcnt(0) in front of the MFMA chain and at the top of every
+//     step, and vmcnt(0) also waits for the acknowledgement of the wave's own stores of the step before and for the prefetch
+//     from HBM.  So: the weight loads are retired by a wait hipcc can see before the loop; the status word is read through an
+//     opaque asm (waited for on the spot, rare path); and Z_t / R_t arrive by LDS-DMA (global_load_lds: no register
+//     destination, nothing for the compiler to track) through 2-deep per-wave LDS rings, one step ahead, with an explicit
+//     counted wait where they are read.
+//   * memory operations complete in issue order: a prefetch from HBM issued in FRONT of the gather holds the gathered blocks
+//     (L2 hits) back for the length of its miss.  The prefetch of step t+1 is issued from inside the MFMA chain of step t (the
+//     matrix pipe is busy anyway), behind the gather.
+//   * XCD-local clusters publish with plain stores (lstm_cluster.h), whose acknowledgement comes from the local L2: the
+//     vmcnt(0) of the next gather, which covers them, costs next to nothing.
+// Measured and not kept (profiles/r03_scan_*): hint flags (every publishing wave also stores its epoch; a consumer polls the 32
+// flags of its producers and fetches the payload once) - the extra round trip costs more than the re-fetches it saves (3.6 / 5.0);
+// LDS-DMA landing zones for the payload, polled with ds_reads - presetting the zones, issuing eight DMA instructions (~150
+// cycles each) and the LDS traffic put 1.4k cycles in front of every gather (4.5 / 5.6); re-fetching only the stale blocks
+// (4.1 / 5.3); a raised wave priority for the cell phase, or for the wider layer's waves (no change).
+typedef __attribute__((address_space(3))) float lds_float;
+constexpr int KS_STG = 8;                      // steps per staged chunk of the transposed output
+constexpr unsigned KS_ROUND_LIMIT = 1u << 20;  // re-fetch rounds of one wave before it gives up (~1 s)
+
+// LDS-DMA: one wave-instruction copies 64 x 16 B (64 x 4 B) from global memory [gbase + voff] (gbase wave-uniform, voff per
+// lane) to LDS [lds_addr + 16 (4) * lane]; M0 carries the LDS address and is restored (hipcc does not know it was touched)
+__device__ __forceinline__ void mgr_dma_b128(const void* gbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(gbase), "s"(lds_addr)
+               : "memory");
+}
+__device__ __forceinline__ void mgr_dma_b32(const void* gbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 sc1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(gbase), "s"(lds_addr)
+               : "memory");
+}
+
+// LDS of one workgroup (floats): partial sums [2][16][64] f32x4 | 4 staging tiles [8][64] of the transposed output | 4 Z rings
+// [2][64] f32x4 | 4 residual rings [2][64]
+constexpr int KS_LDS_FLOATS = 2 * 16 * 64 * 4 + 4 * KS_STG * 64 + 4 * 2 * 256 + 4 * 2 * 64;
+
+template <int KS>
+__device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const ClusterCommon& cm, int bg, int ug, float* smem, bool fast) {
   constexpr int H = 4 * KS, N = 4 * H, QN = (KS + 3) / 4, IMG = QN * 256, NBW = (QN + 3) / 4;
-  static_assert(NBW <= 8, "at most 8 image blocks per wave (H <= 512)");
+  static_assert(NBW >= 1 && NBW <= 8, "1..8 image blocks per wave (H <= 512)");
   unsigned* status = cm.status;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..3
@@ -293,21 +341,15 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
   const float* __restrict__ Z = jb.Z;
   const float* __restrict__ Up = jb.Up;
 
-  // hidden unit of MFMA slot (tile, unit-in-tile) = of k-slot (s = tile, kk = unit-in-tile)
-  auto unit_of = [](int tile, int u) {
-    if (!PERM) return tile * 4 + u;
+  auto unit_of = [](int tile, int u) {   // hidden unit of MFMA slot (tile, unit-in-tile): see cluster_run_ks
     const int q = tile >> 2, nv = (KS - 4 * q) < 4 ? (KS - 4 * q) : 4;
     return 16 * q + nv * u + (tile & 3);
   };
-
-  // K range of this wave: image blocks [qb, qb + nb)
-  const int qb = wave * NBW;
+  const int qb = wave * NBW;     // K range of this wave: image blocks [qb, qb + nb) = what unit groups qb .. qb + nb - 1 publish
   int nb = QN - qb;
   nb = nb < 0 ? 0 : (nb > NBW ? NBW : nb);
   nb = __builtin_amdgcn_readfirstlane(nb);
 
-  // U^T fragments of the workgroup's four tiles for this wave's k-steps (zero where tile or k-step does not exist):
-  // A[m = lane&15 = 4*(unit-in-tile) + gate][k = lane>>4] = U[unit of k-slot (s, uq)][packed column of slot (tile, j>>2), gate j&3]
   float uf[4][NBW * 4];
 #pragma unroll
   for (int tt = 0; tt < 4; ++tt) {
@@ -318,143 +360,112 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
       uf[tt][sl] = (gt < KS && s < KS) ? Up[(size_t)unit_of(s, uq) * N + unit_of(gt, j >> 2) * 4 + (j & 3)] : 0.f;
     }
   }
-  // the cell this lane finishes: PERM: slot (tile 4*ug + uq, unit-in-tile wave); identity: slot (tile 4*ug + wave, unit-in-tile uq)
-  const int ftile = ug * 4 + (PERM ? uq : wave);
-  const bool cvalid = ftile < KS;   // (identity order: wave-uniform)
-  const int unit = cvalid ? unit_of(ftile, PERM ? wave : uq) : 0;
-  // where its partial sums lie in the reduction buffer [tile][src wave][slot lane = u*16 + j], and its word of the image
-  const int red_off = PERM ? ((uq * 4) * 64 + wave * 16 + j) * 4 : ((wave * 4) * 64 + lane) * 4;
-  const int idx = PERM ? ((ug * 4 + wave) * 16 + j) * 4 + uq : ((ug * 4 + uq) * 16 + j) * 4 + wave;   // [q][kk][j][r]
+  const int ftile = ug * 4 + uq;     // the cell this lane finishes: slot (tile 4*ug + uq, unit-in-tile wave)
+  const bool cvalid = ftile < KS;
+  const int unit = cvalid ? unit_of(ftile, wave) : 0;
+  const int red_off = ((uq * 4) * 64 + wave * 16 + j) * 4;
 
-  float* red = smem;  // [2][tile][src wave][lane] f32x4
-  // transposed output (jb.YT): this lane's last <= 32 outputs wait in LDS (row of 36 floats: 16-byte aligned, 8 banks apart)
-  // and leave as one 128-byte row segment YT[b][unit][32-step chunk] - the transposed copy the next layer's dropout-aware
-  // projection and dW read (gemm.hip) costs no kernel of its own and no second pass over Y
-  float* stg = smem + 2 * 16 * 64 * 4 + (wave * 64 + lane) * KS_STG_ROW;
+  float* red = smem;                                               // [2][tile][src wave][lane] f32x4
+  float* stg = smem + 2 * 16 * 64 * 4 + wave * (KS_STG * 64);      // [KS_STG][64 lanes]
+  float* zring = smem + 2 * 16 * 64 * 4 + 4 * KS_STG * 64 + wave * (2 * 256);                  // [2][64] f32x4
+  float* rring = smem + 2 * 16 * 64 * 4 + 4 * KS_STG * 64 + 4 * 2 * 256 + wave * (2 * 64);    // [2][64]
+  const unsigned zring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)zring);
+  const unsigned rring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)rring);
   float* ytrow = nullptr;
   if (jb.YT && cvalid && bvalid) {
     ytrow = jb.YT + (size_t)b * jb.ytb + (size_t)unit * jb.ldt;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(stg + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < KS_STG; ++i) stg[i * 64 + lane] = 0.f;
   }
   float* xb = jb.xbuf + (size_t)bg * 2 * IMG;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, 2 * IMG * 4, 0x00020000);
+  // Z_t (and the residual input R_t) of this lane's cell come through 2-deep per-wave LDS rings filled by LDS-DMA one step
+  // ahead.  Why not a plain load: hipcc puts an s_waitcnt vmcnt(0) for ANY pending load it can see in front of the MFMA chain
+  // and at the loop head (it merges its scoreboard conservatively across the time loop), so a visible prefetch from HBM is
+  // waited for in full, on the critical path, right after it is issued.  A DMA has no register destination - nothing for the
+  // compiler to wait for - and its landing is covered by the wait of the NEXT step's gather (memory operations complete in
+  // issue order).  Byte offsets of the lane within Z / R: the launcher admits only tensors below 4 GiB.
+  const unsigned zvoff = (unsigned)(((size_t)bc * T * N + (size_t)unit * 4) * sizeof(float));
+  const unsigned rvoff = jb.R ? (unsigned)(((size_t)bc * T * jb.ldr + unit) * sizeof(float)) : 0u;
+  auto prefetch = [&](int step) {   // (everything wave-uniform except the lane offsets)
+    if (step < T) {
+      const int t = reverse ? T - 1 - step : step;
+      mgr_dma_b128(Z + (size_t)t * N, zvoff, zring_lds + (step & 1) * 1024);
+      if (jb.R) mgr_dma_b32(jb.R + (size_t)t * jb.ldr, rvoff, rring_lds + (step & 1) * 256);
+    }
+  };
+  prefetch(0);
+  // (a wait hipcc can see: with the weight loads retired before the time loop its scoreboard enters the loop empty; otherwise the
+  // loop-head merge keeps them "maybe pending" and every MFMA chain gets an s_waitcnt vmcnt(0) in front - behind the Z prefetch)
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
 
   float c = 0.f;
   bool nonfinite = false;
-  f32x4 zr0 = {0.f, 0.f, 0.f, 0.f}, zr1 = zr0, zr2 = zr0;
-  auto loadz = [&](f32x4& z, int step) {
-    if (step < T && cvalid) {
-      const int t = reverse ? T - 1 - step : step;
-      z = *reinterpret_cast<const f32x4*>(Z + ((size_t)bc * T + t) * N + unit * 4);
-    }
-  };
-  loadz(zr0, 0);
-  loadz(zr1, 1);
   bool failed = false;
-
-  // ---- gather: the image blocks of this wave's K range go straight into registers.
-  // The loads are issued from inline asm, so hipcc does not know that the registers have loads pending and inserts no
-  // s_waitcnt in front of their readers; instead the wave POLLS THE REGISTERS: they are preset to a pattern no h word can
-  // have (quiet-NaN exponent, wrong epoch parity) and an empty asm with "+v" constraints makes every iteration re-read
-  // them.  A word that still shows the preset has not landed; a landed word with the previous epoch's parity means the
-  // producer was late and the block is fetched again.  Nothing here waits on vmcnt, so the wave's own write-through
-  // stores (whose acknowledgement takes longer than a load round trip) are never waited for.  That no compiler-inserted
-  // copy or spill touches these registers while a load may be in flight is verified on the device assembly of every build
-  // (_build.check_hidden_loads).  A non-finite h can never be mistaken for the preset: the cell replaces it before
-  // publishing (below).
-  auto hidden_load = [&](u32x4& dst, const char* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(dst) : "v"(p) : "memory");
-  };
-  // both statements only tell the compiler "these registers may have changed" (they are written by loads it cannot see);
-  // touch() sleeps a few cycles between polls, poll_end() drains the loads and marks the end of a polling window for
-  // _build.check_hidden_loads
-#define MGR_POLLED_ASM(TEXT)                                                                                                  \
-  if constexpr (NBW == 8)                                                                                                       \
-    asm volatile(TEXT : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])::"memory"); \
-  else if constexpr (NBW == 5)                                                                                                  \
-    asm volatile(TEXT : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4])::"memory");                                 \
-  else if constexpr (NBW == 2)                                                                                                  \
-    asm volatile(TEXT : "+v"(v[0]), "+v"(v[1])::"memory");                                                                     \
-  else                                                                                                                          \
-    static_assert(NBW == 8 || NBW == 5 || NBW == 2, "add an arm for this block count");
-  auto touch = [&](u32x4 (&v)[NBW]) { MGR_POLLED_ASM("s_sleep 1") };
-  auto poll_end = [&](u32x4 (&v)[NBW]) { MGR_POLLED_ASM("s_waitcnt vmcnt(0) ; MGR_POLL_END") };
-#undef MGR_POLLED_ASM
-  auto mfmas = [&](const u32x4 (&v)[NBW], f32x4 (&acc)[4]) {
-#pragma unroll
-    for (int i = 0; i < NBW; ++i) {
-      const float hv[4] = {__uint_as_float(v[i].x), __uint_as_float(v[i].y), __uint_as_float(v[i].z), __uint_as_float(v[i].w)};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt)   // k-steps / blocks that do not exist carry zero weights
-          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[tt][i * 4 + r], hv[r], acc[tt], 0, 0, 0);
-      }
+  unsigned rounds = 0;        // re-fetches / re-polls of the whole launch: the bound of every spin below
+  auto tick = [&]() {         // a wasted round: look at the launch's give-up word now and then, give up after ~1 s of them
+    ++rounds;
+    if ((rounds & 255u) == 0) {
+      // (through an opaque asm, waited for on the spot: a load hipcc can see inside the polling loops leaves a "maybe pending"
+      // register in its scoreboard, and it then puts an s_waitcnt vmcnt(0) in front of the MFMA chain - behind the Z prefetch)
+      unsigned st;
+      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(st) : "v"(status) : "memory");
+      if (__builtin_amdgcn_readfirstlane(st) != 0u) failed = true;
+    }
+    if (rounds > KS_ROUND_LIMIT) {
+      failed = true;
+      if (lane == 0) __hip_atomic_store(status, MGR_ST_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
 
-  auto do_step = [&](int step, f32x4& zuse, f32x4& zload) {
+  for (int step = 0; step < T; ++step) {
     const int t = reverse ? T - 1 - step : step;
-    loadz(zload, step + 2);
     f32x4 acc[4];
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (step > 0 && nb > 0 && !failed) {
+    u32x4 v[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) v[i] = (u32x4){0u, 0u, 0u, 0u};
+    const bool gather = step > 0 && nb > 0 && !failed;
+    if (gather) {
       const int slot = (step - 1) & 1;
       const unsigned par = ((((unsigned)(step - 1)) >> 1) & 1u) ^ 1u;
-      const unsigned bad = 0x7FC00000u | (par ^ 1u);   // never a published word (|h| < 2): bit 30 set, wrong parity
-      const char* gp[NBW];
-#pragma unroll
-      for (int i = 0; i < NBW; ++i) {
-        const int q = (i < nb) ? qb + i : QN - 1;        // unused slots re-read a valid block (their weights are zero)
-        gp[i] = reinterpret_cast<const char*>(xb) + ((size_t)slot * IMG + q * 256 + lane * 4) * 4;
-      }
-      u32x4 v[NBW];
-      unsigned rounds = 0, spins = 0;
-      bool issue = true;
+      // nb blocks of 1 KiB straight into registers (the block layout [kk][sample][r] IS the B fragment of four k-steps); every
+      // word is validated by its epoch parity - the data is the flag - and what still shows the previous epoch is fetched again
       for (;;) {
-        if (issue) {
 #pragma unroll
-          for (int i = 0; i < NBW; ++i) v[i] = (u32x4){bad, bad, bad, bad};
-#pragma unroll
-          for (int i = 0; i < NBW; ++i) hidden_load(v[i], gp[i]);
-          issue = false;
-          spins = 0;
-        }
-        touch(v);
-        unsigned a_and = v[0].x, a_or = v[0].x;
+        for (int i = 0; i < NBW; ++i)   // (blocks beyond nb - wave-uniform - re-read a valid block: they meet zero weights)
+          v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (slot * IMG + (qb + (i < nb ? i : 0)) * 256 + lane * 4) * 4, 0, 16);   // sc1
+        unsigned a_and = 0xFFFFFFFFu, a_or = 0u;
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
           a_and &= v[i].x & v[i].y & v[i].z & v[i].w;
           a_or |= v[i].x | v[i].y | v[i].z | v[i].w;
         }
         const bool lane_fresh = par ? (a_and & 1u) != 0u : (a_or & 1u) == 0u;
-        if (__all(lane_fresh)) break;                 // every word shows this epoch (hence has landed)
-        if (__all(((a_or >> 30) & 1u) == 0u)) {       // everything landed, something was still the previous epoch
-          issue = true;
-          ++rounds;
-        } else if (++spins > 4096u) {                 // a load cannot take this long (~1 ms): drain and start over
-          __builtin_amdgcn_s_waitcnt(0x0F70);
-          issue = true;
-          rounds += 64;                               // (so that this path, too, gives up after about a second)
-        }
-        if (issue) {
-          if ((rounds & 63u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) failed = true;
-          if (rounds > KS_ROUND_LIMIT) {
-            failed = true;
-            if (lane == 0) __hip_atomic_store(status, MGR_ST_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          if (failed) break;
+        if (__all(lane_fresh) || failed) break;
+        tick();
+        if (failed) break;
+      }
+    }
+    // Z / R of the NEXT step leave BEHIND the gather (an HBM miss in front of it would hold the gathered blocks - L2 hits - back
+    // for the length of the miss: memory operations complete in issue order), from inside the MFMA chain: the matrix pipe is
+    // busy anyway, the eight scalar / vector-memory instructions of the two DMAs cost nothing there
+    if (!(gather && !failed)) prefetch(step + 1);
+    if (gather && !failed) {
+#pragma unroll
+      for (int i = 0; i < NBW; ++i) {
+        if (i == (NBW > 1 ? 1 : 0)) prefetch(step + 1);
+        const float hv[4] = {__uint_as_float(v[i].x), __uint_as_float(v[i].y), __uint_as_float(v[i].z), __uint_as_float(v[i].w)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt)   // k-steps / blocks that do not exist carry zero weights
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[tt][i * 4 + r], hv[r], acc[tt], 0, 0, 0);
         }
       }
-      mfmas(v, acc);
-      // keep the polling registers allocated until here, then make sure no re-issued load is still in flight before this
-      // wave publishes (a producer may overwrite the slot only after it has seen that publish)
-      poll_end(v);
     }
-    // the four partial sums of every tile meet in LDS (all four go through it: selecting "my own" accumulator by the
-    // run-time wave id would force the accumulators into scratch memory)
+    // the four partial sums of every tile meet in LDS (double-buffered on the step parity: one barrier per step)
     float* rbuf = red + (step & 1) * (16 * 64 * 4);
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(rbuf + ((tt * 4 + wave) * 64 + lane) * 4) = acc[tt];
@@ -463,63 +474,71 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
     unsigned hbits = par;   // cells of a padding tile: value 0 with the current parity, so that consumers can test whole blocks
     float h = 0.f, yv = 0.f;
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Z_t / R_t were fetched one step ago; the only vector-memory operations this wave has issued since that may still be in
+    // flight are the one or two DMAs of step t + 1: a counted wait makes their landing explicit (in practice it never waits)
+    if (jb.R)
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    const f32x4 zt = *reinterpret_cast<const f32x4*>(zring + (step & 1) * 256 + lane * 4);
+    const float rt = jb.R ? rring[(step & 1) * 64 + lane] : 0.f;
     if (cvalid) {
-      f32x4 tot = zuse;
+      f32x4 tot = zt;   // (same summation order as cluster_run_ks: the K-split steps are bit-identical)
       const float* mine = rbuf + red_off;
 #pragma unroll
       for (int src = 0; src < 4; ++src) tot += *reinterpret_cast<const f32x4*>(mine + src * 64 * 4);
       h = mgr_cell_fwd(tot[0], tot[1], tot[2], tot[3], c, g4);
-      yv = h;
-      if (!(fabsf(h) < 2.f)) {
-        // NaN / Inf (diverged weights, bad checkpoint): Y keeps the NaN so that the loss turns NaN like the reference's, but
-        // what is published - and fed back - is finite: a NaN word would look like a load that has not landed (bit 30)
+      if (!(fabsf(h) < 2.f) && !nonfinite) {
+        // NaN / Inf (diverged weights, bad checkpoint): what is published - and fed back - stays finite (0), Y of this (sample,
+        // unit) is NaN from here on (latched) and the launch raises MGR_SCAN_NONFINITE (mgr.h)
+        __hip_atomic_fetch_or(cm.sticky, MGR_ST_NONFINITE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nonfinite = true;
+      }
+      if (nonfinite) {
         h = 0.f;
         c = 0.f;
-        if (!nonfinite) __hip_atomic_fetch_or(cm.sticky, MGR_ST_NONFINITE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        nonfinite = true;
       }
       hbits = (__float_as_uint(h) & ~1u) | par;  // epoch parity rides in the mantissa LSB
       h = __uint_as_float(hbits);
-      if (!nonfinite) yv = h;
+      yv = nonfinite ? __uint_as_float(0x7FC00000u) : h;
     }
     if (step + 1 < T) {
-      if (PERM) {
-        // lane (r, j) holds image word j*4 + r of the wave's 64-word segment: bring word l to lane l, one coalesced store
-        const unsigned w = __builtin_amdgcn_ds_bpermute((((lane & 3) << 4) | (lane >> 2)) << 2, hbits);
-        if (fast)   // whole cluster on one XCD (verified at start): the line stays in the L2 every peer's sc1 load is served from
-          __builtin_amdgcn_raw_buffer_store_b32(w, rs, ((step & 1) * IMG + (ug * 4 + wave) * 64 + lane) * 4, 0, 0);
-        else
-          __builtin_amdgcn_raw_buffer_store_b32(w, rs, ((step & 1) * IMG + (ug * 4 + wave) * 64 + lane) * 4, 0, 16);  // sc1
-      } else {
-        __builtin_amdgcn_raw_buffer_store_b32(hbits, rs, ((step & 1) * IMG + idx) * 4, 0, 16);  // sc1 write-through
-      }
+      // lane (r, j) holds image word j*4 + r of the wave's 64-word segment: bring word l to lane l, one coalesced store
+      // (XCD-local clusters: a plain store into the L2 every peer's sc1 load is served from; else write-through)
+      const unsigned w = __builtin_amdgcn_ds_bpermute((((lane & 3) << 4) | (lane >> 2)) << 2, hbits);
+      if (fast)
+        __builtin_amdgcn_raw_buffer_store_b32(w, rs, ((step & 1) * IMG + (ug * 4 + wave) * 64 + lane) * 4, 0, 0);
+      else
+        __builtin_amdgcn_raw_buffer_store_b32(w, rs, ((step & 1) * IMG + (ug * 4 + wave) * 64 + lane) * 4, 0, 16);  // sc1
     }
     if (cvalid && bvalid) {
       size_t row = (size_t)b * T + t;
-      float yo = yv;
-      if (jb.R) yo += jb.R[row * jb.ldr + unit];
+      const float yo = yv + rt;
       jb.Y[row * jb.ldy + unit] = yo;
       if (jb.G) *reinterpret_cast<float4*>(jb.G + (row * H + unit) * 4) = g4;
       if (jb.Cs) jb.Cs[row * H + unit] = c;
       if (ytrow) {
-        stg[t & 31] = yo;
-        // the chunk [t & ~31, +32) is complete when the walk leaves it (all lanes of the launch agree on t)
-        if (reverse ? (t & 31) == 0 : ((t & 31) == 31 || t == T - 1)) {
-          float* dst = ytrow + (t & ~31);
-#pragma unroll 1
-          for (int i = 0; i < 8; ++i) {
-            *reinterpret_cast<f32x4*>(dst + 4 * i) = *reinterpret_cast<const f32x4*>(stg + 4 * i);
-            *reinterpret_cast<f32x4*>(stg + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};   // (a partial last chunk pads with zeros)
+        stg[(t & (KS_STG - 1)) * 64 + lane] = yo;
+        // the chunk [t & ~7, +8) is complete when the walk leaves it (all lanes of the launch agree on t)
+        if (reverse ? (t & (KS_STG - 1)) == 0 : ((t & (KS_STG - 1)) == KS_STG - 1 || t == T - 1)) {
+          float* dst = ytrow + (t & ~(KS_STG - 1));
+          f32x4 o0, o1;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            o0[i] = stg[i * 64 + lane];
+            o1[i] = stg[(4 + i) * 64 + lane];
           }
+          *reinterpret_cast<f32x4*>(dst) = o0;
+          *reinterpret_cast<f32x4*>(dst + 4) = o1;
+#pragma unroll
+          for (int i = 0; i < KS_STG; ++i) stg[i * 64 + lane] = 0.f;   // (a partial last chunk pads with zeros)
         }
       }
     }
-  };
-
-  for (int s0 = 0; s0 < T; s0 += 3) {
-    do_step(s0, zr0, zr2);
-    if (s0 + 1 < T) do_step(s0 + 1, zr1, zr0);
-    if (s0 + 2 < T) do_step(s0 + 2, zr2, zr1);
+  }
+  if (ytrow) {   // zeros behind T up to the row length (mgr.h: the transposed copy is zero in [T, ldt))
+    for (int t0 = (T + KS_STG - 1) / KS_STG * KS_STG; t0 + 4 <= jb.ldt; t0 += 4)
+      *reinterpret_cast<f32x4*>(ytrow + t0) = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 }
 
@@ -551,11 +570,12 @@ __global__ __launch_bounds__(CL_WAVES * 64) void k_scan_cluster(ClusterLaunch L)
   }
 }
 
-// K-split step: every job of the launch is a one-tile-per-wave, 4-wave cluster with an exchange (two workgroups per CU)
+// K-split step: every job of the launch is a one-tile-per-wave, 4-wave cluster with an exchange (two workgroups per CU); XCD-local
+// layout where the launcher chose it (lstm_cluster.h, mgr_cluster_octet), contiguous workgroup ids otherwise
 __global__ __launch_bounds__(256, 2) void k_scan_cluster_ks(ClusterLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   mgr_cluster_enter(L.cm);
-  if (L.xcd_local) {   // XCD-local exchange: lstm_cluster.h, mgr_cluster_octet
+  if (L.xcd_local) {
     for (int k_ = 0; k_ < L.njobs; ++k_) {
       const ClusterJob& jb = L.job[k_];
       const int w_ = (int)blockIdx.x - jb.cls_begin, G = jb.G_;
@@ -565,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void k_scan_cluster_ks(ClusterLaunch L) {
       const int bg = cl - jb.cls_cluster0;
       if (cl >= jb.cls_nclusters || bg < 0 || bg >= jb.nbg) continue;
 #define CLKS_CASE(KS) \
-  if (jb.ks == KS) { cluster_run_ks<KS, true>(jb, L.cm, bg, ug, smem, same); return mgr_cluster_exit(L.cm); }
+  if (jb.ks == KS) { cluster_run_ks<KS>(jb, L.cm, bg, ug, smem, same); return mgr_cluster_exit(L.cm); }
       CLKS_FOREACH(CLKS_CASE)
 #undef CLKS_CASE
       return;
@@ -574,20 +594,7 @@ __global__ __launch_bounds__(256, 2) void k_scan_cluster_ks(ClusterLaunch L) {
   }
   MGR_FOR_MY_JOB(L, jb, bg, ug) {
 #define CLKS_CASE(KS) \
-  if (jb.ks == KS) { cluster_run_ks<KS, true>(jb, L.cm, bg, ug, smem); return mgr_cluster_exit(L.cm); }
-    CLKS_FOREACH(CLKS_CASE)
-#undef CLKS_CASE
-    return;
-  }
-}
-
-// the same step with hidden units in identity order (mgr_tune key 7 = 2): kept as the cross-check of the unit permutation
-__global__ __launch_bounds__(256, 2) void k_scan_cluster_ks_id(ClusterLaunch L) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  mgr_cluster_enter(L.cm);
-  MGR_FOR_MY_JOB(L, jb, bg, ug) {
-#define CLKS_CASE(KS) \
-  if (jb.ks == KS) { cluster_run_ks<KS, false>(jb, L.cm, bg, ug, smem); return mgr_cluster_exit(L.cm); }
+  if (jb.ks == KS) { cluster_run_ks<KS>(jb, L.cm, bg, ug, smem, false); return mgr_cluster_exit(L.cm); }
     CLKS_FOREACH(CLKS_CASE)
 #undef CLKS_CASE
     return;
@@ -663,19 +670,12 @@ int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool a
   if (!(c->attr_done & 1u)) {   // (function attributes are per device, hence per context)
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_ks), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_ks_id), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     c->attr_done |= 1u;
   }
-  MGR_REQUIRE(!L.xcd_local || (ks_eligible(L, any_exchange, waves) && L.ksplit == 1), "XCD-local layout is only understood by the K-split kernel");
+  MGR_REQUIRE(!L.xcd_local || ks_eligible(L, any_exchange, waves), "XCD-local layout is only understood by the K-split kernel");
   if (ks_eligible(L, any_exchange, waves)) {
-    // partial-sum exchange only (no h image)
-    size_t lds_ks = 2 * 16 * 64 * 4 * sizeof(float);
-    for (int i = 0; i < L.njobs; ++i)
-      if (L.job[i].YT) lds_ks = (2 * 16 * 64 * 4 + 256 * KS_STG_ROW) * sizeof(float);   // + staging rows of the transposed output
-    if (L.ksplit == 2)
-      hipLaunchKernelGGL(k_scan_cluster_ks_id, dim3(total_wgs), dim3(256), lds_ks, mgr_stream(c), L);
-    else
-      hipLaunchKernelGGL(k_scan_cluster_ks, dim3(total_wgs), dim3(256), lds_ks, mgr_stream(c), L);
+    // partial-sum exchange, staging tiles of the transposed output, Z / R rings (no h image): 50 KiB, two workgroups per CU
+    hipLaunchKernelGGL(k_scan_cluster_ks, dim3(total_wgs), dim3(256), KS_LDS_FLOATS * sizeof(float), mgr_stream(c), L);
   } else {
     hipLaunchKernelGGL(k_scan_cluster, dim3(total_wgs), dim3(waves * 64), lds, mgr_stream(c), L);
   }

@@ -130,8 +130,12 @@ class Engine:
                 off += _pad4(n)
         self.n_train = off
         self.params = dev.zeros((max(off, 4),))
+        # this engine's own scan-status block (several engines may share one Device): [0] status bits, [2] skipped updates
+        self.status = dev.zeros((16,), np.uint32)
         if not self.inference_only:
-            self.grads = dev.zeros((max(off, 4),))
+            # the 4 floats behind the gradients carry the update-gate flag through the gradient all-reduce (apply_gradients)
+            self.grads = dev.zeros((max(off, 4) + 4,))
+            self.gate_flag = self.grads.view(max(off, 4), (4,))
             self.m = dev.zeros((max(off, 4),))
             self.v = dev.zeros((max(off, 4),))
         self.frozen = {}
@@ -257,10 +261,16 @@ class Engine:
         return self.grads.view(off, (n,))
 
     # ------------------------------------------------------------------------------------------ weights
+    def _bind(self):
+        """Scans enqueued from here on report into THIS engine's status block (the Device may be shared)."""
+        self.dev.call("mgr_scan_status_bind", self.status)
+
     def set_weights(self, weights):
-        """weights: dict name -> numpy array in Keras layout (see NetworkSpec.weight_table)."""
+        """weights: dict name -> numpy array in Keras layout (see NetworkSpec.weight_table).  Fresh weights start with a clean
+        scan status: a NaN / give-up recorded under the old ones (diverged run) must not haunt a restored checkpoint."""
         dev = self.dev
         dev.stream(0)
+        self.clear_scan_status()
         for name, shape, tr, kind in self.spec.weight_table():
             if name not in weights:
                 continue
@@ -319,6 +329,7 @@ class Engine:
         self.m.zero()
         self.v.zero()
         self.iterations = 0
+        self.clear_scan_status()
 
     # ------------------------------------------------------------------------------------------ helpers
     def _seed(self, slot):
@@ -570,24 +581,42 @@ class Engine:
         _capi.check(self.lib.mgr_lstm_scan_fwd_multi(self.dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes))
 
     # ------------------------------------------------------------------------------------------ public
-    def _check_scans(self):
-        """Raises if a persistent scan gave up on a bounded spin (its outputs are garbage); a non-finite hidden state is not
-        an error of the engine - the outputs / loss carry the NaN like the reference's would - and is remembered in
-        `nonfinite_seen` until clear_scan_status()."""
-        st = C.c_uint(0)
-        self.dev.call("mgr_scan_status", C.byref(st))
-        if st.value & _capi.SCAN_NONFINITE:
+    def scan_health(self):
+        """(status bits, optimizer updates skipped by the update gate) of THIS engine since the last clear_scan_status(),
+        read on the current stream; never raises."""
+        st = (C.c_uint * 4)()
+        self._bind()
+        self.dev.call("mgr_scan_status_ex", st)
+        self.updates_skipped = int(st[2])
+        if st[0] & _capi.SCAN_NONFINITE:
             self.nonfinite_seen = True
+        return int(st[0]), int(st[2])
+
+    def _check_scans(self, step=None):
+        """Raises if a persistent scan of this engine gave up on a bounded spin (its outputs are garbage; the update gate keeps
+        that step's gradients away from the weights, apply_gradients); a non-finite hidden state is not an error of the
+        engine - the outputs / loss carry the NaN like the reference's would - and is remembered in `nonfinite_seen` until
+        clear_scan_status().  `updates_skipped` counts the optimizer steps the gate has dropped since then."""
+        bits, skipped = self.scan_health()
+        if bits & ~_capi.SCAN_NONFINITE:
+            where = "" if step is None else " (noticed with the loss of training step %d)" % step
+            raise _capi.MgrError("a persistent scan gave up on a bounded spin (status %d)%s: the outputs of that pass are invalid and "
+                                 "its optimizer update is skipped on the device (the weights stay as they were) - "
+                                 "clear_scan_status() to continue" % (bits, where))
 
     nonfinite_seen = False
+    updates_skipped = 0
 
     def clear_scan_status(self):
         """Forget recorded scan status bits (after recovering from a diverged run / a give-up)."""
+        self._bind()
         self.dev.call("mgr_scan_status_clear")
         self.nonfinite_seen = False
+        self.updates_skipped = 0
 
     def predict(self, inputs):
         """Softmax output (B,T,C) with learning phase 0 (sequence_decoding.py:81)."""
+        self._bind()
         self._upload_inputs(inputs, None, False)
         self._forward(False, None)
         P = self.P.download()
@@ -596,6 +625,7 @@ class Engine:
 
     def forward_train_phase(self, inputs, rand=None):
         """Softmax output with learning phase 1 (dropout / noise active) - no gradient."""
+        self._bind()
         self._upload_inputs(inputs, rand, True)
         self._forward(True, rand)
         P = self.P.download()
@@ -630,6 +660,7 @@ class Engine:
 
     def loss_on_batch(self, inputs, labels, input_length, label_length, rand=None, train_phase=True):
         """Per-sample CTC loss (validation inside fit_generator: learning phase stays 1, multimodal.py:66)."""
+        self._bind()
         self._upload_inputs(inputs, rand, train_phase)
         self._upload_labels(labels, input_length, label_length)
         self._forward(train_phase, rand)
@@ -657,7 +688,7 @@ class Engine:
         v = float(self.loss_mean.download()[0])
         self._synced_step = self._step_id - 1
         try:
-            self._check_scans()   # raises if a persistent scan ever gave up: results would be garbage
+            self._check_scans(step=self._step_id - 1)   # raises if a persistent scan ever gave up: results would be garbage
         finally:
             dev.stream(0)
         if self.nonfinite_seen:
@@ -685,6 +716,7 @@ class Engine:
         fusion work, and this step consumes the encoder pass enqueued by the previous call (Schedule)."""
         sp, dev, B, T = self.spec, self.dev, self.B, self.T
         sch, ES = self.schedule, self.ES
+        self._bind()
         pipelined = prefetch_next and rand is None and self.can_pipeline and sch.pipeline
         depth = max(len(s_["layers"]) for s_ in sp.streams)
         # ---- 1. this step's encoder pass: the one the previous call prefetched, or in line on stream 0
@@ -894,10 +926,17 @@ class Engine:
         """all-reduce (if data parallel) -> clip -> Adam -> max-norm; identical on every replica."""
         dev, o = self.dev, self.spec.optimizer
         dev.stream(0)
+        self._bind()
+        # Update gate: a scan of this step that gave up (garbage gradients) or met a non-finite state must not reach the weights,
+        # and the host only learns of it with the loss - after these kernels are queued.  So the decision is taken on the device:
+        # the flag is evaluated here (stream order: behind every scan and GEMM of the step), rides behind the gradients through
+        # the all-reduce (all replicas skip together) and closes Adam + max-norm; read_loss then raises with the weights intact.
+        dev.call("mgr_update_gate_eval", _capi.SCAN_GAVE_UP | _capi.SCAN_NONFINITE, self.gate_flag)
         gscale = 1.0
         if self.comm is not None:   # (a 1-rank communicator is legal: the reduction is then the identity)
-            self.comm.allreduce_sum(self.grads, self.n_train)
+            self.comm.allreduce_sum(self.grads, max(self.n_train, 4) + 4)
             gscale = 1.0 / self.world
+        dev.call("mgr_update_gate_set", self.gate_flag)
         k = self.iterations
         lr_k = o["lr"] * (1.0 / (1.0 + o["decay"] * k))
         t = k + 1
@@ -909,6 +948,7 @@ class Engine:
                 mv = self.spec.kernel_maxnorm(name.rsplit("/", 2)[0])   # "<prefix>/<fwd|bwd>/W" -> "<prefix>"
                 if mv > 0:
                     dev.call("mgr_maxnorm_cols", self.params.view(off, (n,)), shape[0], shape[1], mv, 1e-7)
+        dev.call("mgr_update_gate_set", 0)
         self.iterations += 1
 
     def close(self):

@@ -124,3 +124,100 @@ def test_oracle_beam_search_equals_exhaustive_enumeration(seed):
         assert tuple(seqs[0][r]) == ranked[r][0], (r, seqs[0], ranked[:3])
         assert abs(scores[0][r] - math.log(ranked[r][1])) < 1e-9
     assert abs(sum(ex.values()) - 1.0) < 1e-12
+
+
+# ---- round 3: max-norm, pad_sequences, hard_sigmoid (Keras constraints_test / sequence_test / activations_test) ----------------
+def _maxnorm_arrays():
+    k = KAT["max_norm_explicit"]
+    x = np.array(k["x_columns"], np.float64).T                       # the Keras test transposes: listed rows are columns
+    tgt = np.array([[eval(v.replace("sqrt", "math.sqrt")) if isinstance(v, str) else v for v in col]
+                    for col in k["target_columns"]], np.float64).T
+    return k, x, tgt
+
+
+def test_max_norm_vector_verifies_itself_and_pins_the_oracle():
+    """keras constraints.max_norm(2.0), axis 0: each column keeps its direction and gets norm min(norm, 2) - and the oracle's
+    maxnorm_cols (what oracle/network_ref.py applies after Adam, multimodal.py:164) reproduces the published target."""
+    k, x, tgt = _maxnorm_arrays()
+    assert x.shape == (3, 4)
+    n_in, n_out = np.linalg.norm(x, axis=0), np.linalg.norm(tgt, axis=0)
+    assert np.allclose(n_out, np.minimum(n_in, k["max_value"]), rtol=1e-12)
+    nz = n_in > 0
+    assert np.allclose(tgt[:, nz] / n_out[nz], x[:, nz] / n_in[nz], rtol=1e-12)
+    for dt in (np.float64, np.float32):
+        w = x.astype(dt)
+        kr.maxnorm_cols(w, maxv=k["max_value"])          # (in place, like the constraint applied to a variable)
+        np.testing.assert_allclose(w, tgt, rtol=k["rtol"], atol=1e-12)
+
+
+def test_pad_sequences_vectors_pin_the_data_generator_padding():
+    """The published vectors first verify themselves (the formula Keras documents), then pin the two padding rules of the
+    reference's generator as this build implements them: features post/post (datagen.pad_post) and label rows padded behind
+    with -1, truncated in FRONT (BaseDataGenerator, Keras' default truncating='pre')."""
+    from mgr_amd.datagen import pad_post
+    k = KAT["pad_sequences"]
+
+    def keras_pad(seqs, maxlen, padding="pre", truncating="pre", value=0.0):   # the documented algorithm, for the self-check
+        out = []
+        for s in seqs:
+            s = np.asarray(s, np.float64)
+            s = s[-maxlen:] if truncating == "pre" else s[:maxlen]
+            pad = np.full((maxlen - len(s),) + s.shape[1:], value)
+            out.append(np.concatenate([pad, s]) if padding == "pre" else np.concatenate([s, pad]))
+        return np.array(out)
+
+    a, av = k["a"], k["a_vector"]
+    assert np.array_equal(keras_pad(a, 3), k["maxlen3_padding_pre"])
+    assert np.array_equal(keras_pad(a, 3, padding="post"), k["maxlen3_padding_post"])
+    assert np.array_equal(keras_pad(a, 2, truncating="pre"), k["maxlen2_truncating_pre"])
+    assert np.array_equal(keras_pad(a, 2, truncating="post"), k["maxlen2_truncating_post"])
+    assert np.array_equal(keras_pad(a, 3, value=1), k["maxlen3_value1"])
+    assert np.array_equal(keras_pad(av, 3, padding="post"), k["vector_maxlen3_padding_post"])
+    assert np.array_equal(keras_pad(av, 2, truncating="post"), k["vector_maxlen2_truncating_post"])
+    # features: padding='post', truncating='post'
+    for s, want in zip(av, k["vector_maxlen3_padding_post"]):
+        got = pad_post(s, 3)
+        assert got.dtype == np.float32 and np.array_equal(got, want)
+    for s, want in zip(av[1:], k["vector_maxlen2_truncating_post"][1:]):     # rows that are not padded: only the truncation shows
+        assert np.array_equal(pad_post(s, 2), want)
+    assert np.array_equal(pad_post(av[0], 2), [[1, 1], [0, 0]])              # post/post of the short row (both rules combined)
+    for s, want in zip(a, k["maxlen3_padding_post"]):
+        assert np.array_equal(pad_post(np.array(s, np.float32)[:, None], 3)[:, 0], want)
+
+
+def test_pad_sequences_vectors_pin_the_generator_batches():
+    """The same rules through the product's DataGenerator.get_batch: a store whose files hold the published sequences."""
+    from mgr_amd.datagen import BaseDataGenerator
+    k = KAT["pad_sequences"]
+
+    class Store:
+        def file_ids(self):
+            return [1, 2, 3]
+
+        def features(self, fid, modality):
+            return np.array(k["a_vector"][fid - 1], np.float64)
+
+        def labels(self, fid):
+            return np.array(k["a"][fid - 1], np.float32)
+
+    class Gen(BaseDataGenerator):
+        streams = (("x", "m", "feat_dim"),)
+        feat_dim = 2
+
+    g = Gen()
+    g._setup(minibatch_size=3, maxlen=2, nb_classes=6, dataset="val", val_split=0.0, absolute_max_sequence_len=2, store=Store())
+    assert g.get_file_list(False) == [1, 2, 3]
+    inputs, _ = g.get_batch(train=False)
+    assert np.array_equal(inputs["x"][1:], np.array(k["vector_maxlen2_truncating_post"], np.float64)[1:])
+    assert np.array_equal(inputs["x"][0], [[1, 1], [0, 0]])                  # padding='post' of the short row
+    assert np.array_equal(inputs["the_labels"], [[1, -1], [1, 2], [2, 3]])   # value -1 behind, Keras' default truncating='pre'
+    assert np.array_equal(inputs["label_length"][:, 0], [1, 2, 2]) and np.array_equal(inputs["input_length"][:, 0], [0, 0, 0])
+
+
+def test_hard_sigmoid_vector_pins_the_oracle():
+    k = KAT["hard_sigmoid"]
+    for xs, want in ((k["standard_values"], k["expected_standard"]), (k["edge_values"], k["expected_edge"])):
+        x = np.array(xs, np.float64)
+        assert np.allclose(np.clip(0.2 * x + 0.5, 0.0, 1.0), want, rtol=1e-12)          # the vector is the published formula
+        np.testing.assert_allclose(kr.hard_sigmoid(x), want, rtol=k["rtol"])
+        np.testing.assert_allclose(kr.hard_sigmoid(x.astype(np.float32)), want, rtol=k["rtol"])

@@ -283,8 +283,8 @@ def test_cluster_scan_matches_oracle(device, B, T, H, path):
 
 @pytest.mark.parametrize("H,B,T", [(100, 17, 40), (300, 33, 25), (500, 64, 30)])
 def test_cluster_step_variants_agree(device, H, B, T):
-    """One-tile-per-wave clusters: the K-split / register-polling step (default) and the LDS-image step (mgr_tune key 7)
-    compute the same recurrence; both against the oracle, over enough steps to cycle the epoch parity many times."""
+    """One-tile-per-wave clusters: the K-split step (default: blocks gathered straight into registers) and the LDS-image step
+    (mgr_tune key 7) compute the same recurrence; both against the oracle, over enough steps to cycle the epoch parity many times."""
     from mgr_amd import _capi
     dev = device
     rng = np.random.default_rng(H)
@@ -527,8 +527,8 @@ def test_param_grads_dropout_sparse_equals_dense(device, B, T, F, H, p, reverse)
 @pytest.mark.parametrize("H,B,T,path", [(300, 20, 75, 0), (500, 33, 70, 0), (100, 16, 64, 0), (128, 5, 33, 0), (300, 20, 75, 1),
                                         (60, 7, 40, 0), (300, 18, 50, 7)])
 def test_scan_writes_the_transposed_output_itself(device, H, B, T, path):
-    """mgr_scan_job.YT: the scans leave YT[b][col0 + u][t] = Y[b, t, u] (+ residual) with zeros behind T up to the next multiple
-    of 32, two directions into column ranges of ONE wider copy - from inside the K-split multi-CU kernel (LDS-staged rows) or,
+    """mgr_scan_job.YT: the scans leave YT[b][col0 + u][t] = Y[b, t, u] (+ residual) with zeros behind T up to the row
+    length ldt, two directions into column ranges of ONE wider copy - from inside the K-split multi-CU kernel (LDS-staged rows) or,
     for every other kernel family (path 1: fallback kernels; 7: LDS-image cluster step; small H), through the transpose
     the call appends.  Y itself is unchanged by the option."""
     from mgr_amd import _capi
@@ -567,7 +567,5 @@ def test_scan_writes_the_transposed_output_itself(device, H, B, T, path):
     finally:
         dev.call("mgr_tune", 0, 0)
         dev.call("mgr_tune", 7, 0)
-    T32 = (T + 31) // 32 * 32
     assert np.array_equal(yt[:, :, :T], y.transpose(0, 2, 1))
-    assert not yt[:, :, T:T32].any()
-    assert (yt[:, :, T32:] == 7.0).all()
+    assert not yt[:, :, T:].any()          # zeros behind T up to the row length, whatever the buffer held (mgr.h)

@@ -1,8 +1,7 @@
-"""Forward cluster scan variants at the config-F shapes (B = 64, T = 1900), audio alone and audio + skeletal in one launch:
-  tune7 = 0  K-split step, permuted unit order      tune7 = 2  same, identity unit order      tune7 = 1  LDS-image step
-(round 2 also measured a PAIRED form - two batch groups per 8-wave workgroup, matrix / cell wave roles, LDS-DMA landing zones;
- source kept as tools/probes/lstm_cluster_pair.hip.txt, numbers in profiles/r02_pair_scan_probe.txt, discussion in DESIGN.md 5)
-Prints ms per launch, us per time step, the launch's give-up word and the largest difference to the first variant."""
+"""Forward cluster scans of config F's encoder depth (audio H=500, skeletal H=300, both directions, B = 64, T = 1900): audio alone,
+skeletal alone, all four in ONE launch - under mgr_tune settings given on the command line as key=value[,key=value...] groups:
+    python tools/scan_variant_probe.py "" 3=1 7=1      # default (K-split step, XCD-local) | write-through exchange | LDS-image step
+Prints ms per launch, us per time step, the launch's give-up word and the largest difference to the first setting."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np
@@ -11,8 +10,14 @@ from mgr_amd import _capi
 dev = _capi.Device(0); lib = dev.lib
 B, T = 64, 1900
 rng = np.random.default_rng(0)
-variants = [(0, 0), (0, 3), (2, 0), (1, 0)]   # (tune7, x): x = 3 turns the XCD-local exchange of the K-split step OFF
-for hs in ((500,), (500, 300)):
+settings = sys.argv[1:] or [""]
+
+
+def parse(s):
+    return [tuple(int(x) for x in kv.split("=")) for kv in s.split(",") if kv]
+
+
+for hs in ((500,), (300,), (500, 300)):
     jobs, keep = [], []
     for H in hs:
         for rev in (0, 1):
@@ -23,19 +28,24 @@ for hs in ((500,), (500, 300)):
     arr = _capi.make_scan_jobs(jobs)
     ws = dev.bytes(lib.mgr_lstm_scan_multi_ws_bytes(len(jobs), arr))
     ref = None
-    for t7, t10 in variants:
-        dev.call("mgr_tune", 7, t7); dev.call("mgr_tune", 3, 1 if t10 == 3 else 0); dev.call("mgr_tune", 1, 1)
+    for s in settings:
+        kv = parse(s)
+        for k, v in kv:
+            dev.call("mgr_tune", k, v)
+        dev.call("mgr_tune", 1, 1)
         try:
             _capi.check(lib.mgr_lstm_scan_fwd_multi(dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes)); dev.sync()
             dev.record(0)
-            for _ in range(3):
+            for _ in range(4):
                 _capi.check(lib.mgr_lstm_scan_fwd_multi(dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes))
             dev.record(1); dev.sync()
+            ms = dev.elapsed_ms(0, 1) / 4
+            y = np.concatenate([keep[2 + 3 * i].download().ravel() for i in range(0, len(jobs), 2)])
+            if ref is None: ref = y
+            print("H=%-10s tune %-14s : %7.3f ms  %5.2f us/step  status=%d  maxdiff=%.2e" % (hs, s or "-", ms, ms * 1e3 / T, int(ws.download().view(np.uint32)[0]), float(np.abs(y - ref).max())), flush=True)
         except _capi.MgrError as e:
-            print("H=%-10s tune7=%d tune3=%d : FAILED %s" % (hs, t7, t10, e)); continue
-        ms = dev.elapsed_ms(0, 1) / 3
-        y = keep[2].download()
-        if ref is None: ref = y
-        print("H=%-10s tune7=%d tune3=%d : %7.3f ms  %5.2f us/step  status=%d  maxdiff=%.2e" % (hs, t7, t10, ms, ms * 1e3 / T, int(ws.download().view(np.uint32)[0]), float(np.abs(y - ref).max())), flush=True)
-    dev.call("mgr_tune", 7, 0); dev.call("mgr_tune", 3, 0); dev.call("mgr_tune", 1, 0)
+            print("H=%-10s tune %-14s : FAILED %s" % (hs, s, e), flush=True)
+        for k, v in kv:
+            dev.call("mgr_tune", k, 0)
+        dev.call("mgr_tune", 1, 0)
     for a in keep + [ws]: a.free()
