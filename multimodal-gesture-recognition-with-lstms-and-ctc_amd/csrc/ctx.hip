@@ -90,6 +90,8 @@ int mgr_free(mgr_ctx* c, void* dptr) {
   MGR_REQUIRE(c, "null ctx");
   if (!dptr) return 0;
   MGR_HIP(hipSetDevice(c->device));
+  if (dptr == c->status_bound) c->status_bound = nullptr;   // a freed status block is not reported into any more
+  if (dptr == c->gate_flag) c->gate_flag = nullptr;
   MGR_HIP(hipFree(dptr));
   return 0;
 }

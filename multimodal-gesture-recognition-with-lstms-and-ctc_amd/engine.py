@@ -959,4 +959,5 @@ class Engine:
         if self._own_dev:
             self.dev.close()
             return
+        self.dev.call("mgr_scan_status_bind", 0)      # (the context goes back to its own status block)
         self.mem.free_all()
