@@ -383,7 +383,9 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
   for (int i = 0; i < njobs; ++i) {
     const mgr_scan_bwd_job& j = jobs[i];
     nbg[i] = (j.B + 15) / 16;
-    use_cluster[i] = (path == 0 || path == 3) && mgr_cluster_bwd_supported(j.H);
+    // (the cluster kernel addresses the saved state with 32-bit byte offsets per lane: LDS-DMA prefetch)
+    const bool small = (size_t)j.B * j.T * j.H * 16 < ((size_t)1 << 32) && (size_t)j.B * j.T * j.lddy * 4 < ((size_t)1 << 32);
+    use_cluster[i] = (path == 0 || path == 3) && mgr_cluster_bwd_supported(j.H) && small;
     if (use_cluster[i]) total += ((j.H + 15) / 16) * nbg[i];
   }
   if (total + 8 * njobs > 2 * c->cu_count)

@@ -13,16 +13,43 @@
 // Hand-off: the data is the flag - the mantissa LSB of every exchanged word carries the epoch parity (a 1-ulp
 // perturbation of a partial sum); two slots per (destination, source) pair suffice (see lstm_cluster.hip).
 // After the reduction every thread runs the cell backward for ONE (unit, sample): 256 threads = 16 units x 16 samples;
-// saved forward state and dY are prefetched two steps ahead through a 3-deep register ring.
+// saved forward state and dY are prefetched two steps ahead by LDS-DMA through 3-deep per-wave LDS rings.
 // Bounded spins, status word, one launch for all concurrently scanned directions (co-residency by construction).
+//
+// Round 3 (what the forward K-split step taught, lstm_cluster.hip): (i) memory operations complete in issue order, so the
+// prefetch of the saved state (three HBM misses) must be issued BEHIND the gather of the step, not in front of it; (ii) any load
+// hipcc can still see pending at the head of the time loop makes it put an s_waitcnt vmcnt(0) there and in front of the
+// gathered data, which waits for those misses AND for the acknowledgement of the wave's own stores - so the saved state comes
+// by LDS-DMA (no register destination), the weight loads are retired by a visible wait before the loop, and the status word is
+// read through an opaque asm.  H = 100 (config F's fusion layer): 3.2 -> see profiles/r03_*; H = 300 / 500 (split roles) likewise.
 #include "lstm_cluster.h"
 #include "lstm_common.h"
 
 namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_float;
 constexpr unsigned POLL_LIMIT = 1u << 20;
 constexpr int BW_WAVES = 4;
+constexpr int BW_RING_FLOATS = 3 * (256 + 64 + 64);   // per compute wave: 3 slots x { gates [64] float4 | dy [64] | c [64] }
+constexpr int BW_LDS_FLOATS = 4 * 256 + 5 * 256 + BW_WAVES * BW_RING_FLOATS;
+
+// LDS-DMA: one wave-instruction copies 64 x 16 B (64 x 4 B) from global memory [gbase + voff] (gbase wave-uniform, voff per
+// lane) to LDS [lds_addr + 16 (4) * lane]; M0 carries the LDS address and is restored (hipcc does not know it was touched)
+__device__ __forceinline__ void mgr_dma_b128(const void* gbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(gbase), "s"(lds_addr)
+               : "memory");
+}
+__device__ __forceinline__ void mgr_dma_b32(const void* gbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 sc1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(gbase), "s"(lds_addr)
+               : "memory");
+}
 
 // SPLIT = false: 4 waves, each gathers its share of the incoming partial tiles AND computes / stores its outgoing ones.
 // SPLIT = true : 8 waves, one workgroup per CU.  Waves 0-3 only compute and store, waves 4-7 only gather: a gather wave
@@ -46,6 +73,9 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
   const int bc = bvalid ? b : B - 1;
   float* dzi = smem;                 // [4 blocks][4 gates][16 samples][4] own dz image: k-step s = own unit s, kk = gate
   float* red = smem + 4 * 256;       // [4 waves (+1: own tile, SPLIT)][64 lanes][4] partial sums of the tiles addressed to this workgroup
+  // saved-state rings of the compute wave `wave`: [3 slots] x { gates [64] float4 | dy [64] | c [64] }
+  float* ring = smem + 4 * 256 + 5 * 256 + wave * BW_RING_FLOATS;
+  const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)ring);
 
   // A fragments: tile m (units 16m..16m+15) x this workgroup's 64 gate columns: k-step s (own unit s), kk = gate
   //   A[i = lane&15][kk = lane>>4] = Up[unit 16m+i][4*(16*ug + s) + kk]
@@ -70,35 +100,35 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
   float* xb = jb.xbuf + (size_t)bg * 2 * SLOT;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, 2 * SLOT * 4, 0x00020000);
 
-  struct Saved {
-    float dy, c;
-    float4 g;
-  };
-  Saved r0, r1, r2;
-  r0.dy = r0.c = r1.dy = r1.c = r2.dy = r2.c = 0.f;
-  r0.g = r1.g = r2.g = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto load = [&](Saved& sv, int k) {
-    if (computer && uvalid && k < T) {
+  // byte offsets of this lane's (sample, unit) within dY / gates / cs at t = 0 (lanes without a unit read unit 0: a valid address);
+  // the launcher admits only tensors below 4 GiB to this kernel
+  const int ul = uvalid ? unit : 0;
+  const unsigned dyoff = (unsigned)(((size_t)bc * T * jb.lddy + ul) * sizeof(float));
+  const unsigned goff = (unsigned)(((size_t)bc * T * H + ul) * 4 * sizeof(float));
+  const unsigned coff = (unsigned)(((size_t)bc * T * H + ul) * sizeof(float));
+  auto prefetch = [&](int k) {       // saved state of iteration k -> ring slot k % 3 (three DMAs; everything wave-uniform but the offsets)
+    if (computer && k < T) {
       const int n = T - 1 - k;
       const int t = reverse ? T - 1 - n : n;
-      const size_t row = (size_t)bc * T + t;
-      sv.dy = jb.dY[row * jb.lddy + unit];
-      sv.g = *reinterpret_cast<const float4*>(jb.gates + (row * H + unit) * 4);
-      sv.c = jb.cs[row * H + unit];
+      const unsigned base = ring_lds + (unsigned)(k % 3) * (BW_RING_FLOATS / 3 * 4);
+      mgr_dma_b128(jb.gates + (size_t)t * H * 4, goff, base);
+      mgr_dma_b32(jb.dY + (size_t)t * jb.lddy, dyoff, base + 1024);
+      mgr_dma_b32(jb.cs + (size_t)t * H, coff, base + 1280);
     }
   };
-  load(r0, 0);
-  load(r1, 1);
+  prefetch(0);
+  prefetch(1);
+  // (a wait hipcc can see: with the weight loads retired here its scoreboard enters the time loop empty - lstm_cluster.hip)
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   float dcc = 0.f;
   f32x4 own_tile = {0.f, 0.f, 0.f, 0.f};  // the partial tile this workgroup computed for itself (held by wave ug % 4)
   bool failed = false;
   __syncthreads();
 
-  auto do_step = [&](int k, Saved& use, Saved& prev, Saved& ld) {
+  for (int k = 0; k < T; ++k) {
     const int n = T - 1 - k;
     const int t = reverse ? T - 1 - n : n;
     const bool has_prev = n > 0;
-    load(ld, k + 2);
     // ---- 1. reduce the partial tiles addressed to this workgroup (published at iteration k-1)
     float dhr = 0.f;
     if (k > 0) {
@@ -129,7 +159,11 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
           if (pend) {
             __builtin_amdgcn_s_sleep(1);
             ++spins;
-            if ((spins & 255u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) failed = true;
+            if ((spins & 255u) == 0) {   // (opaque to hipcc, waited for on the spot: no load of its own may stay pending)
+              unsigned st;
+              asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(st) : "v"(status) : "memory");
+              if (__builtin_amdgcn_readfirstlane(st) != 0u) failed = true;
+            }
             if (spins > POLL_LIMIT) {
               failed = true;
               if (lane == 0) __hip_atomic_store(status, MGR_ST_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -154,6 +188,7 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
       } else if (GT <= 1) {
         if (wave == 0 && computer) sum = own_tile;
       }
+      prefetch(k + 2);   // behind the gather of this step (memory operations complete in issue order)
       if (SPLIT && GT > 1) {
         if (gatherer) *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = sum;
         if (computer && wave == (ug & (BW_WAVES - 1))) *reinterpret_cast<f32x4*>(red + (4 * 64 + lane) * 4) = own_tile;
@@ -164,16 +199,26 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
       dhr = red[(0 * 64 + lane) * 4 + wave] + red[(1 * 64 + lane) * 4 + wave] + red[(2 * 64 + lane) * 4 + wave] +
             red[(3 * 64 + lane) * 4 + wave];
       if (SPLIT && GT > 1) dhr += red[(4 * 64 + lane) * 4 + wave];
+    } else {
+      prefetch(k + 2);
     }
     // ---- 2. cell backward for (unit, sample); own dz slice -> global dZ and the LDS B-operand image
     float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (computer) {
+      // the saved state of iterations k and k + 1 was fetched one and two steps ago; the only DMAs of this wave that may still be
+      // in flight are the three of iteration k + 2: a counted wait makes the landing explicit (in practice it never waits)
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    }
     if (computer && uvalid) {
-      const float dh = use.dy + dhr;
-      const float cp = has_prev ? prev.c : 0.f;
-      dz = mgr_cell_bwd(dh, use.g, use.c, cp, dcc);
+      const float* ru = ring + (k % 3) * (BW_RING_FLOATS / 3);
+      const float* rp = ring + ((k + 1) % 3) * (BW_RING_FLOATS / 3);
+      const float4 ug4 = *reinterpret_cast<const float4*>(ru + lane * 4);
+      const float dh = ru[256 + lane] + dhr;
+      const float cp = has_prev ? rp[320 + lane] : 0.f;
+      dz = mgr_cell_bwd(dh, ug4, ru[320 + lane], cp, dcc);
       if (bvalid) *reinterpret_cast<float4*>(jb.dZ + ((size_t)b * T + t) * N + unit * 4) = dz;
     }
-    if (!has_prev) return;  // the first forward step has no predecessor: nothing to send (workgroup-uniform)
+    if (!has_prev) break;   // the first forward step has no predecessor: nothing to send (workgroup-uniform; it is the last iteration)
     if (computer) {
       // own unit index s = 4*uq + wave -> image [q = s>>2 = uq][kk = gate][j][r = s&3 = wave]
       float* p = dzi + ((uq * 4) * 16 + j) * 4 + wave;
@@ -222,13 +267,8 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
         }
       }
     }
-  };
-
-  for (int k0 = 0; k0 < T; k0 += 3) {
-    do_step(k0, r0, r1, r2);
-    if (k0 + 1 < T) do_step(k0 + 1, r1, r2, r0);
-    if (k0 + 2 < T) do_step(k0 + 2, r2, r0, r1);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the wave ends
 }
 
 #define BW_FOREACH(X) X(8) X(16) X(32) X(64) X(100) X(128) X(300) X(500)
@@ -320,7 +360,7 @@ int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs)
     size_t lds = 84 * 1024;
     hipLaunchKernelGGL(k_scan_cluster_bwd_split, dim3(total_wgs), dim3(2 * BW_WAVES * 64), lds, mgr_stream(c), L);
   } else {
-    size_t lds = (size_t)(4 * 256 + 5 * 64 * 4) * sizeof(float);
+    size_t lds = (size_t)BW_LDS_FLOATS * sizeof(float);
     hipLaunchKernelGGL(k_scan_cluster_bwd, dim3(total_wgs), dim3(BW_WAVES * 64), lds, mgr_stream(c), L);
   }
   MGR_LAUNCH_CHECK();
