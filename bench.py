@@ -70,6 +70,33 @@ def _spawn_ranks(n):
     return rc
 
 
+class Watchdog:
+    """A rank that makes no progress for `limit` seconds ends itself with exit code 3 (os._exit from a timer thread: no exec, no
+    cleanup that could block on the GPU).  Under torch.distributed.run the launcher then terminates the other ranks; under
+    _spawn_ranks the first non-zero exit does.  The first RCCL run with N > 1 must not turn into a hang on somebody's box: a
+    communicator that never finishes its rendezvous, an all-reduce a peer never joins, a scan that waits for a workgroup that
+    was never placed - all of them stop the beat."""
+
+    def __init__(self, limit, rank):
+        import threading
+        self.limit, self.rank, self.last, self.where = float(limit), rank, time.time(), "start"
+        if self.limit > 0:
+            t = threading.Thread(target=self._run, daemon=True)
+            t.start()
+
+    def beat(self, where):
+        self.last, self.where = time.time(), where
+
+    def _run(self):
+        while True:
+            time.sleep(min(5.0, max(0.05, self.limit / 4)))
+            idle = time.time() - self.last
+            if idle > self.limit:
+                sys.stderr.write("bench.py: rank %d made no progress for %.0f s (last: %s) - giving up\n" % (self.rank, idle, self.where))
+                sys.stderr.flush()
+                os._exit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +115,10 @@ def main():
     ap.add_argument("--cpu-B", type=int, default=64)
     ap.add_argument("--comm", choices=("rccl", "host"), default="rccl",
                     help="gradient all-reduce: RCCL over xGMI (one GPU per rank) or summed on the host (ranks may share a GPU)")
+    ap.add_argument("--rccl-channels", type=int, default=8,
+                    help="NCCL_MAX_NCHANNELS for the gradient all-reduce unless the environment sets it (0: RCCL's default)")
+    ap.add_argument("--watchdog", type=float, default=120.0, help="seconds without progress after which a rank exits with code 3 (0: off)")
+    ap.add_argument("--stall-at-step", type=int, default=-1, help=argparse.SUPPRESS)   # test hook: stop making progress there
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -99,6 +130,7 @@ def main():
         # started without a launcher: be the launcher (one child per GPU; this process never touches the GPU)
         sys.exit(_spawn_ranks(args.gpus))
 
+    dog = Watchdog(args.watchdog, rank)
     import mgr_amd  # noqa: F401
     from mgr_amd import _capi
     from mgr_amd.configs import baseline_config
@@ -123,6 +155,7 @@ def main():
         if not args.batch:
             B = max(16, B // share)
     dev = _capi.Device(local_rank % max(1, ndev))
+    dog.beat("device")
     if args.show_plan:
         dev.call("mgr_tune", 2, 1)
     if args.scan_path:
@@ -136,7 +169,8 @@ def main():
             # rendezvous over the launcher's MASTER_ADDR / MASTER_PORT (+101); importing torch here would pull the wheel's
             # own HIP / HSA / RCCL copies into the process next to the ROCm installation's
             from mgr_amd.parallel import tcp_bootstrap
-            comm = RcclComm(dev, rank, world, tcp_bootstrap(rank, world))
+            comm = RcclComm(dev, rank, world, tcp_bootstrap(rank, world, timeout=max(30.0, args.watchdog)), max_channels=args.rccl_channels)
+    dog.beat("communicator")
 
     from mgr_amd.engine import Schedule
     eng = Engine(spec, B, T, Lmax, device=dev, seed=1000 + rank, comm=comm, world=world,
@@ -146,6 +180,7 @@ def main():
     eng._upload_inputs(xs, None, True)
     eng._upload_labels(labels, il, ll)
     dev.sync()
+    dog.beat("engine")
 
     def step(prefetch):
         # frozen encoders: the encoder pass of the NEXT step runs concurrently with this step's fusion / CTC / BPTT /
@@ -153,7 +188,11 @@ def main():
         # not prefetch, so exactly K complete steps - K encoder passes, K fusion passes - lie inside the timed region.
         eng.enqueue_train_step(None, None, None, None, rand=None, apply_update=True, upload=False,
                                prefetch_next=prefetch and not args.no_pipeline)
-        return eng.read_loss()
+        loss = eng.read_loss()
+        dog.beat("step %d" % (eng._step_id - 1))
+        if eng._step_id - 1 == args.stall_at_step:
+            time.sleep(1e6)
+        return loss
 
     for i in range(args.warmup):
         loss = step(i + 1 < args.warmup)
@@ -172,6 +211,7 @@ def main():
     dt = time.perf_counter() - t0
     if comm:
         dt = comm.allreduce_max_scalar(dt)
+    dog.beat("timed region done")
     fam = {}
     for i, name in enumerate(_capi.KERNEL_FAMILIES):
         n, ms = dev.prof_get(i)
@@ -221,6 +261,7 @@ def main():
         whole_ex = spec.flops_per_frame(executed=True) * value / 1e12     # what the dropout-aware kernels really multiply
         # ---- parity: same weights / batch / injected randomness on a short-T slice vs the fp64 oracle ----
         parity = None
+        dog.limit = max(dog.limit, 600.0) if dog.limit > 0 else 0   # (the CPU legs below are minutes of host work, not a hang)
         if not args.no_parity and world == 1:
             parity = loss_parity(spec, dev, T)
         cpu = None
@@ -237,7 +278,8 @@ def main():
                                       "(frozen audio 2xBiLSTM(500)+skeletal 2xBiLSTM(300), fusion BiLSTM(100), Dense 22, CTC)"
                           if args.config == "F" else args.config,
                           "per_gpu_batch": B, "global_batch": B * world, "maxlen": T, "parallelism": "dp%d" % world,
-                          "comm": (args.comm if world > 1 else None), "ranks_per_gpu": share},
+                          "comm": (args.comm if world > 1 else None), "ranks_per_gpu": share,
+                          "rccl_max_channels": (RcclComm.max_channels_in_effect if world > 1 and args.comm == "rccl" else None)},
                "roofline": roof, "cpu_baseline": cpu,
                "whole_step_tflops_algorithmic": round(whole, 3),
                "whole_step_frac_of_mfma_peak_algorithmic": round(whole / MFMA_F32_PEAK_TFLOPS, 5),

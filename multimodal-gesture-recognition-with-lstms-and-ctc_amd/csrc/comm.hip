@@ -32,9 +32,7 @@ int rccl_load() {
   // librccl.so (built against the wheel's bundled HIP / HSA runtimes), and a bare dlopen("librccl.so") returns THAT one -
   // whose HSA wrapper is not the initialised runtime ("pfn_hsa_system_get_info failed with 4107 ... no ROCm-capable
   // device is detected", seen under torch.distributed.run).  RTLD_LOCAL: its symbols are only reached through dlsym here.
-  const char* env = getenv("MGR_RCCL_PATH");
-  const char* names[] = {env ? env : "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so",
-                         "librccl.so.1", "librccl.so"};
+  const char* names[] = {"/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"};
   void* h = nullptr;
   for (const char* n : names) {
     h = dlopen(n, RTLD_NOW | RTLD_LOCAL);

@@ -34,16 +34,23 @@ def shard_batch(batch, rank, world):
 
 
 class RcclComm:
+    #: NCCL_MAX_NCHANNELS this process created its communicator under (None: RCCL's default) - bench.py records it
+    max_channels_in_effect = None
+
     def __init__(self, dev, rank, world, bootstrap, max_channels=8):
         """bootstrap(bytes_or_None) -> bytes : rank 0 passes the id, every rank gets it back.
         max_channels: upper bound of RCCL channels (= workgroups of its all-reduce kernel) unless the environment already
-        says NCCL_MAX_NCHANNELS: the gradient vector is a few MB, and the kernel has to find room on CUs that persistent
-        scans of this context occupy - 8 workgroups do, RCCL's default of dozens may have to wait for a scan
-        to end.  None leaves RCCL's default."""
+        says NCCL_MAX_NCHANNELS: the gradient vector is a few MB (latency-bound), and the kernel has to find room on CUs that
+        persistent scans of this context occupy - 8 workgroups of a collective's shape start within 200 us beside 408 resident
+        scan workgroups (tests/test_gpu_residency.py::test_a_collective_shaped_guest_...), RCCL's default of dozens may have to
+        wait for a scan to end.  None / 0 leaves RCCL's default.  The variable is process-wide: what was in effect when the
+        communicator was created is kept in `max_channels_in_effect` and printed in bench.py's JSON line."""
         import os
         self.dev, self.rank, self.world = dev, rank, world
         if max_channels and "NCCL_MAX_NCHANNELS" not in os.environ:
             os.environ["NCCL_MAX_NCHANNELS"] = str(int(max_channels))     # read by RCCL when the communicator is created
+        v = os.environ.get("NCCL_MAX_NCHANNELS")
+        RcclComm.max_channels_in_effect = self.max_channels_in_effect = int(v) if v and v.isdigit() else None
         lib = dev.lib
         uid = None
         if rank == 0:

@@ -1,6 +1,6 @@
 """Rank process of the 2-rank data-parallel GPU tests (tests/test_gpu_dataparallel.py).  Runs in a process forked from a fork
-server that never touched the GPU; initialises the GPU itself.  One GPU is shared by all ranks (Device(0)), gradients are
-summed by parallel.HostComm - everything else is the product path: Engine.enqueue_train_step's pipelined schedule, shard_batch,
+server that never touched the GPU; initialises the GPU itself.  Either one GPU is shared by all ranks (Device(0)) and gradients
+are summed by parallel.HostComm, or every rank has its own GPU and RCCL sums them - everything else is the product path: Engine.enqueue_train_step's pipelined schedule, shard_batch,
 Engine.apply_gradients' world > 1 branch (all-reduce -> /world -> clip -> Adam -> max-norm)."""
 import os
 import sys
@@ -50,16 +50,22 @@ def run_steps(eng, spec, batches, steps, pipelined=True):
     return losses
 
 
-def dp_rank(rank, world, port, out_path, exact, B, T, Lmax, steps):
+def dp_rank(rank, world, port, out_path, exact, B, T, Lmax, steps, comm_kind="host"):
+    """comm_kind "host": every rank on GPU 0, gradients summed by parallel.HostComm; "rccl": rank r on GPU r, gradients summed by
+    ncclAllReduce over xGMI (parallel.RcclComm; the unique id travels over a plain TCP exchange on 127.0.0.1:port)."""
     try:
         sys.path.insert(0, ROOT)
         import mgr_amd  # noqa: F401
         from mgr_amd import _capi
         from mgr_amd.engine import Engine
-        from mgr_amd.parallel import HostComm, shard_batch
+        from mgr_amd.parallel import HostComm, RcclComm, shard_batch, tcp_bootstrap
         from mgr_amd.synthetic import synthetic_weights
-        dev = _capi.Device(0)
-        comm = HostComm(dev, rank, world, addr="127.0.0.1", port=port, timeout=120.0)
+        if comm_kind == "rccl":
+            dev = _capi.Device(rank)
+            comm = RcclComm(dev, rank, world, tcp_bootstrap(rank, world, addr="127.0.0.1", port=port, timeout=120.0))
+        else:
+            dev = _capi.Device(0)
+            comm = HostComm(dev, rank, world, addr="127.0.0.1", port=port, timeout=120.0)
         spec = dp_spec(exact)
         eng = Engine(spec, B // world, T, Lmax, device=dev, seed=100 + rank, comm=comm, world=world)
         assert eng.can_pipeline
@@ -83,3 +89,20 @@ def dp_rank(rank, world, port, out_path, exact, B, T, Lmax, steps):
         with open(out_path + ".err", "w") as f:
             f.write(traceback.format_exc())
         raise
+
+
+def run_bench(out_path, argv, timeout):
+    """Runs `python bench.py <argv>` as a child of THIS process (forked from the fork server: it never touched the GPU, so it may
+    exec) and leaves {rc, seconds, stdout, stderr} in out_path as JSON."""
+    import json
+    import subprocess
+    import time
+    t0 = time.time()
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True, timeout=timeout)
+        rec = dict(rc=r.returncode, stdout=r.stdout[-4000:], stderr=r.stderr[-4000:])
+    except subprocess.TimeoutExpired as e:
+        rec = dict(rc=None, stdout=str(e.stdout)[-2000:], stderr=str(e.stderr)[-2000:])
+    rec["seconds"] = time.time() - t0
+    with open(out_path, "w") as f:
+        json.dump(rec, f)

@@ -1,5 +1,6 @@
 """CPU suite (no GPU): host logic, the C-ABI surface, and the fail-loud behaviour without a GPU."""
 import io
+import time
 import os
 import re
 
@@ -269,3 +270,50 @@ def test_executed_flop_accounting():
     skipped += 2 * (2 * 39 * 2000 * 0.4)      # audio l0: F = 39, p = .4 also takes the dropout-aware kernel
     skipped += 2 * (2 * 20 * 1200 * 0.6)      # skeletal l0: F = 20, p = .6
     assert abs((alg - ex) - skipped) < 1e-6 * alg
+
+
+def test_bench_watchdog_ends_a_rank_that_stops_making_progress(tmp_path):
+    """bench.py's Watchdog: beats keep the process alive; when they stop, the process exits with code 3 and says where it was."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "d = bench.Watchdog(0.4, 7)\n"
+            "for i in range(6):\n"
+            "    time.sleep(0.15); d.beat('step %%d' %% i)\n"      # 0.9 s of life with a 0.4 s limit: the beats are honoured
+            "print('alive', flush=True)\n"
+            "time.sleep(30)\n" % root)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=25)
+    assert r.returncode == 3 and "alive" in r.stdout
+    assert "rank 7 made no progress" in r.stderr and "last: step 5" in r.stderr
+    assert time.time() - t0 < 10
+    # limit 0 switches it off
+    code0 = "import sys, time; sys.path.insert(0, %r); import bench; d = bench.Watchdog(0, 0); time.sleep(0.5); print('ok')" % root
+    r = subprocess.run([sys.executable, "-c", code0], capture_output=True, text=True, timeout=25)
+    assert r.returncode == 0 and "ok" in r.stdout
+
+
+def test_bench_launcher_terminates_the_other_ranks_when_one_fails(tmp_path, monkeypatch):
+    """bench._spawn_ranks: the first rank that exits non-zero (e.g. ended by its watchdog) takes the others with it - nobody is
+    left waiting in a collective.  Ranks are fresh child processes of a launcher that never touched the GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "fake_rank.py"
+    script.write_text("import os, sys, time\n"
+                      "r = int(os.environ['RANK'])\n"
+                      "open(os.path.join(%r, 'pid%%d' %% r), 'w').write(str(os.getpid()))\n"
+                      "if r == 1:\n"
+                      "    time.sleep(0.5); sys.exit(3)\n"
+                      "time.sleep(60)\n" % str(tmp_path))
+    code = ("import sys; sys.path.insert(0, %r); import bench\n"
+            "sys.argv = [%r]\n"
+            "sys.exit(bench._spawn_ranks(3))\n" % (root, str(script)))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=40)
+    assert r.returncode == 3 and time.time() - t0 < 20
+    time.sleep(0.3)
+    for k in range(3):
+        pid = int(open(tmp_path / ("pid%d" % k)).read())
+        assert not os.path.exists("/proc/%d" % pid) or open("/proc/%d/stat" % pid).read().split()[2] == "Z", k

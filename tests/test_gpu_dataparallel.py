@@ -1,4 +1,5 @@
-"""-m gpu: a REAL world-size-2 data-parallel training step on the one GPU of the test box (BASELINE configs[3]).
+"""-m gpu: a REAL world-size-2 data-parallel training step (BASELINE configs[3]), in two variants: comm=host on the one GPU
+of the test box, comm=rccl on two GPUs (skipped where there is one: it enables itself on the first multi-GPU box).
 
 Two rank processes share GPU 0; each owns half of the global batch and its own Engine with the pipelined two-stream schedule
 on; gradients are summed by parallel.HostComm (RCCL refuses two ranks on one device).  Everything else is the path the 8-GPU
@@ -26,14 +27,22 @@ def _free_port():
     return p
 
 
-def _run_ranks(tmp_path, world, exact, B, T, Lmax, steps):
+def _need(comm_kind, world):
+    """RCCL refuses two ranks on one device: the rccl variants need `world` GPUs and enable themselves on a box that has them."""
+    if comm_kind == "rccl":
+        from mgr_amd._capi import device_count
+        if device_count() < world:
+            pytest.skip("comm=rccl needs %d GPUs (this box has %d): RCCL refuses two ranks on one device" % (world, device_count()))
+
+
+def _run_ranks(tmp_path, world, exact, B, T, Lmax, steps, comm_kind="host"):
     from multiprocessing import forkserver
     if getattr(forkserver._forkserver, "_forkserver_pid", None) is None:
         pytest.skip("the fork server must be started before the GPU is initialised: run through `pytest -m gpu` (tests/conftest.py)")
     ctx = mp.get_context("forkserver")
     port = _free_port()
     outs = [str(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
-    procs = [ctx.Process(target=dp_worker.dp_rank, args=(r, world, port, outs[r], exact, B, T, Lmax, steps)) for r in range(world)]
+    procs = [ctx.Process(target=dp_worker.dp_rank, args=(r, world, port, outs[r], exact, B, T, Lmax, steps, comm_kind)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -48,13 +57,16 @@ def _run_ranks(tmp_path, world, exact, B, T, Lmax, steps):
 
 
 
-def test_two_ranks_on_one_gpu_equal_one_process_on_the_full_batch(device, tmp_path):
-    """No random draws (dropout / noise 0): 4 pipelined steps of 2 ranks x B/2 must reproduce 1 process x B - per-step losses,
+@pytest.mark.parametrize("comm_kind", ["host", "rccl"])
+def test_two_ranks_equal_one_process_on_the_full_batch(device, tmp_path, comm_kind):
+    """comm=host: two ranks share GPU 0 (HostComm); comm=rccl: one GPU per rank, ncclAllReduce over xGMI - the same equalities.
+    No random draws (dropout / noise 0): 4 pipelined steps of 2 ranks x B/2 must reproduce 1 process x B - per-step losses,
     the all-reduced gradient, the updated weights - up to fp32 summation order; the two replicas must agree bit for bit."""
     from mgr_amd.engine import Engine
     from mgr_amd.synthetic import synthetic_weights
     B, T, Lmax, steps, world = 32, 96, 8, 4, 2
-    ranks = _run_ranks(tmp_path, world, True, B, T, Lmax, steps)
+    _need(comm_kind, world)
+    ranks = _run_ranks(tmp_path, world, True, B, T, Lmax, steps, comm_kind)
     # the same steps in one process on the full batch (this process, same GPU)
     spec = dp_worker.dp_spec(True)
     eng = Engine(spec, B, T, Lmax, device=device, seed=100)
@@ -83,10 +95,12 @@ def test_two_ranks_on_one_gpu_equal_one_process_on_the_full_batch(device, tmp_pa
     assert np.abs(w_ref["dense/W"] - synthetic_weights(spec, 3)["dense/W"]).max() > 1e-4
 
 
-def test_two_ranks_with_device_rng_stay_in_lockstep(device, tmp_path):
+@pytest.mark.parametrize("comm_kind", ["host", "rccl"])
+def test_two_ranks_with_device_rng_stay_in_lockstep(device, tmp_path, comm_kind):
     """The real configuration (dropout .4-.6, noise .5, per-rank RNG seeds): replicas must still hold identical weights after
     5 pipelined steps, losses finite and different between the ranks (different shards, different masks)."""
-    ranks = _run_ranks(tmp_path, 2, False, 32, 96, 8, 5)
+    _need(comm_kind, 2)
+    ranks = _run_ranks(tmp_path, 2, False, 32, 96, 8, 5, comm_kind)
     r0, r1 = ranks
     assert int(r0["status"]) == 0 and int(r1["status"]) == 0
     assert np.all(np.isfinite(r0["losses"])) and np.all(np.isfinite(r1["losses"]))
@@ -94,3 +108,40 @@ def test_two_ranks_with_device_rng_stay_in_lockstep(device, tmp_path):
     for k in r0.files:
         if k.startswith(("w__", "g__")):
             assert np.array_equal(r0[k], r1[k]), k
+
+
+def _bench_in_clean_process(tmp_path, argv, timeout):
+    import json
+    from multiprocessing import forkserver
+    if getattr(forkserver._forkserver, "_forkserver_pid", None) is None:
+        pytest.skip("the fork server must be started before the GPU is initialised: run through `pytest -m gpu` (tests/conftest.py)")
+    out = str(tmp_path / "bench.json")
+    p = mp.get_context("forkserver").Process(target=dp_worker.run_bench, args=(out, argv, timeout))
+    p.start()
+    p.join(timeout + 30)
+    assert not p.is_alive() and os.path.exists(out)
+    return json.load(open(out))
+
+
+def test_bench_two_ranks_host_comm_prints_one_line(device, tmp_path):
+    """`bench.py --gpus 2 --comm host` end to end on the 1-GPU box: launcher, two rank processes, TCP rendezvous, the pipelined
+    data-parallel step, max-over-ranks timing, ONE JSON line from rank 0."""
+    import json
+    rec = _bench_in_clean_process(tmp_path, ["--gpus", "2", "--comm", "host", "--steps", "3", "--warmup", "1", "--batch", "16",
+                                             "--maxlen", "96", "--no-cpu", "--no-parity"], 240)
+    assert rec["rc"] == 0, rec
+    lines = [l for l in rec["stdout"].splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["comm"] == "host" and d["config"]["global_batch"] == 32 and np.isfinite(d["loss"])
+
+
+def test_bench_watchdog_turns_a_stalled_rank_into_a_prompt_failure(device, tmp_path):
+    """One rank stops making progress at step 2 (test hook); its peer is then stuck in the gradient all-reduce.  Without the
+    watchdog this is a hang until the driver's limit; with it the stalled rank exits with code 3 after --watchdog seconds, the
+    launcher terminates the peer, and the whole command is back within a minute - no rank process survives."""
+    rec = _bench_in_clean_process(tmp_path, ["--gpus", "2", "--comm", "host", "--steps", "6", "--warmup", "1", "--batch", "16",
+                                             "--maxlen", "96", "--no-cpu", "--no-parity", "--watchdog", "6", "--stall-at-step", "2"], 150)
+    assert rec["rc"] == 3, rec
+    assert "made no progress" in rec["stderr"]
+    assert rec["seconds"] < 90, rec["seconds"]
