@@ -56,6 +56,11 @@ int mgr_host_alloc(mgr_ctx* ctx, size_t bytes, void** out);
 int mgr_host_free(mgr_ctx* ctx, void* p);
 int mgr_h2d_async(mgr_ctx* ctx, void* d, const void* h_pinned, size_t n);
 int mgr_d2h(mgr_ctx* ctx, void* h, const void* d, size_t n);
+/* The way back without a host stall: device -> pinned host memory (mgr_host_alloc), ordered on the current stream; the bytes are
+ * valid once an event recorded behind the call has completed (mgr_event_record + mgr_event_sync).  What predict_generator's
+ * pipeline downloads posteriors / decoded paths with while the next batch is computed (sequence_decoding.py:118-127). */
+int mgr_d2h_async(mgr_ctx* ctx, void* h_pinned, const void* d, size_t n);
+int mgr_event_sync(mgr_ctx* ctx, int ev);                 /* the host waits for event ev as last recorded */
 int mgr_d2d(mgr_ctx* ctx, void* dst, const void* src, size_t n);
 int mgr_sync(mgr_ctx* ctx);
 int mgr_stream_set(mgr_ctx* ctx, int idx);

@@ -28,6 +28,8 @@ SIGNATURES = {
     "mgr_h2d": (i32, [vp, vp, vp, sz]),
     "mgr_d2h": (i32, [vp, vp, vp, sz]),
     "mgr_d2d": (i32, [vp, vp, vp, sz]),
+    "mgr_d2h_async": (i32, [vp, vp, vp, sz]),
+    "mgr_event_sync": (i32, [vp, i32]),
     "mgr_sync": (i32, [vp]),
     "mgr_stream_set": (i32, [vp, i32]),
     "mgr_stream_wait": (i32, [vp, i32, i32]),
@@ -263,6 +265,13 @@ class Device:
     def h2d_async(self, darr, host_pinned):
         """Enqueue a copy from a pinned() array on the current stream; does not block the host."""
         check(self.lib.mgr_h2d_async(self.ctx, darr.ptr, host_pinned.ctypes.data, host_pinned.nbytes))
+
+    def d2h_async(self, host_pinned, darr):
+        """Enqueue a copy into a pinned() array on the current stream; valid after an event recorded behind it (event_sync)."""
+        check(self.lib.mgr_d2h_async(self.ctx, host_pinned.ctypes.data, darr.ptr, min(host_pinned.nbytes, darr.nbytes)))
+
+    def event_sync(self, ev):
+        check(self.lib.mgr_event_sync(self.ctx, ev))
 
     def zeros(self, shape, dtype=np.float32):
         return self.empty(shape, dtype).zero()

@@ -137,6 +137,19 @@ int mgr_d2h(mgr_ctx* c, void* h, const void* d, size_t n) {
   return 0;
 }
 
+int mgr_d2h_async(mgr_ctx* c, void* h_pinned, const void* d, size_t n) {
+  MGR_REQUIRE(c && d && h_pinned, "null argument");
+  // h_pinned must come from mgr_host_alloc; its contents are valid once an event recorded behind this call has completed
+  MGR_HIP(hipMemcpyAsync(h_pinned, d, n, hipMemcpyDeviceToHost, mgr_stream(c)));
+  return 0;
+}
+
+int mgr_event_sync(mgr_ctx* c, int ev) {
+  MGR_REQUIRE(c && ev >= 0 && ev < MGR_NUM_EVENTS, "bad event index");
+  MGR_HIP(hipEventSynchronize(c->events[ev]));
+  return 0;
+}
+
 int mgr_d2d(mgr_ctx* c, void* dst, const void* src, size_t n) {
   MGR_REQUIRE(c && dst && src, "null argument");
   MGR_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, mgr_stream(c)));

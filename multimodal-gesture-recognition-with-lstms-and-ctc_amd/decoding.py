@@ -62,6 +62,13 @@ def greedy_decode(pred_out, thr, skip=2, dev=None):
     return [confidence_filter_collapse(best[j], prob[j], thr) for j in range(best.shape[0])]
 
 
+def greedy_decode_argmax(best, prob, thr):
+    """The same from per-frame (best label, its probability) arrays - what Model.predict_generator(decode="argmax") returns
+    straight from the device, without the (N, T, C) posteriors crossing PCIe."""
+    best, prob = np.asarray(best), np.asarray(prob)
+    return [confidence_filter_collapse(best[j], prob[j], thr) for j in range(best.shape[0])]
+
+
 def write_mlf(path, decoded_names, f_list, ignore_list, name_fmt="Sample%05d"):
     """HTK master label file in the reference's layout (sequence_decoding.py:35-36,57-65)."""
     with open(path, "w") as of:

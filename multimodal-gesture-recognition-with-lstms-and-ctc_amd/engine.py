@@ -202,8 +202,9 @@ class Engine:
                     self.dY1[s["name"]] = dev.empty((B, T, 2 * Hs[0]))
         self.FEAT = dev.empty((B, T, W))
         self._feat_ring = [self.FEAT]
-        if train and self.can_pipeline:
-            self._feat_ring.append(dev.empty((B, T, W)))   # second FEAT buffer for cross-step pipelining
+        if (train and self.can_pipeline) or self.inference_only:
+            # second FEAT buffer: cross-step pipelining of training (frozen encoders) / batch pipelining of inference
+            self._feat_ring.append(dev.empty((B, T, W)))
         # Transposed copies [B, features, T padded to 128] of the inputs of the WIDE dropout layers (depth-2 encoder layers, the
         # fusion layer): the dropout-aware projection gathers kept FEATURES, which are contiguous rows there (gemm.hip,
         # k_gemm_nn_sparse<.., true>).  Row-major stays what everything else reads (dW GEMMs, residual adds, dense layer).
@@ -631,6 +632,140 @@ class Engine:
         P = self.P.download()
         self._check_scans()
         return P
+
+    # ------------------------------------------------------------------------------------------ pipelined inference / validation
+    EV_ENC = (46, 47)     # the encoder pass into FEAT buffer 0 / 1 is complete
+    EV_FUSED = (48, 49)   # the fusion / head pass that read FEAT buffer 0 / 1 (and whatever decodes its output) is complete
+    EV_OUT = (50, 51)     # the result of the batch in output slot 0 / 1 has reached its pinned host buffer
+
+    def predict_stream(self, batches, output="posteriors", train_phase=False, beam_width=10, merge_repeated=True):
+        """Batches of an inference / validation run are independent of each other: this generator keeps two of them in flight.
+        Batch n + 1 is uploaded (copy stream) and runs its encoder pass (stream ES, into the other FEAT buffer) beside batch n's
+        fusion layer / head / decode kernels (stream 0) and beside the download of batch n - 1's result (its own stream, into
+        pinned host memory); the host only ever waits for the result it is about to hand out.  What the reference does with
+        predict_generator over the whole set (sequence_decoding.py:118-127) and with the validation loop of every epoch
+        (multimodal.py:264-269), one blocking batch at a time.
+
+        batches: iterable of input dicts {stream name: (B, T, F)} - for output="loss" of tuples (inputs, labels, input_length,
+        label_length).  Yields, in order, per batch:
+          "posteriors"  P (B, T, C) float32                  (learning phase 0 unless train_phase)
+          "argmax"      (best (B, T - skip) int32, prob (B, T - skip) float32): mgr_frame_argmax on the device, the (B, T, C)
+                        posteriors never travel to the host (decoding.confidence_filter_collapse does the rest)
+          "beam"        (paths: list of B label lists, log-probabilities (B,) float64): mgr_ctc_beam_search on the device
+          "loss"        per-sample CTC losses (B,) float32  (a training engine; learning phase as train_phase)
+        Results are bit-identical to the one-batch-at-a-time calls (predict / loss_on_batch): same kernels, same order per batch."""
+        sp, dev, B, T = self.spec, self.dev, self.B, self.T
+        Cn, skip = sp.num_classes, int(sp.ctc["skip"])
+        if output not in ("posteriors", "argmax", "beam", "loss"):
+            raise ValueError("unknown output %r" % (output,))
+        if output == "loss" and self.inference_only:
+            raise ValueError("output='loss' needs a training engine (labels, CTC workspace)")
+        self._bind()
+        if self._prefetched is not None:     # a pipelined training encoder pass is in flight: let it finish, then discard it
+            dev.wait(0, self.ES)
+            self._prefetched = None
+        dev.sync()                           # (nothing of an earlier call may still use the buffers the pipeline cycles through)
+        ring = self._feat_ring
+        ES, OUT = (self.ES if len(ring) > 1 else 0), self.LOSS_STREAM
+        st = self.__dict__.setdefault("_stream_bufs", {})
+
+        def bufs(key, make):
+            if key not in st:
+                st[key] = make()
+            return st[key]
+
+        # two P buffers: the decode kernels / the download of batch n read one on their own stream while the head of batch n + 1
+        # writes the other
+        pring = bufs("pring", lambda: [self.P, self.mem.empty((B, T, Cn))])
+        if output == "posteriors":
+            pins = bufs("P", lambda: [dev.pinned((B, T, Cn), np.float32) for _ in range(2)])
+        elif output == "argmax":
+            dbest = bufs("dbest", lambda: self.mem.empty((B, T - skip), np.int32))
+            dprob = bufs("dprob", lambda: self.mem.empty((B, T - skip), np.float32))
+            pins = bufs("am", lambda: [(dev.pinned((B, T - skip), np.int32), dev.pinned((B, T - skip), np.float32)) for _ in range(2)])
+        elif output == "beam":
+            dil = bufs("dil", lambda: self.mem.empty((B,), np.int32))
+            dil.upload(np.full(B, T - skip, np.int32))
+            dout = bufs("dout", lambda: self.mem.empty((B, T - skip), np.int32))
+            dlen = bufs("dlen", lambda: self.mem.empty((B,), np.int32))
+            dlogp = bufs("dlogp", lambda: self.mem.empty((B,), np.float64))
+            wsb = bufs("wsb%d" % beam_width, lambda: self.mem.bytes(self.lib.mgr_ctc_beam_ws_bytes(B, T, Cn, int(beam_width))))
+            pins = bufs("beam", lambda: [(dev.pinned((B, T - skip), np.int32), dev.pinned((B,), np.int32), dev.pinned((B,), np.float64))
+                                         for _ in range(2)])
+        else:
+            pins = bufs("loss", lambda: [dev.pinned((B,), np.float32) for _ in range(2)])
+
+        def collect(i):
+            o = i & 1
+            dev.event_sync(self.EV_OUT[o])
+            if output == "posteriors":
+                return pins[o].copy()
+            if output == "argmax":
+                return pins[o][0].copy(), pins[o][1].copy()
+            if output == "beam":
+                po, pl, ps = pins[o]
+                return [[int(v) for v in po[b, :pl[b]]] for b in range(B)], ps.copy()
+            return pins[o].copy()
+
+        n = 0
+        try:
+            for i, item in enumerate(batches):
+                o, f = i & 1, i % len(ring)
+                inputs = item[0] if output == "loss" else item
+                # ---- upload + encoder pass of batch i (stream ES), beside what stream 0 still does for batch i - 1
+                self._upload_inputs(inputs, None, train_phase, stream=ES)
+                self._xin_user[self._xin_slot] = 1 << 60       # (its readers are known by event, not by a loss read-back)
+                dev.stream(ES)
+                dev.wait_event(ES, self.EV_FUSED[f])            # the fusion pass that read this FEAT buffer two batches ago
+                self._enqueue_encoders(train_phase, None, ring[f], ES, self.rng_step)
+                dev.stream(ES)
+                dev.record(self.EV_ENC[f])
+                # ---- fusion layer, head, decode / loss kernels of batch i (stream 0)
+                dev.stream(0)
+                dev.wait_event(0, self.EV_ENC[f])
+                dev.wait_event(0, self.EV_OUT[o])               # batch i - 2's decode / download read the P buffer this pass overwrites
+                if output == "loss":
+                    self._upload_labels(item[1], item[2], item[3])
+                self.P = pring[o]
+                self._enqueue_fusion_head(train_phase, None, ring[f], self.rng_step)
+                if train_phase:
+                    self.rng_step += 1
+                dev.stream(0)
+                if output == "loss":
+                    dev.call("mgr_ctc_loss_grad", self.P, self.labels_d, self.ilen_d, self.llen_d, B, T, Cn, self.Lmax, skip, Cn - 1,
+                             float(sp.ctc["eps"]), 1.0, self.loss_b, 0, self.ws_ctc, self.ws_ctc.nbytes)
+                    dev.record(self.EV_LAB[self._lab_slot])
+                    self._lab_user[self._lab_slot] = 1 << 60
+                dev.record(self.EV_FUSED[f])
+                # ---- decode kernels and the way back to pinned host memory: their own stream, beside batch i + 1's fusion layer
+                dev.stream(OUT)
+                dev.wait_event(OUT, self.EV_FUSED[f])
+                if output == "posteriors":
+                    dev.d2h_async(pins[o], pring[o])
+                elif output == "argmax":
+                    dev.call("mgr_frame_argmax", pring[o], B, T, Cn, skip, dbest, dprob)
+                    dev.d2h_async(pins[o][0], dbest)
+                    dev.d2h_async(pins[o][1], dprob)
+                elif output == "beam":
+                    dev.call("mgr_ctc_beam_search", pring[o], dil, B, T, Cn, skip, Cn - 1, int(beam_width), C.c_float(float(sp.ctc["eps"])),
+                             1 if merge_repeated else 0, dout, dlen, dlogp, wsb, wsb.nbytes)
+                    dev.d2h_async(pins[o][0], dout)
+                    dev.d2h_async(pins[o][1], dlen)
+                    dev.d2h_async(pins[o][2], dlogp)
+                else:
+                    dev.d2h_async(pins[o], self.loss_b)
+                dev.record(self.EV_OUT[o])
+                dev.stream(0)
+                n = i + 1
+                if i >= 1:
+                    yield collect(i - 1)
+            if n >= 1:
+                yield collect(n - 1)
+        finally:
+            self.P = pring[0]
+            dev.stream(0)
+            dev.sync()
+            self._check_scans()
 
     def _upload_labels(self, labels, input_length, label_length):
         lab = np.asarray(labels)

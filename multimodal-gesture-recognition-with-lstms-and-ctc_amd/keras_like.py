@@ -320,6 +320,12 @@ class Model:
                         raise ValueError("weight %s: expected %s got %s" % (k, self._weights[k].shape, np.shape(v)))
                     self._weights[k] = np.asarray(v, np.float32).copy()
 
+    def clear_scan_status(self):
+        """Forget a recorded non-finite state / scan give-up of the engine (Engine.clear_scan_status); set_weights_dict /
+        load_weights of a good checkpoint do it implicitly."""
+        if self._engine is not None:
+            self._engine.clear_scan_status()
+
     def get_weights(self):
         w = self.get_weights_dict()
         return [w[n] for n, _, _, _ in self.spec.weight_table()]
@@ -473,11 +479,7 @@ class Model:
                 losses.append(self.train_on_batch(x, y, next_x=pending[0] if pending is not None else None))
             logs = {"loss": float(np.mean(losses)) if losses else float("nan")}
             if validation_data is not None and validation_steps:
-                vl = []
-                for _ in range(int(validation_steps)):
-                    x, y = next(validation_data)
-                    vl.append(self.test_on_batch(x, y))
-                logs["val_loss"] = float(np.mean(vl))
+                logs["val_loss"] = self.evaluate_generator(validation_data, validation_steps)
             if verbose:
                 print("Epoch %d/%d - %.1fs - %s" % (epoch + 1, epochs, time.time() - t0,
                                                     " - ".join("%s: %.4f" % kv for kv in logs.items())))
@@ -491,15 +493,79 @@ class Model:
                 cb.on_train_end({})
         return hist
 
-    def predict_generator(self, generator, steps, verbose=0, **kwargs):
+    @staticmethod
+    def _pad_batch(arrs, B):
+        """A short last batch is padded with zero rows to the engine's batch size (a sample's results do not depend on the
+        other rows of its batch); returns (padded arrays, true row count)."""
+        n = next(iter(arrs.values())).shape[0] if isinstance(arrs, dict) else arrs.shape[0]
+        if n == B:
+            return arrs, n
+        pad = lambda a: np.concatenate([np.asarray(a), np.zeros((B - n,) + np.asarray(a).shape[1:], np.asarray(a).dtype)], axis=0)
+        return ({k: pad(v) for k, v in arrs.items()} if isinstance(arrs, dict) else pad(arrs)), n
+
+    def predict_generator(self, generator, steps, verbose=0, decode=None, beam_width=10, **kwargs):
+        """keras Model.predict_generator (sequence_decoding.py:118-127): the batches of the run are pipelined through
+        Engine.predict_stream - upload and encoder pass of batch n + 1 beside the fusion layer / head of batch n and the
+        download of batch n - 1 - and give bit for bit what predict_on_batch gives one batch at a time.
+        decode=None returns the softmax outputs (N, T, C) like Keras; decode="argmax" returns (best, prob), each (N, T - skip):
+        the per-frame best label and its probability computed on the device (what decode_batch needs; the (N, T, C) posteriors
+        never cross PCIe); decode="beam" returns (paths, log-probabilities) of mgr_ctc_beam_search(beam_width)."""
+        steps = int(steps)
+        if steps <= 0:
+            return np.zeros((0,))
+        first = next(generator)
+        x0 = first[0] if isinstance(first, tuple) else first
+        ins0 = self._split_inputs(x0)
+        f0 = next(iter(ins0.values()))
+        B, T = f0.shape[0], f0.shape[1]
+        e = self._ensure_engine(B, T, self._engine.Lmax if self._engine else 1, inference_only=self._engine is None)
+        counts = []
+
+        def feed():
+            for i in range(steps):
+                batch = first if i == 0 else next(generator)
+                x = batch[0] if isinstance(batch, tuple) else batch
+                ins, n = self._pad_batch(self._split_inputs(x), B)
+                counts.append(n)
+                yield ins
+
+        output = {None: "posteriors", "argmax": "argmax", "beam": "beam"}[decode]
         outs = []
-        for i in range(int(steps)):
-            batch = next(generator)
-            x = batch[0] if isinstance(batch, tuple) else batch
-            outs.append(self.predict_on_batch(x))
+        for i, r in enumerate(e.predict_stream(feed(), output=output, train_phase=bool(learning_phase()), beam_width=beam_width)):
+            n = counts[i]
+            if output == "posteriors":
+                outs.append(r[:n])
+            elif output == "argmax":
+                outs.append((r[0][:n], r[1][:n]))
+            else:
+                outs.append((r[0][:n], r[1][:n]))
             if verbose:
-                print("%d/%d" % (i + 1, int(steps)))
-        return np.concatenate(outs, axis=0)
+                print("%d/%d" % (i + 1, steps))
+        if output == "posteriors":
+            return np.concatenate(outs, axis=0)
+        if output == "argmax":
+            return np.concatenate([o[0] for o in outs], axis=0), np.concatenate([o[1] for o in outs], axis=0)
+        return [p for o in outs for p in o[0]], np.concatenate([o[1] for o in outs], axis=0)
+
+    def evaluate_generator(self, generator, steps, **kwargs):
+        """Mean CTC loss over `steps` batches (the validation loop of fit_generator, multimodal.py:264-269), pipelined like
+        predict_generator; the learning phase is whatever is set (the reference leaves it at 1 during validation)."""
+        steps = int(steps)
+        if steps <= 0:
+            return float("nan")
+        first = next(generator)
+        x0 = first[0]
+        ins0 = self._split_inputs(x0)
+        f0 = next(iter(ins0.values()))
+        e = self._ensure_engine(f0.shape[0], f0.shape[1], np.asarray(x0["the_labels"]).shape[1])
+
+        def feed():
+            for i in range(steps):
+                x = (first if i == 0 else next(generator))[0]
+                yield self._split_inputs(x), np.asarray(x["the_labels"]), x["input_length"], x["label_length"]
+
+        means = [float(np.mean(l)) for l in e.predict_stream(feed(), output="loss", train_phase=bool(learning_phase()))]
+        return float(np.mean(means))
 
 
 def model_from_json(text, device=0):

@@ -1,7 +1,7 @@
 """Decode for the fusion network (reference multimodal_fusion/sequence_decoding.py:21-69)."""
 import numpy as np
 
-from ..decoding import greedy_decode, write_mlf
+from ..decoding import greedy_decode, greedy_decode_argmax, write_mlf
 
 # gesture code -> class name; the blank (21) is emitted as "sil" (reference :26-29)
 map_gest = {0: "oov", 1: "VA", 2: "VQ", 3: "PF", 4: "FU", 5: "CP", 6: "CV", 7: "DC", 8: "SP", 9: "CN", 10: "FN",
@@ -18,4 +18,14 @@ def decode_batch(pred_out, f_list, out_file="final_ctc_recout.mlf"):
     ids = greedy_decode(np.asarray(pred_out), THRESHOLD, skip=2)
     ret = [[map_gest[i] for i in seq] for seq in ids]
     write_mlf(out_file, ret, f_list, ignore_list, "Sample%05d")
+    return ret
+
+
+def decode_argmax(best, prob, f_list, out_file=None):
+    """decode_batch from the per-frame (best label, probability) pairs that Model.predict_generator(decode="argmax") computes
+    on the device: same filter, same collapse, same MLF."""
+    ids = greedy_decode_argmax(best, prob, THRESHOLD)
+    ret = [[map_gest[i] for i in seq] for seq in ids]
+    if out_file is not None:
+        write_mlf(out_file, ret, f_list, ignore_list, "Sample%05d")
     return ret

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--beam", type=int, default=10)
     ap.add_argument("--cpu-n", type=int, default=6)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="sequences per inference batch")
     args = ap.parse_args()
     import mgr_amd  # noqa: F401
     from mgr_amd import _capi, decoding
@@ -57,20 +58,34 @@ def main():
 
     dev = _capi.Device(0)
     N, T, C = args.n, args.maxlen, 22
-    # ---- predict_generator half: fusion network inference in chunks of 46 sequences
+    # ---- predict_generator half: fusion network inference, one batch at a time (round 2's path) and pipelined (Engine.predict_stream)
     spec = fusion_spec()
-    Bp = 46 if N % 46 == 0 else min(N, 64)
+    Bp = args.batch
     eng = Engine(spec, Bp, T, 1, device=dev, seed=1, inference_only=True)
     eng.set_weights(synthetic_weights(spec, 20131900 + 5))
-    xs, _, _, _ = synthetic_arrays(spec, Bp, T, 1, 20131900 + 5)
-    eng.predict(xs)
+    nchunks = (N + Bp - 1) // Bp
+    chunks = [synthetic_arrays(spec, Bp, T, 1, 20131900 + 5 + i)[0] for i in range(min(nchunks, 3))]
+    feed = lambda: (chunks[i % len(chunks)] for i in range(nchunks))
+    eng.predict(chunks[0])
     dev.sync()
     t0 = time.perf_counter()
-    nchunks = (N + Bp - 1) // Bp
-    for _ in range(nchunks):
-        eng.predict(xs)
+    seq = [eng.predict(x) for x in feed()]
     dev.sync()
     t_pred = time.perf_counter() - t0
+    list(eng.predict_stream(feed(), output="posteriors"))            # warm-up (pinned buffers)
+    t0 = time.perf_counter()
+    pipe = list(eng.predict_stream(feed(), output="posteriors"))
+    t_pipe = time.perf_counter() - t0
+    same = all(np.array_equal(a, b) for a, b in zip(seq, pipe))
+    list(eng.predict_stream(feed(), output="argmax"))
+    t0 = time.perf_counter()
+    am = list(eng.predict_stream(feed(), output="argmax"))
+    ids = [decoding.greedy_decode_argmax(b, p, 0.5) for b, p in am]
+    t_e2e_best = time.perf_counter() - t0
+    list(eng.predict_stream(feed(), output="beam", beam_width=args.beam))
+    t0 = time.perf_counter()
+    bm = list(eng.predict_stream(feed(), output="beam", beam_width=args.beam))
+    t_e2e_beam = time.perf_counter() - t0
     eng.close()
 
     # ---- decode half
@@ -97,11 +112,23 @@ def main():
     out = {
         "metric": "CTC decode, ChaLearn-2013-test-shaped synthetic set", "n_sequences": N, "maxlen": T, "classes": C,
         "beam_width": args.beam,
-        "predict_sequences_per_s": round(nchunks * Bp / t_pred, 1), "predict_ms_per_chunk_of_%d" % Bp: round(t_pred / nchunks * 1e3, 2),
+        "predict_batch": Bp, "predict_batches": nchunks,
+        "predict_one_batch_at_a_time": {"sequences_per_s": round(nchunks * Bp / t_pred, 1), "ms_per_batch": round(t_pred / nchunks * 1e3, 2),
+                                        "frames_per_s": round(nchunks * Bp * T / t_pred)},
+        "predict_pipelined": {"sequences_per_s": round(nchunks * Bp / t_pipe, 1), "ms_per_batch": round(t_pipe / nchunks * 1e3, 2),
+                              "frames_per_s": round(nchunks * Bp * T / t_pipe), "bit_identical_to_sequential": bool(same),
+                              "incl": "host batch -> pinned staging -> H2D, (B,T,C) posteriors -> host"},
+        "end_to_end_pipelined": {"predict_plus_best_path": {"sequences_per_s": round(nchunks * Bp / t_e2e_best, 1), "ms_total": round(t_e2e_best * 1e3, 1),
+                                                            "note": "frame arg-max on the device, threshold filter + collapse on the host"},
+                                 "predict_plus_beam": {"sequences_per_s": round(nchunks * Bp / t_e2e_beam, 1), "ms_total": round(t_e2e_beam * 1e3, 1),
+                                                       "note": "beam search on the device from the posteriors in HBM (its own stream, beside the next batch).  "
+                                                               "WORST CASE for the beam kernel: a random-weight network's posteriors are near-uniform, every "
+                                                               "frame extends every prefix; beam_sequences_per_s below is the rate on peaky, trained-like posteriors"}},
         "beam_sequences_per_s": round(N / tb, 1), "beam_ms_total_incl_h2d_d2h": round(tb * 1e3, 2),
         "best_path_sequences_per_s": round(N / tg, 1), "best_path_ms_total_incl_h2d_d2h": round(tg * 1e3, 2),
         "cpu_oracle": {"sample": k, "beam_sequences_per_s": round(k / t_cpu_beam, 3),
                        "best_path_sequences_per_s": round(k / t_cpu_greedy, 1), "cores": 1, "kind": "port"},
+        "cpu_oracle_comparison_covers": "%d of %d sequences (all %d are compared in tests/test_gpu_fullsize.py::test_config_D_decode_full_set_matches_oracle_on_every_sequence)" % (k, N, N),
         "label_error_rate_vs_cpu_ref": {"beam": decoding.label_error_rate(beam[:k], ref_beam),
                                         "best_path": decoding.label_error_rate(greedy[:k], ref_greedy)},
         "exact_match_vs_cpu_ref": {"beam": sum(a == b for a, b in zip(beam[:k], ref_beam)) / k,
