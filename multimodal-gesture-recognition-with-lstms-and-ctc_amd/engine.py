@@ -159,8 +159,13 @@ class Engine:
                     L.cs = dev.empty((B, T, H))
                     L.dZ = dev.empty((B, T, 4 * H))
                     L.ws_scan = dev.bytes(self.lib.mgr_lstm_scan_ws_bytes(B, T, H))
-                    L.ws_pg = dev.bytes(self.lib.mgr_lstm_param_grads_dropout_ws_bytes(B, T, fin, H) if p > 0
-                                        else self.lib.mgr_lstm_param_grads_ws_bytes(B, T, fin, H))
+                    need = (self.lib.mgr_lstm_param_grads_dropout_ws_bytes(B, T, fin, H) if p > 0
+                            else self.lib.mgr_lstm_param_grads_ws_bytes(B, T, fin, H))
+                    if p > 0 and self.schedule.transposed_inputs:
+                        # (+ the transposed dZ of the dropout-aware dW from the transposed activation copy: sized here, not by a
+                        # hipMalloc in the middle of the first training step)
+                        need = max(need, self.lib.mgr_lstm_param_grads_dropout_t_ws_bytes(B, T, fin, H, (T + 127) // 128 * 128))
+                    L.ws_pg = dev.bytes(need)
                 if p > 0:
                     L.mask = dev.empty((4, B, fin))
                     L.ws_sp = dev.bytes(self.lib.mgr_lstm_input_proj_dropout_ws_bytes(B, fin, H))   # kept-feature lists
@@ -980,7 +985,9 @@ class Engine:
                     # two per CU): if GEMM waves get there first the scan's workgroups trickle in behind them and the
                     # whole scan runs at half speed (measured 22.7 vs 11.4 ms).  So the GEMMs wait - on the device - until
                     # the scan launched next on this context reports every workgroup resident.
-                    if self.schedule.resident_wait_us > 0:
+                    # (not in front of a host-blocking all-reduce: HostComm holds the host inside finish(), the scan the gate waits
+                    # for would only be enqueued after it - the gate would always run into its bound)
+                    if self.schedule.resident_wait_us > 0 and not getattr(self.comm, "host_blocking", False):
                         dev.call("mgr_stream_wait_next_resident", self.schedule.resident_wait_us)
                     finish()
                     if ahead:

@@ -95,6 +95,9 @@ def _kernel_maxnorm(inner, name):
     """kernel_constraint of an LSTM config -> max-norm value (0.0 = unconstrained).  The reference constrains every LSTM input
     kernel with maxnorm(3) over axis 0 (multimodal.py:162, speech_lstm_ctc_words.py:60); anything else is refused rather than
     silently replaced."""
+    for other in ("recurrent_constraint", "bias_constraint"):      # (checked FIRST: a layer without a kernel constraint may carry one)
+        if inner.get(other) is not None:
+            raise ValueError("%s of layer %s is not implemented" % (other, name))
     kc = inner.get("kernel_constraint")
     if kc is None:
         return 0.0
@@ -104,9 +107,6 @@ def _kernel_maxnorm(inner, name):
         raise ValueError("kernel_constraint %r of layer %s is not implemented (only MaxNorm)" % (cls, name))
     if int(cfg.get("axis", 0)) != 0:
         raise ValueError("MaxNorm over axis %r (layer %s) is not implemented (the reference uses axis 0)" % (cfg.get("axis"), name))
-    for other in ("recurrent_constraint", "bias_constraint"):
-        if inner.get(other) is not None:
-            raise ValueError("%s of layer %s is not implemented" % (other, name))
     return float(cfg.get("max_value", 2))
 
 

@@ -87,6 +87,7 @@ class HostComm:
     result is broadcast, so every replica receives the same bits."""
 
     PORT_OFFSET = 102
+    host_blocking = True      # allreduce_sum blocks the host: the engine must not park a device-side wait in front of it
 
     def __init__(self, dev, rank, world, addr=None, port=None, timeout=600.0):
         import os

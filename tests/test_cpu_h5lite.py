@@ -215,6 +215,15 @@ def test_keras_json_to_spec():
     lstm_cfgs[1]["kernel_constraint"] = {"class_name": "UnitNorm", "config": {"axis": 0}}
     with pytest.raises(ValueError, match="only MaxNorm"):
         keras_io.spec_from_keras_json(json.dumps(d))
+    # a recurrent / bias constraint is refused whether or not the layer also has a kernel constraint (it used to be accepted -
+    # and silently ignored - on layers WITHOUT one)
+    for kc in (None, {"class_name": "MaxNorm", "config": {"max_value": 3, "axis": 0}}):
+        for other in ("recurrent_constraint", "bias_constraint"):
+            lstm_cfgs[1]["kernel_constraint"] = kc
+            lstm_cfgs[1][other] = {"class_name": "MaxNorm", "config": {"max_value": 3, "axis": 0}}
+            with pytest.raises(ValueError, match=other + " of layer"):
+                keras_io.spec_from_keras_json(json.dumps(d))
+            lstm_cfgs[1][other] = None
 
 
 def test_model_hdf5_checkpoint_round_trip(tmp_path):

@@ -38,15 +38,24 @@ def _run_case(device, key, B=None, T=None, lmin=3, lmax=10, check_grads=True, se
     loss = float(eng.loss_mean.download()[0])
     assert abs(loss - ref_loss) <= 1e-4 * abs(ref_loss), (key, loss, ref_loss)
     assert np.allclose(eng.loss_b.download(), ref_lb, rtol=1e-4)
-    # (with doubled weights the recurrence amplifies fp32 rounding: a different - equally valid - summation order of the scan
-    # kernel moves this figure between 1.8e-4 and 2.2e-4 at config A; the loss bound above is the north-star tolerance)
-    assert rel_err(eng.P.download(), ref_P) < 3e-4
+    # What bounds the activations and gradients is fp32 arithmetic itself, not the kernels: the SAME oracle run in float32 (numpy /
+    # OpenBLAS, yet another summation order) sits at a comparable distance from the fp64 run.  The GPU figures are held to a small
+    # multiple of that distance (the error model) and, as an outer limit, to the absolute caps used since round 1: softmax 3e-4,
+    # gradients 5e-3 of the tensor maximum (fp32 BPTT through 200-1900 steps x 2 layers amplifies rounding; with doubled weights
+    # the recurrence amplifies it further: 1.8e-4 .. 2.2e-4 at config A depending on the scan kernel's summation order).
+    f32 = lambda d: {k: np.asarray(v, np.float32) for k, v in d.items()}
+    rand32 = {k: (None if v is None else np.asarray(v, np.float32)) for k, v in rand.items()}
+    _, _, g32, P32 = nr.loss_and_grads(sd, f32(w), f32(xs), labels, il, ll, rand32)
+    eP, eP32 = rel_err(eng.P.download(), ref_P), rel_err(P32, ref_P)
+    print("%s B=%d T=%d wscale=%g: softmax err gpu %.2e, numpy-f32 %.2e" % (key, B, T, wscale, eP, eP32))
+    assert eP < 3e-4 and eP < max(4.0 * eP32, 2e-5), (key, "softmax", eP, eP32)
     if check_grads:
         g = eng.get_grads()
         assert set(g) == set(ref_g)
         for k in ref_g:
-            # fp32 BPTT through 200-1000 steps (x2 layers) amplifies rounding: 5e-3 of the tensor max at full size
-            assert rel_err(g[k], ref_g[k]) < 5e-3, (key, k, rel_err(g[k], ref_g[k]))
+            eg, eg32 = rel_err(g[k], ref_g[k]), rel_err(g32[k], ref_g[k])
+            print("   grad %-28s gpu %.2e, numpy-f32 %.2e" % (k, eg, eg32))
+            assert eg < 5e-3 and eg < max(4.0 * eg32, 1e-4), (key, k, eg, eg32)
     eng.close()
     return loss
 
