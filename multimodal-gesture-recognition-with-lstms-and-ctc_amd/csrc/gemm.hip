@@ -15,6 +15,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef MGR_GEMM_BK
 #define MGR_GEMM_BK 16
@@ -396,31 +397,40 @@ constexpr int SP_TM = 128, SP_SK = 16;   // tile: 128 rows x (32 WC) units x 4 g
 // TR: X is the TRANSPOSED activation copy XT[b][f][t] (row stride ldx = padded T, mgr_transpose_bt): a kept feature is then a
 // contiguous ROW of 128 time steps and the A stage is two coalesced float4 loads per thread that go to LDS as they are (the LDS
 // image is k-major already), instead of eight scattered 4-byte loads that fetch a 128-byte line for 64 useful bytes.
+// Measured and not kept (round 3, profiles/r03_gemm_sparse_probes.txt): TWO workgroups per tile with two gates each (64 instead of
+// 128 accumulator VGPRs, four workgroups per CU): 2.74 ms against 2.47 ms at F = 1000, H = 500 - occupancy is not what this kernel lacks.
 template <int WC, bool TR>
 __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_gemm_nn_sparse(const float* __restrict__ X, int ldx, const int* __restrict__ kidx,
                                                         const float* __restrict__ kval, const int* __restrict__ kcnt,
                                                         const float* __restrict__ Wp, const float* __restrict__ bp,
                                                         float* __restrict__ Z, int B, int T, int Fp, int F, int H) {
   constexpr int TM = SP_TM, TU = 32 * WC, SK = SP_SK, NT = 128 * WC;
-  constexpr int APT = TM * SK / NT;   // A elements per thread and stage: 16 k x TM rows over NT threads
-  constexpr int ARS = NT / 16;        // rows covered by one pass of the threads over the A stage
-  constexpr int BPT = SK * TU / NT;   // B elements per thread and stage
-  constexpr int BKS = NT / TU;        // k rows covered by one pass of the threads over the B stage
-  __shared__ __attribute__((aligned(16))) float As[2][SK][TM + 4];
-  __shared__ float Bs[2][SK][TU + 4];
-  __shared__ int Ls[SP_MAXF];
+  constexpr int QT = NT / 4;          // threads per k-quad of a stage: thread (quad q = tid / QT, r = tid % QT)
+  constexpr int RPT = TM / QT;        // A rows per thread (r, r + QT, ...): 2 (WC = 2) or 1 (WC = 4)
+  static_assert(TU == QT && SK == 16, "one B unit per thread and quad; 16 list positions per stage = 4 quads x 4 slots");
+  // LDS images, K-QUAD-MAJOR (round 3): list position p of a stage lives at [quad p % 4][row / unit][slot p / 4].  The MFMA
+  // k-steps are dealt so that a lane's operands of all eight steps are two whole quads: lane half lh takes position
+  // (2 lh + ks / 4) + 4 (ks % 4) in step ks, i.e. quads 2 lh and 2 lh + 1 in slot order.  Fragment reads per stage and lane:
+  // 6 ds_read_b128 instead of 24 ds_read_b32 (the k-major image needed one read per operand and step; which k meets which
+  // step is free as long as A and B agree).  Staging: B, and A from the transposed copy: a thread holds the four positions of ONE
+  // quad for its unit / its rows - four coalesced 4-byte loads, ONE ds_write_b128; A from the row-major input: a thread holds
+  // ONE position for eight rows (16 neighbouring lanes read the 16 gathered features of one row) and writes eight dwords.
+  __shared__ __attribute__((aligned(16))) float As[2][4][TM + 4][4];   // (+4 rows: the quads of a non-transposed stage land 16 banks apart)
+  __shared__ __attribute__((aligned(16))) float Bs[2][4][TU][4];
+  __shared__ unsigned short Ls[SP_MAXF];
   __shared__ float Vs[SP_MAXF];
+  static_assert(SP_MAXF <= 65536, "feature indices are kept as 16-bit values in LDS");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave / WC, wc = wave % WC;
   const int N = 4 * H;
-  const int ak = TR ? tid / (TM / 8) : tid & 15;   // A staging: this thread's k within the stage ...
-  const int ar = TR ? (tid % (TM / 8)) * 4 : tid >> 4;   // ... and its first row (TR: rows ar..ar+3 and 64+ar..; else ar, ar+ARS, ...)
-  static_assert(!TR || (NT / (TM / 8) == SK && APT == 8), "transposed A stage: 16 k x (2 float4 per thread)");
-  const int bu = tid % TU, bk = tid / TU;   // B staging: this thread's unit, its first k (then +BKS, ...)
+  const int q = tid / QT, r = tid % QT;      // B staging, and A staging from the transposed copy: quad, unit / row
+  const int ak = tid & 15, ar = tid >> 4;    // A staging from the row-major input: list position, first row (then + NT / 16, ...)
+  constexpr int ARS = NT / 16, APT = TM * SK / NT;
   const int l31 = lane & 31, lh = lane >> 5;
   const int ncol = (H + TU - 1) / TU, nrow = (T + TM - 1) / TM;
   struct Regs {
-    float a[APT], w[BPT], v[BPT];
+    float a[APT], w[4], v[4];
   };
+  static_assert(APT == RPT * 4, "both A staging forms hold TM * SK / NT elements per thread");
   // Workgroup -> tile, XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the
   // ncol workgroups that share one (sample, row tile) of X - and read it four times each, once per gate pass - are the ids
   // x, x + 8, x + 16, ...: they meet in ONE L2 instead of pulling the same rows into all eight.
@@ -429,19 +439,21 @@ __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_gemm_nn_sparse(co
     const int rt = (jj / ncol) * 8 + x;   // linear (sample, row tile)
     if (rt >= nrow * B) return;
     const int u0 = (jj % ncol) * TU, r0 = (rt % nrow) * TM, b = rt / nrow;
-    const float* Xb = TR ? X + (size_t)b * F * ldx + r0 + ar : X + (size_t)b * T * ldx;
-    const int ucl = (u0 + bu < H) ? u0 + bu : H - 1;
+    // TR: X is the transposed copy XT[b][f][t] (row stride ldx = padded T): a kept feature is a contiguous row of time steps, the
+    // 64 threads of a quad read 256 contiguous bytes of it; else X[b][t][f]: a kept feature is a column (scattered 4-byte loads)
+    const float* Xb = TR ? X + (size_t)b * F * ldx + r0 + r : X + (size_t)b * T * ldx;
+    const int ucl = (u0 + r < H) ? u0 + r : H - 1;
     f32x16 acc[4][2];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][mt][r] = 0.f;
-    int arow[APT];   // row offsets of this thread's A elements (clamped: rows >= T are computed but never stored)
+        for (int e = 0; e < 16; ++e) acc[g][mt][e] = 0.f;
+    int arow[APT];   // row-major input: element offsets of this thread's rows (clamped: rows >= T are computed but never stored)
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
-      int row = r0 + ar + ARS * i;
+      const int row = r0 + ar + ARS * i;
       arow[i] = (row < T ? row : T - 1) * ldx;   // (one sample's [T, ldx] block stays below 2^31 elements)
     }
 #pragma unroll
@@ -451,49 +463,58 @@ __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_gemm_nn_sparse(co
         const int* list = kidx + ((size_t)g * B + b) * Fp;
         const float* lval = kval + ((size_t)g * B + b) * Fp;
         for (int i = tid; i < nst * SK; i += NT) {
-          Ls[i] = list[i];
+          Ls[i] = (unsigned short)list[i];
           Vs[i] = lval[i];
         }
       }
       __syncthreads();
       const float* Wg = Wp + (size_t)g * F * H + ucl;   // (Wp: the gate-major copy [4][F][H])
-      auto fetch = [&](Regs& r, int st) {
-        if constexpr (TR) {
-          const float* xp = Xb + (size_t)Ls[st * SK + ak] * ldx;   // (rows beyond T: the copy is padded to whole row tiles)
-          const float4 v0 = *reinterpret_cast<const float4*>(xp), v1 = *reinterpret_cast<const float4*>(xp + 64);
-          r.a[0] = v0.x; r.a[1] = v0.y; r.a[2] = v0.z; r.a[3] = v0.w;
-          r.a[4] = v1.x; r.a[5] = v1.y; r.a[6] = v1.z; r.a[7] = v1.w;
-        } else {
+      auto fetch = [&](Regs& R, int st) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int p = st * SK + q + 4 * c;
+          const int f = Ls[p];
+          R.v[c] = Vs[p];
+          R.w[c] = Wg[(size_t)f * H];
+          if constexpr (TR) {
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) R.a[i * 4 + c] = Xb[(size_t)f * ldx + QT * i];
+          }
+        }
+        if constexpr (!TR) {
           const float* xp = Xb + Ls[st * SK + ak];
 #pragma unroll
-          for (int i = 0; i < APT; ++i) r.a[i] = xp[arow[i]];
-        }
-#pragma unroll
-        for (int j = 0; j < BPT; ++j) {
-          const int q = st * SK + bk + BKS * j;
-          r.w[j] = Wg[(size_t)Ls[q] * H];
-          r.v[j] = Vs[q];
+          for (int i = 0; i < APT; ++i) R.a[i] = xp[arow[i]];
         }
       };
-      auto stash = [&](const Regs& r, int buf) {
+      auto stash = [&](const Regs& R, int buf) {
         if constexpr (TR) {
-          *reinterpret_cast<float4*>(&As[buf][ak][ar]) = make_float4(r.a[0], r.a[1], r.a[2], r.a[3]);
-          *reinterpret_cast<float4*>(&As[buf][ak][64 + ar]) = make_float4(r.a[4], r.a[5], r.a[6], r.a[7]);
+#pragma unroll
+          for (int i = 0; i < RPT; ++i)
+            *reinterpret_cast<float4*>(&As[buf][q][r + QT * i][0]) = make_float4(R.a[i * 4], R.a[i * 4 + 1], R.a[i * 4 + 2], R.a[i * 4 + 3]);
         } else {
 #pragma unroll
-          for (int i = 0; i < APT; ++i) As[buf][ak][ar + ARS * i] = r.a[i];
+          for (int i = 0; i < APT; ++i) As[buf][ak & 3][ar + ARS * i][ak >> 2] = R.a[i];
         }
-#pragma unroll
-        for (int j = 0; j < BPT; ++j) Bs[buf][bk + BKS * j][bu] = r.w[j] * r.v[j];
+        *reinterpret_cast<float4*>(&Bs[buf][q][r][0]) = make_float4(R.w[0] * R.v[0], R.w[1] * R.v[1], R.w[2] * R.v[2], R.w[3] * R.v[3]);
       };
       auto mma = [&](int buf) {
+        const int ra = wr * 64 + l31, ub = wc * 32 + l31;
+        const f32x4 a00 = *reinterpret_cast<const f32x4*>(&As[buf][2 * lh][ra][0]);
+        const f32x4 a01 = *reinterpret_cast<const f32x4*>(&As[buf][2 * lh + 1][ra][0]);
+        const f32x4 a10 = *reinterpret_cast<const f32x4*>(&As[buf][2 * lh][ra + 32][0]);
+        const f32x4 a11 = *reinterpret_cast<const f32x4*>(&As[buf][2 * lh + 1][ra + 32][0]);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bs[buf][2 * lh][ub][0]);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bs[buf][2 * lh + 1][ub][0]);
 #pragma unroll
-        for (int ks = 0; ks < SK / 2; ++ks) {
-          const float a0 = As[buf][ks * 2 + lh][wr * 64 + l31];
-          const float a1 = As[buf][ks * 2 + lh][wr * 64 + 32 + l31];
-          const float bb = Bs[buf][ks * 2 + lh][wc * 32 + l31];
-          acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb, acc[g][0], 0, 0, 0);
-          acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bb, acc[g][1], 0, 0, 0);
+        for (int c = 0; c < 4; ++c) {
+          acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00[c], b0[c], acc[g][0], 0, 0, 0);
+          acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10[c], b0[c], acc[g][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01[c], b1[c], acc[g][0], 0, 0, 0);
+          acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11[c], b1[c], acc[g][1], 0, 0, 0);
         }
       };
       if (nst > 0) {
