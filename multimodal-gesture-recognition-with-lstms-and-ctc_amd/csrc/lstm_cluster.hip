@@ -340,6 +340,12 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
   const int bc = bvalid ? b : B - 1;
   const float* __restrict__ Z = jb.Z;
   const float* __restrict__ Up = jb.Up;
+  // Job fields the time loop uses, as values hipcc cannot re-derive from the kernel argument: left to itself it re-loads them from
+  // the argument segment inside the loop (s_load + s_waitcnt lgkmcnt(0), one of them right behind the barrier, on the critical path)
+  const float* Rp = jb.R;
+  float *Yp = jb.Y, *Gp = jb.G, *Csp = jb.Cs;
+  int ldr = jb.ldr, ldy = jb.ldy;
+  asm volatile("" : "+s"(Rp), "+s"(Yp), "+s"(Gp), "+s"(Csp), "+s"(ldr), "+s"(ldy));
 
   auto unit_of = [](int tile, int u) {   // hidden unit of MFMA slot (tile, unit-in-tile): see cluster_run_ks
     const int q = tile >> 2, nv = (KS - 4 * q) < 4 ? (KS - 4 * q) : 4;
@@ -386,12 +392,12 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
   // compiler to wait for - and its landing is covered by the wait of the NEXT step's gather (memory operations complete in
   // issue order).  Byte offsets of the lane within Z / R: the launcher admits only tensors below 4 GiB.
   const unsigned zvoff = (unsigned)(((size_t)bc * T * N + (size_t)unit * 4) * sizeof(float));
-  const unsigned rvoff = jb.R ? (unsigned)(((size_t)bc * T * jb.ldr + unit) * sizeof(float)) : 0u;
+  const unsigned rvoff = Rp ? (unsigned)(((size_t)bc * T * ldr + unit) * sizeof(float)) : 0u;
   auto prefetch = [&](int step) {   // (everything wave-uniform except the lane offsets)
     if (step < T) {
       const int t = reverse ? T - 1 - step : step;
       mgr_dma_b128(Z + (size_t)t * N, zvoff, zring_lds + (step & 1) * 1024);
-      if (jb.R) mgr_dma_b32(jb.R + (size_t)t * jb.ldr, rvoff, rring_lds + (step & 1) * 256);
+      if (Rp) mgr_dma_b32(Rp + (size_t)t * ldr, rvoff, rring_lds + (step & 1) * 256);
     }
   };
   prefetch(0);
@@ -469,19 +475,19 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
     float* rbuf = red + (step & 1) * (16 * 64 * 4);
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(rbuf + ((tt * 4 + wave) * 64 + lane) * 4) = acc[tt];
+    // Z_t / R_t were fetched one step ago; the only vector-memory operations this wave has issued since that may still be in
+    // flight are the one or two DMAs of step t + 1: a counted wait makes their landing explicit (in practice it never waits)
+    if (Rp)
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    const f32x4 zt = *reinterpret_cast<const f32x4*>(zring + (step & 1) * 256 + lane * 4);
+    const float rt = Rp ? rring[(step & 1) * 64 + lane] : 0.f;
     __syncthreads();
     const unsigned par = (((unsigned)step >> 1) & 1u) ^ 1u;
     unsigned hbits = par;   // cells of a padding tile: value 0 with the current parity, so that consumers can test whole blocks
     float h = 0.f, yv = 0.f;
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // Z_t / R_t were fetched one step ago; the only vector-memory operations this wave has issued since that may still be in
-    // flight are the one or two DMAs of step t + 1: a counted wait makes their landing explicit (in practice it never waits)
-    if (jb.R)
-      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    const f32x4 zt = *reinterpret_cast<const f32x4*>(zring + (step & 1) * 256 + lane * 4);
-    const float rt = jb.R ? rring[(step & 1) * 64 + lane] : 0.f;
     if (cvalid) {
       f32x4 tot = zt;   // (same summation order as cluster_run_ks: the K-split steps are bit-identical)
       const float* mine = rbuf + red_off;
@@ -503,8 +509,9 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
       yv = nonfinite ? __uint_as_float(0x7FC00000u) : h;
     }
     if (step + 1 < T) {
-      // lane (r, j) holds image word j*4 + r of the wave's 64-word segment: bring word l to lane l, one coalesced store
-      // (XCD-local clusters: a plain store into the L2 every peer's sc1 load is served from; else write-through)
+      // lane (r, j) holds image word j*4 + r of the wave's 64-word segment: bring word l to lane l, one coalesced store (storing
+      // the words from the lanes that hold them - the same 256 bytes in permuted lane order - is slower: 3.01 against 2.93 us per
+      // step at H = 500).  XCD-local clusters: a plain store into the L2 every peer's sc1 load is served from; else write-through
       const unsigned w = __builtin_amdgcn_ds_bpermute((((lane & 3) << 4) | (lane >> 2)) << 2, hbits);
       if (fast)
         __builtin_amdgcn_raw_buffer_store_b32(w, rs, ((step & 1) * IMG + (ug * 4 + wave) * 64 + lane) * 4, 0, 0);
@@ -514,9 +521,9 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
     if (cvalid && bvalid) {
       size_t row = (size_t)b * T + t;
       const float yo = yv + rt;
-      jb.Y[row * jb.ldy + unit] = yo;
-      if (jb.G) *reinterpret_cast<float4*>(jb.G + (row * H + unit) * 4) = g4;
-      if (jb.Cs) jb.Cs[row * H + unit] = c;
+      Yp[row * ldy + unit] = yo;
+      if (Gp) *reinterpret_cast<float4*>(Gp + (row * H + unit) * 4) = g4;
+      if (Csp) Csp[row * H + unit] = c;
       if (ytrow) {
         stg[(t & (KS_STG - 1)) * 64 + lane] = yo;
         // the chunk [t & ~7, +8) is complete when the walk leaves it (all lanes of the launch agree on t)
