@@ -1,5 +1,12 @@
 # Usage (on the GPU box): bash tools/profile_round.sh <tag>
-# Produces gpurun_out/<tag>_bench.json, <tag>_kernel_stats.csv, <tag>_kernel_trace.csv, <tag>_pmc_*.csv
+# The per-round evidence set, all under gpurun_out/ (copy what is to be judged into profiles/ with tools/summarize_profile.py):
+#   <tag>_bench.json                     the default bench.py line (config F = BASELINE configs[2])
+#   <tag>_kernel_stats.csv, _kernel_trace.csv   rocprofv3 --kernel-trace --stats of the same command
+#   <tag>_pmc_*.csv                      separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ counters), bench.py --steps 2 --warmup 1
+#   <tag>_cfg_<C>_bench.json, <tag>_cfg_<C>_kernel_stats.csv   the other BASELINE configurations (S, S_ref, A_ref, E): untruncated bench
+#                                        line + rocprof kernel stats each
+#   <tag>_decode.json, <tag>_decode_kernel_stats.csv          BASELINE configs[4]: tools/decode_bench.py + its kernel stats (k_beam, k_frame_argmax)
+#   <tag>_fit.txt, <tag>_dp2_host.json   fit_generator with host batches; bench.py --gpus 2 --comm host
 TAG=${1:-r01}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
@@ -17,5 +24,21 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE 
   timeout 400 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $R/gpurun_out/${TAG}_pmc_$name -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-parity > $R/gpurun_out/${TAG}_pmc_$name.log 2>&1
   cp $R/gpurun_out/${TAG}_pmc_$name/*/*_counter_collection.csv $R/gpurun_out/${TAG}_pmc_$name.csv
 done
-ls -la $R/gpurun_out | tail -20
-cat $R/gpurun_out/${TAG}_bench.json | cut -c1-600
+if [ "$2" != "quick" ]; then
+  for C in S S_ref A_ref E; do
+    cd $R && timeout 300 python bench.py --config $C --steps 10 --no-cpu > gpurun_out/${TAG}_cfg_${C}_bench.log 2>&1
+    tail -1 gpurun_out/${TAG}_cfg_${C}_bench.log > gpurun_out/${TAG}_cfg_${C}_bench.json
+    cd /tmp; rm -rf $R/gpurun_out/${TAG}_cfgprof
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_cfgprof -- python3 $R/bench.py --config $C --steps 5 --warmup 2 --no-cpu --no-parity > /dev/null 2>&1
+    cp $R/gpurun_out/${TAG}_cfgprof/*/*_kernel_stats.csv $R/gpurun_out/${TAG}_cfg_${C}_kernel_stats.csv
+  done
+  cd $R && timeout 600 python tools/decode_bench.py > gpurun_out/${TAG}_decode.json 2> gpurun_out/${TAG}_decode.err
+  cd /tmp; rm -rf $R/gpurun_out/${TAG}_cfgprof
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_cfgprof -- python3 $R/tools/decode_bench.py --cpu-n 1 --reps 1 > /dev/null 2>&1
+  cp $R/gpurun_out/${TAG}_cfgprof/*/*_kernel_stats.csv $R/gpurun_out/${TAG}_decode_kernel_stats.csv
+  rm -rf $R/gpurun_out/${TAG}_cfgprof
+  cd $R && timeout 600 python tools/fit_bench.py > gpurun_out/${TAG}_fit.txt 2>&1
+  cd $R && timeout 600 python bench.py --gpus 2 --comm host --no-cpu --no-parity 2> gpurun_out/${TAG}_dp2_host.err | tail -1 > gpurun_out/${TAG}_dp2_host.json
+fi
+ls $R/gpurun_out | grep "^${TAG}_" | tr '\n' ' '
+cut -c1-400 $R/gpurun_out/${TAG}_bench.json

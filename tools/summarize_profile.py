@@ -57,7 +57,7 @@ for k in sorted(f, key=lambda k: -f[k]["FETCH_SIZE"]):
     out.append("| %s | %d | %.1f | %.1f |" % (k, fc[k], 2 * f[k]["FETCH_SIZE"] / fc[k] / 1024,
                                            w[k]["WRITE_SIZE"] / max(1, wc[k]) / 1024))
 # per-family HBM bytes per launch for bench.py's roofline.traffic (read + write, FETCH_SIZE x2-corrected, KB -> bytes)
-FAMILY = {"k_scan_cluster_ks": "scan_fwd", "k_scan_cluster": "scan_fwd", "k_scan_cluster_ks_id": "scan_fwd", "k_scan_simple": "scan_fwd",
+FAMILY = {"k_scan_cluster_ks": "scan_fwd", "k_scan_cluster": "scan_fwd", "k_scan_simple": "scan_fwd",
           "k_scan_fwd_mfma": "scan_fwd", "k_scan_cluster_bwd": "scan_bwd", "k_scan_bwd_mfma": "scan_bwd", "k_gemm_nn": "gemm_nn",
           "k_gemm_tn": "gemm_tn", "k_gemm_nt": "gemm_nt"}
 fam_bytes, fam_n = collections.defaultdict(float), collections.Counter()
@@ -92,5 +92,32 @@ for k in sorted(s, key=lambda k: -s[k]["SQ_VALU_MFMA_BUSY_CYCLES"]):
     out.append("| %s | %d | %.3f | %.2f | %.2f | %.2f | %.3g |" % (
         k, sc[k], v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * v["GRBM_GUI_ACTIVE"] / 8), v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"],
         v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], v["SQ_ACTIVE_INST_ANY"] / v["SQ_WAVE_CYCLES"], v["SQ_LDS_BANK_CONFLICT"]))
+# ---- the other BASELINE configurations, decode, fit_generator, 2-rank host run (written by profile_round.sh without "quick")
+import glob
+extra = []
+for f in sorted(glob.glob("%s/%s_cfg_*_bench.json" % (G, tag))):
+    cfg = os.path.basename(f)[len(tag) + 5:-len("_bench.json")]
+    try:
+        d = json.loads(open(f).read())
+    except ValueError:
+        continue
+    shutil.copy(f, "profiles/%s_cfg_%s_bench.json" % (tag, cfg))
+    ks = "%s/%s_cfg_%s_kernel_stats.csv" % (G, tag, cfg)
+    top = ""
+    if os.path.exists(ks):
+        shutil.copy(ks, "profiles/%s_cfg_%s_kernel_stats.csv" % (tag, cfg))
+        rr = list(csv.DictReader(open(ks)))[:3]
+        top = "; ".join("%s %.2f ms avg x %s" % (short(r["Name"]), float(r["AverageNs"]) / 1e6, r["Calls"]) for r in rr)
+    roof = d.get("roofline") or {}
+    extra.append("| %s | %.3f | %.0f | %s %.3f | %s | %s |" % (cfg, d["ms_per_step"], d["value"], roof.get("kernel"), roof.get("frac") or 0.0,
+                                                       (d.get("ctc_loss_parity") or {}).get("rel_delta"), top))
+if extra:
+    out.append("\n## Other BASELINE configurations (bench.py --config, 10 steps; parity cases, not the headline)\n")
+    out.append("| config | ms/step | frames/s | dominant family, frac of f32-MFMA peak | CTC loss rel. delta vs fp64 oracle | top kernels (rocprofv3 --stats, 5 steps) |\n|---|---|---|---|---|---|")
+    out += extra
+for name in ("decode.json", "decode_kernel_stats.csv", "fit.txt", "dp2_host.json"):
+    f = "%s/%s_%s" % (G, tag, name)
+    if os.path.exists(f) and os.path.getsize(f) > 0:
+        shutil.copy(f, "profiles/%s_%s" % (tag, name))
 open("profiles/%s_summary.md" % tag, "w").write("\n".join(out) + "\n")
 print("\n".join(out[3:]))
