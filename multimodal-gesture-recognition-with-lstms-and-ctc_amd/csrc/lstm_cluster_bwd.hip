@@ -271,9 +271,13 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the wave ends
 }
 
-#define BW_FOREACH(X) X(8) X(16) X(32) X(64) X(100) X(128) X(300) X(500)
+#define BW_SMALL(X) X(8) X(16) X(32) X(64) X(100) X(128)
+#define BW_LARGE(X) X(300) X(500)
+#define BW_FOREACH(X) BW_SMALL(X) BW_LARGE(X)
 
-template <bool SPLIT>
+// SMALL: every job of the launch is narrow (H <= 128) - its own kernel, so that the fusion layer's BPTT (56 workgroups beside
+// the projection GEMMs of the other stream) is allocated ~100 VGPRs instead of the 256 the H = 500 instantiation needs
+template <bool SPLIT, bool SMALL = false>
 __device__ __forceinline__ void scan_cluster_bwd_body(const ClusterBwdLaunch& L, float* smem) {
   mgr_cluster_enter(L.cm);
   const int bid = blockIdx.x;
@@ -296,10 +300,19 @@ __device__ __forceinline__ void scan_cluster_bwd_body(const ClusterBwdLaunch& L,
     if (bg < 0 || bg >= jb.nbg) continue;
 #define BW_CASE(HH) \
   if (jb.H == HH) { cluster_bwd_run<HH, SPLIT>(jb, bg, ug, smem, L.cm.status, fast); return mgr_cluster_exit(L.cm); }
-    BW_FOREACH(BW_CASE)
+    if constexpr (SMALL) {
+      BW_SMALL(BW_CASE)
+    } else {
+      BW_FOREACH(BW_CASE)
+    }
 #undef BW_CASE
     return;
   }
+}
+
+__global__ __launch_bounds__(BW_WAVES * 64) void k_scan_cluster_bwd_s(ClusterBwdLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  scan_cluster_bwd_body<false, true>(L, smem);
 }
 
 __global__ __launch_bounds__(BW_WAVES * 64) void k_scan_cluster_bwd(ClusterBwdLaunch L) {
@@ -354,6 +367,7 @@ int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs)
   if (!(c->attr_done & 2u)) {
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd_s), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     c->attr_done |= 2u;
   }
   if (bwd_split(c, L, total_wgs)) {
@@ -361,7 +375,12 @@ int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs)
     hipLaunchKernelGGL(k_scan_cluster_bwd_split, dim3(total_wgs), dim3(2 * BW_WAVES * 64), lds, mgr_stream(c), L);
   } else {
     size_t lds = (size_t)BW_LDS_FLOATS * sizeof(float);
-    hipLaunchKernelGGL(k_scan_cluster_bwd, dim3(total_wgs), dim3(BW_WAVES * 64), lds, mgr_stream(c), L);
+    bool small = true;
+    for (int i = 0; i < L.njobs; ++i) small = small && L.job[i].H <= 128;
+    if (small && c->tune[13] != 1)
+      hipLaunchKernelGGL(k_scan_cluster_bwd_s, dim3(total_wgs), dim3(BW_WAVES * 64), lds, mgr_stream(c), L);
+    else
+      hipLaunchKernelGGL(k_scan_cluster_bwd, dim3(total_wgs), dim3(BW_WAVES * 64), lds, mgr_stream(c), L);
   }
   MGR_LAUNCH_CHECK();
   return 0;

@@ -57,7 +57,7 @@ for k in sorted(f, key=lambda k: -f[k]["FETCH_SIZE"]):
     out.append("| %s | %d | %.1f | %.1f |" % (k, fc[k], 2 * f[k]["FETCH_SIZE"] / fc[k] / 1024,
                                            w[k]["WRITE_SIZE"] / max(1, wc[k]) / 1024))
 # per-family HBM bytes per launch for bench.py's roofline.traffic (read + write, FETCH_SIZE x2-corrected, KB -> bytes)
-FAMILY = {"k_scan_cluster_ks": "scan_fwd", "k_scan_cluster": "scan_fwd", "k_scan_simple": "scan_fwd",
+FAMILY = {"k_scan_cluster_ks": "scan_fwd", "k_scan_cluster_ks_s": "scan_fwd", "k_scan_cluster_bwd_s": "scan_bwd", "k_scan_cluster_bwd_split": "scan_bwd", "k_scan_cluster": "scan_fwd", "k_scan_simple": "scan_fwd",
           "k_scan_fwd_mfma": "scan_fwd", "k_scan_cluster_bwd": "scan_bwd", "k_scan_bwd_mfma": "scan_bwd", "k_gemm_nn": "gemm_nn",
           "k_gemm_tn": "gemm_tn", "k_gemm_nt": "gemm_nt"}
 fam_bytes, fam_n = collections.defaultdict(float), collections.Counter()
