@@ -521,9 +521,12 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
     if (cvalid && bvalid) {
       size_t row = (size_t)b * T + t;
       const float yo = yv + rt;
-      Yp[row * ldy + unit] = yo;
-      if (Gp) *reinterpret_cast<float4*>(Gp + (row * H + unit) * 4) = g4;
-      if (Csp) Csp[row * H + unit] = c;
+      // (the pinned pointers lost their address space: name it, or hipcc emits flat_store - counted on lgkmcnt as well)
+      typedef __attribute__((address_space(1))) float gfloat;
+      typedef __attribute__((address_space(1))) f32x4 gf32x4;
+      ((gfloat*)Yp)[row * ldy + unit] = yo;
+      if (Gp) *(gf32x4*)(Gp + (row * H + unit) * 4) = (f32x4){g4.x, g4.y, g4.z, g4.w};
+      if (Csp) ((gfloat*)Csp)[row * H + unit] = c;
       if (ytrow) {
         stg[(t & (KS_STG - 1)) * 64 + lane] = yo;
         // the chunk [t & ~7, +8) is complete when the walk leaves it (all lanes of the launch agree on t)
@@ -547,363 +550,6 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
     for (int t0 = (T + KS_STG - 1) / KS_STG * KS_STG; t0 + 4 <= jb.ldt; t0 += 4)
       *reinterpret_cast<f32x4*>(ytrow + t0) = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// DUAL-CHAIN K-split step (round 3): ONE workgroup per CU serves a workgroup's worth of TWO independent recurrences - chain A
-// (the wider layer: audio, H = 500) and chain B (skeletal, H = 300) of the same direction and batch group - and alternates between
-// them, so that the hand-off of one chain (partial sums -> barrier -> cell -> publish -> the peers' gather) runs while the matrix
-// cores work on the other:
-//     MFMA A(t) [B's gather for t issued from inside]  ->  finish A(t)  ->  MFMA B(t) [A's gather for t+1 issued from inside]  ->  finish B(t)
-// With two 4-wave workgroups of different clusters per CU (the single-chain form) the same overlap is left to chance: the
-// two chains drift, 19 of 32 audio workgroups per cluster share their CU with a skeletal workgroup and publish ~1.5k cycles
-// late, and every late publish costs the consumers of that block a second fetch round (profiles/r03_scan_gather_probes.txt).
-// Here the interleave is exact by construction, a gather is issued a fixed distance behind the publish it reads (no wasted
-// rounds in the steady state) and has a whole MFMA chain to land.  One wave per SIMD: the wave owns up to 512 registers (both
-// chains' U^T fragments stay resident), and the CU keeps room for the kernels of the other stream.
-// Both chains use the K-split decomposition, unit order, exchange slots and parity words of cluster_run_ks; results are bit-identical.
-template <int KS>
-struct KsChain {
-  static constexpr int H = 4 * KS, N = 4 * H, QN = (KS + 3) / 4, IMG = QN * 256, NBW = (QN + 3) / 4;
-  static constexpr int LDS_FLOATS = 2 * 16 * 64 * 4 + 4 * KS_STG * 64 + 4 * 2 * 256 + 4 * 2 * 64;   // as KS_LDS_FLOATS, per chain
-  bool active;              // this workgroup owns tiles of the chain (unit group < workgroups of the chain's cluster)
-  int lane, wave, ug, T, reverse, nb, qb, unit, red_off, b, ldr, ldy, ldt;
-  bool cvalid, bvalid, fast, nonfinite;
-  float c;
-  float uf[4][NBW * 4];
-  u32x4 v[NBW];    // the gathered blocks the MFMA chain consumes
-  u32x4 vn[NBW];   // ... and the next step's, in flight since the OTHER chain's MFMA blocks (a second set of registers
-                   //     instead of merging several load sites into v - hipcc merges them with copies behind a vmcnt(0))
-  const float *Z, *Rp;
-  float *Yp, *Gp, *Csp, *ytrow, *red, *stg, *zring, *rring;
-  unsigned zring_lds, rring_lds, zvoff, rvoff;
-  unsigned* sticky;
-  __amdgpu_buffer_rsrc_t rs;
-  u32x4 rsv;       // the same descriptor as plain words, for the hand-issued loads
-  int nst;         // stores a wave issues behind its publish in finish() (wave-uniform): Y, gates, cell state
-
-  static __device__ __forceinline__ int unit_of(int tile, int u) {
-    const int q = tile >> 2, nv = (KS - 4 * q) < 4 ? (KS - 4 * q) : 4;
-    return 16 * q + nv * u + (tile & 3);
-  }
-
-  __device__ __forceinline__ void init(const ClusterJob& jb, const ClusterCommon& cm, int bg, int ug_, float* smem, bool fast_) {
-    const int tid = threadIdx.x;
-    lane = tid & 63;
-    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    ug = ug_;
-    fast = fast_;
-    active = ug < jb.G_;
-    sticky = cm.sticky;
-    const int j = lane & 15, uq = lane >> 4;
-    T = jb.T;
-    reverse = jb.reverse;
-    b = bg * 16 + j;
-    bvalid = b < jb.B;
-    const int bc = bvalid ? b : jb.B - 1;
-    Z = jb.Z;
-    Rp = jb.R;
-    Yp = jb.Y;
-    Gp = jb.G;
-    Csp = jb.Cs;
-    ldr = jb.ldr;
-    ldy = jb.ldy;
-    ldt = jb.ldt;
-    asm volatile("" : "+s"(Z), "+s"(Rp), "+s"(Yp), "+s"(Gp), "+s"(Csp), "+s"(ldr), "+s"(ldy));
-    qb = wave * NBW;
-    int n = QN - qb;
-    n = n < 0 ? 0 : (n > NBW ? NBW : n);
-    nb = __builtin_amdgcn_readfirstlane(active ? n : 0);
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      const int gt = ug * 4 + tt;
-#pragma unroll
-      for (int sl = 0; sl < NBW * 4; ++sl) {
-        const int s = qb * 4 + sl;
-        uf[tt][sl] = (active && gt < KS && s < KS) ? jb.Up[(size_t)unit_of(s, uq) * N + unit_of(gt, j >> 2) * 4 + (j & 3)] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NBW; ++i) v[i] = vn[i] = (u32x4){0u, 0u, 0u, 0u};
-    const int ftile = ug * 4 + uq;
-    cvalid = active && ftile < KS;
-    unit = cvalid ? unit_of(ftile, wave) : 0;
-    red_off = ((uq * 4) * 64 + wave * 16 + j) * 4;
-    red = smem;
-    stg = smem + 2 * 16 * 64 * 4 + wave * (KS_STG * 64);
-    zring = smem + 2 * 16 * 64 * 4 + 4 * KS_STG * 64 + wave * (2 * 256);
-    rring = smem + 2 * 16 * 64 * 4 + 4 * KS_STG * 64 + 4 * 2 * 256 + wave * (2 * 64);
-    zring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)zring);
-    rring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)rring);
-    ytrow = nullptr;
-    if (jb.YT && cvalid && bvalid) {
-      ytrow = jb.YT + (size_t)b * jb.ytb + (size_t)unit * jb.ldt;
-#pragma unroll
-      for (int i = 0; i < KS_STG; ++i) stg[i * 64 + lane] = 0.f;
-    }
-    float* xb = jb.xbuf + (size_t)bg * 2 * IMG;
-    rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, 2 * IMG * 4, 0x00020000);
-    const unsigned long long xa = (unsigned long long)(uintptr_t)xb;
-    rsv = (u32x4){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xa),
-                  (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(xa >> 32) & 0xFFFFu)), (unsigned)(2 * IMG * 4), 0x00020000u};
-    nst = __builtin_amdgcn_readfirstlane(__any(cvalid && bvalid) ? 1 + (Gp ? 1 : 0) + (Csp ? 1 : 0) : 0);
-    zvoff = (unsigned)(((size_t)bc * T * N + (size_t)unit * 4) * sizeof(float));
-    rvoff = Rp ? (unsigned)(((size_t)bc * T * ldr + unit) * sizeof(float)) : 0u;
-    c = 0.f;
-    nonfinite = false;
-  }
-
-  // Z_t / R_t of step `step` -> ring slot step & 1 (LDS-DMA: no register destination, nothing for hipcc to wait for)
-  __device__ __forceinline__ void prefetch(int step) {
-    if (active && step < T) {
-      const int t = reverse ? T - 1 - step : step;
-      mgr_dma_b128(Z + (size_t)t * N, zvoff, zring_lds + (step & 1) * 1024);
-      if (Rp) mgr_dma_b32(Rp + (size_t)t * ldr, rvoff, rring_lds + (step & 1) * 256);
-    }
-  }
-
-  // the image blocks of this wave's K range as published at step - 1, straight into registers
-  __device__ __forceinline__ void issue_gather(int step) {
-    const int slot = (step - 1) & 1;
-#pragma unroll
-    for (int i = 0; i < NBW; ++i)   // (blocks beyond nb - wave-uniform - re-read a valid block: they meet zero weights)
-      v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (slot * IMG + (qb + (i < nb ? i : 0)) * 256 + lane * 4) * 4, 0, 16);   // sc1
-  }
-  // The same into the second register set, HAND-ISSUED: hipcc does not see a pending load, so it places no s_waitcnt vmcnt(0) of
-  // its own at the loop heads and joins behind it (which would also wait for the acknowledgement of this wave's own stores -
-  // the publish of the other chain and its Y / gate / cell-state rows).  land() is the matching counted wait.
-  __device__ __forceinline__ void issue_gather_ahead(int step) {
-    const int slot = (step - 1) & 1;
-#pragma unroll
-    for (int i = 0; i < NBW; ++i) {
-      const unsigned off = (unsigned)((slot * IMG + (qb + (i < nb ? i : 0)) * 256 + lane * 4) * 4);
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc1" : "=v"(vn[i]) : "v"(off), "s"(rsv));
-    }
-  }
-  // wait until at most `younger` vector memory operations are outstanding (those issued behind the hand-issued gather: memory
-  // operations complete in issue order), then make the blocks current.  `younger` must not exceed the operations really issued.
-  __device__ __forceinline__ void land(int younger) {
-    if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if (younger == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (younger == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < NBW; ++i) {
-      asm volatile("" : "+v"(vn[i]));
-      v[i] = vn[i];
-    }
-  }
-  // stores finish() issues behind the other chain's hand-issued gather at `step` (publish + output rows)
-  __device__ __forceinline__ int stores_at(int step) const { return nst + (step + 1 < T ? 1 : 0); }
-
-  // every word shows the parity of epoch step - 1 (wave-uniform)
-  __device__ __forceinline__ bool gather_fresh(int step) const {
-    const unsigned par = ((((unsigned)(step - 1)) >> 1) & 1u) ^ 1u;
-    unsigned a_and = 0xFFFFFFFFu, a_or = 0u;
-#pragma unroll
-    for (int i = 0; i < NBW; ++i) {
-      a_and &= v[i].x & v[i].y & v[i].z & v[i].w;
-      a_or |= v[i].x | v[i].y | v[i].z | v[i].w;
-    }
-    return __all(par ? (a_and & 1u) != 0u : (a_or & 1u) == 0u);
-  }
-
-  template <int I>
-  __device__ __forceinline__ void mfma_block(f32x4 (&acc)[4]) const {
-    const float hv[4] = {__uint_as_float(v[I].x), __uint_as_float(v[I].y), __uint_as_float(v[I].z), __uint_as_float(v[I].w)};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[tt][I * 4 + r], hv[r], acc[tt], 0, 0, 0);
-    }
-  }
-
-  // partial sums -> barrier -> cell -> publish -> outputs.  RINGWAIT >= 0: counted wait that makes this step's Z / R landing
-  // explicit (operations issued behind that prefetch); < 0: a wait since the prefetch already covered it (the dual loop: every
-  // land() sits behind the ring prefetch of the step it precedes)
-  template <int RINGWAIT>
-  __device__ __forceinline__ void finish(int step, const f32x4 (&acc)[4]) {
-    const int t = reverse ? T - 1 - step : step;
-    const int j = lane & 15, uq = lane >> 4;
-    float* rbuf = red + (step & 1) * (16 * 64 * 4);
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(rbuf + ((tt * 4 + wave) * 64 + lane) * 4) = acc[tt];
-    if constexpr (RINGWAIT >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RINGWAIT) : "memory");
-    const f32x4 zt = *reinterpret_cast<const f32x4*>(zring + (step & 1) * 256 + lane * 4);
-    const float rt = Rp ? rring[(step & 1) * 64 + lane] : 0.f;
-    __syncthreads();
-    const unsigned par = (((unsigned)step >> 1) & 1u) ^ 1u;
-    unsigned hbits = par;
-    float h = 0.f, yv = 0.f;
-    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cvalid) {
-      f32x4 tot = zt;
-      const float* mine = rbuf + red_off;
-#pragma unroll
-      for (int src = 0; src < 4; ++src) tot += *reinterpret_cast<const f32x4*>(mine + src * 64 * 4);
-      h = mgr_cell_fwd(tot[0], tot[1], tot[2], tot[3], c, g4);
-      if (!(fabsf(h) < 2.f) && !nonfinite) {
-        __hip_atomic_fetch_or(sticky, MGR_ST_NONFINITE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        nonfinite = true;
-      }
-      if (nonfinite) {
-        h = 0.f;
-        c = 0.f;
-      }
-      hbits = (__float_as_uint(h) & ~1u) | par;
-      h = __uint_as_float(hbits);
-      yv = nonfinite ? __uint_as_float(0x7FC00000u) : h;
-    }
-    if (step + 1 < T) {
-      const unsigned w = __builtin_amdgcn_ds_bpermute((((lane & 3) << 4) | (lane >> 2)) << 2, hbits);
-      if (fast)
-        __builtin_amdgcn_raw_buffer_store_b32(w, rs, ((step & 1) * IMG + (ug * 4 + wave) * 64 + lane) * 4, 0, 0);
-      else
-        __builtin_amdgcn_raw_buffer_store_b32(w, rs, ((step & 1) * IMG + (ug * 4 + wave) * 64 + lane) * 4, 0, 16);  // sc1
-    }
-    if (cvalid && bvalid) {
-      size_t row = (size_t)b * T + t;
-      const float yo = yv + rt;
-      Yp[row * ldy + unit] = yo;
-      if (Gp) *reinterpret_cast<float4*>(Gp + (row * H + unit) * 4) = g4;
-      if (Csp) Csp[row * H + unit] = c;
-      if (ytrow) {
-        stg[(t & (KS_STG - 1)) * 64 + lane] = yo;
-        if (reverse ? (t & (KS_STG - 1)) == 0 : ((t & (KS_STG - 1)) == KS_STG - 1 || t == T - 1)) {
-          float* dst = ytrow + (t & ~(KS_STG - 1));
-          f32x4 o0, o1;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            o0[i] = stg[i * 64 + lane];
-            o1[i] = stg[(4 + i) * 64 + lane];
-          }
-          *reinterpret_cast<f32x4*>(dst) = o0;
-          *reinterpret_cast<f32x4*>(dst + 4) = o1;
-#pragma unroll
-          for (int i = 0; i < KS_STG; ++i) stg[i * 64 + lane] = 0.f;
-        }
-      }
-    }
-  }
-
-  __device__ __forceinline__ void tail() {
-    if (ytrow) {
-      for (int t0 = (T + KS_STG - 1) / KS_STG * KS_STG; t0 + 4 <= ldt; t0 += 4) *reinterpret_cast<f32x4*>(ytrow + t0) = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-  }
-};
-
-template <int KSA, int KSB>
-__device__ __forceinline__ void cluster_run_dual(const ClusterJob& ja, const ClusterJob& jbb, const ClusterCommon& cm, int bg, int ug, float* smem,
-                                                 bool fast) {
-  typedef KsChain<KSA> CA;
-  typedef KsChain<KSB> CB;
-  constexpr int PB = CA::NBW - 1, PA = CB::NBW - 1;   // where, inside a chain's MFMA blocks, the OTHER chain's gather is issued
-  CA A;
-  CB Bc;
-  A.init(ja, cm, bg, ug, smem, fast);
-  Bc.init(jbb, cm, bg, ug, smem + CA::LDS_FLOATS, fast);
-  const int T = A.T, lane = A.lane;
-  unsigned* status = cm.status;
-  A.prefetch(0);
-  Bc.prefetch(0);
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the scoreboard enters the time loop empty (cluster_run_ks)
-  bool failed = false;
-  unsigned rounds = 0;
-  auto tick = [&]() {
-    ++rounds;
-    if ((rounds & 255u) == 0) {
-      unsigned st;
-      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(st) : "v"(status) : "memory");
-      if (__builtin_amdgcn_readfirstlane(st) != 0u) failed = true;
-    }
-    if (rounds > KS_ROUND_LIMIT) {
-      failed = true;
-      if (lane == 0) __hip_atomic_store(status, MGR_ST_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
-  f32x4 acc[4];
-  auto zero = [&]() {
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  };
-  // Step 0 has no recurrent term: both chains only run their cells.  Two loops - workgroups with and without tiles of chain B.
-  // The dual loop is rotated: an iteration starts with chain A's blocks of `step` already landed and verified, so that every
-  // hand-issued gather is issued AND landed inside one iteration (nothing in flight crosses the back edge).
-  zero();
-  A.prefetch(1);
-  A.template finish<-1>(0, acc);
-  if (Bc.active) {
-    Bc.prefetch(1);
-    A.issue_gather_ahead(1);        // (T == 1: reads a slot nobody wrote - harmless, never consumed)
-    Bc.template finish<-1>(0, acc);
-#define DUAL_VERIFY(CH, STEP)                       \
-  for (;;) {                                        \
-    if (CH.gather_fresh(STEP) || failed) break;     \
-    tick();                                         \
-    CH.issue_gather_ahead(STEP);                    \
-    CH.land(0);                                     \
-  }
-    if (T > 1) {
-      A.land(Bc.stores_at(0));
-      DUAL_VERIFY(A, 1)
-    }
-    for (int step = 1; step < T; ++step) {
-      // ------------------------------------------------------------------ chain A, step `step` (landed and verified)
-      zero();
-#define DUAL_BLK_A(I)                                  \
-  if constexpr (I < CA::NBW) {                         \
-    if (I == 1) A.prefetch(step + 1);                  \
-    if (I == PB) Bc.issue_gather_ahead(step);          \
-    A.template mfma_block<(I < CA::NBW ? I : 0)>(acc); \
-  }
-      DUAL_BLK_A(0) DUAL_BLK_A(1) DUAL_BLK_A(2) DUAL_BLK_A(3) DUAL_BLK_A(4) DUAL_BLK_A(5) DUAL_BLK_A(6) DUAL_BLK_A(7)
-#undef DUAL_BLK_A
-      A.template finish<-1>(step, acc);
-      // ------------------------------------------------------------------ chain B, step `step`
-      Bc.land(A.stores_at(step));
-      DUAL_VERIFY(Bc, step)
-      zero();
-      // (the last step fetches a slot nobody reads any more: a harmless load instead of a branch around it)
-#define DUAL_BLK_B(I)                                   \
-  if constexpr (I < CB::NBW) {                          \
-    if (I == 1) Bc.prefetch(step + 1);                  \
-    if (I == PA) A.issue_gather_ahead(step + 1);        \
-    Bc.template mfma_block<(I < CB::NBW ? I : 0)>(acc); \
-  }
-      DUAL_BLK_B(0) DUAL_BLK_B(1) DUAL_BLK_B(2) DUAL_BLK_B(3) DUAL_BLK_B(4) DUAL_BLK_B(5) DUAL_BLK_B(6) DUAL_BLK_B(7)
-#undef DUAL_BLK_B
-      Bc.template finish<-1>(step, acc);
-      // ------------------------------------------------------------------ chain A, step + 1: land and verify
-      if (step + 1 < T) {
-        A.land(Bc.stores_at(step));
-        DUAL_VERIFY(A, step + 1)
-      }
-    }
-#undef DUAL_VERIFY
-  } else {
-    // no tiles of chain B here (chain B's cluster has fewer workgroups): chain A alone, as in cluster_run_ks
-    for (int step = 1; step < T; ++step) {
-      for (;;) {
-        A.issue_gather(step);
-        if (A.gather_fresh(step) || failed) break;
-        tick();
-      }
-      zero();
-#define DUAL_BLK_A(I)                                  \
-  if constexpr (I < CA::NBW) {                         \
-    if (I == 1) A.prefetch(step + 1);                  \
-    A.template mfma_block<(I < CA::NBW ? I : 0)>(acc); \
-  }
-      DUAL_BLK_A(0) DUAL_BLK_A(1) DUAL_BLK_A(2) DUAL_BLK_A(3) DUAL_BLK_A(4) DUAL_BLK_A(5) DUAL_BLK_A(6) DUAL_BLK_A(7)
-#undef DUAL_BLK_A
-      A.template finish<-1>(step, acc);
-    }
-  }
-  A.tail();
-  Bc.tail();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the wave ends
 }
 
 #define CLKS_FOREACH(X) X(125) X(75) X(32) X(25)
@@ -989,58 +635,7 @@ __global__ __launch_bounds__(256, 2) void k_scan_cluster_ks_s(ClusterLaunch L) {
   scan_cluster_ks_body<true>(L, smem);
 }
 
-// Dual-chain launch: job[2p] = chain A, job[2p + 1] = chain B of pair p (same direction, batch, T); ONE class of clusters laid out
-// with chain A's workgroup count: cluster = (pair, batch group), one workgroup per CU
-#define CLDUAL_FOREACH(X) X(125, 75) X(32, 25)
-__global__ __launch_bounds__(256, 1) void k_scan_cluster_dual(ClusterLaunch L) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  mgr_cluster_enter(L.cm);
-  const int G = L.job[0].G_, ncl = L.job[0].cls_nclusters, nbg = L.job[0].nbg;
-  const int w_ = (int)blockIdx.x;
-  int cl, ug;
-  bool same = false;
-  if (L.xcd_local) {
-    if (w_ >= (ncl + 7) / 8 * 8 * G) return;
-    same = mgr_cluster_octet(L.cm, 0, G, 0, w_, cl, ug);
-  } else {
-    cl = w_ / G;
-    ug = w_ % G;
-  }
-  if (cl >= ncl) return;
-  const int mypair = cl / nbg, bg = cl % nbg;
-#pragma unroll
-  for (int p = 0; p < MGR_MAX_SCAN_JOBS / 2; ++p) {   // (constant indices into the kernel argument: no copy of it to scratch memory)
-    if (p != mypair) continue;
-    const ClusterJob& ja = L.job[2 * p];
-    const ClusterJob& jb = L.job[2 * p + 1];
-#define CLDUAL_CASE(KA, KB) \
-  if (ja.ks == KA && jb.ks == KB) { cluster_run_dual<KA, KB>(ja, jb, L.cm, bg, ug, smem, same); return mgr_cluster_exit(L.cm); }
-    CLDUAL_FOREACH(CLDUAL_CASE)
-#undef CLDUAL_CASE
-  }
-}
-
 }  // namespace
-
-bool mgr_cluster_dual_supported(int ksa, int ksb) {
-#define CLDUAL_CASE(KA, KB) \
-  if (ksa == KA && ksb == KB) return true;
-  CLDUAL_FOREACH(CLDUAL_CASE)
-#undef CLDUAL_CASE
-  return false;
-}
-
-int mgr_cluster_dual_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs) {
-  MGR_REQUIRE(total_wgs <= c->cu_count, "dual-chain scan needs %d co-resident workgroups (one per CU) but the device has %d CUs", total_wgs, c->cu_count);
-  if (!(c->attr_done & 8u)) {
-    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_dual), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    c->attr_done |= 8u;
-  }
-  // both chains' partial sums, staging tiles and Z / R rings: 100 KiB - one workgroup per CU by its LDS request as well
-  hipLaunchKernelGGL(k_scan_cluster_dual, dim3(total_wgs), dim3(256), 2 * KS_LDS_FLOATS * sizeof(float), mgr_stream(c), L);
-  MGR_LAUNCH_CHECK();
-  return 0;
-}
 
 bool mgr_cluster_supported(int ks, int tpw) {
 #define CL_CASE(KS, TPW) \
@@ -1117,7 +712,7 @@ int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool a
     // partial-sum exchange, staging tiles of the transposed output, Z / R rings (no h image): 50 KiB, two workgroups per CU
     bool small = true;
     for (int i = 0; i < L.njobs; ++i) small = small && L.job[i].ks <= 32;
-    if (small && c->tune[13] != 2)
+    if (small)
       hipLaunchKernelGGL(k_scan_cluster_ks_s, dim3(total_wgs), dim3(256), KS_LDS_FLOATS * sizeof(float), mgr_stream(c), L);
     else
       hipLaunchKernelGGL(k_scan_cluster_ks, dim3(total_wgs), dim3(256), KS_LDS_FLOATS * sizeof(float), mgr_stream(c), L);

@@ -377,7 +377,7 @@ int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs)
     size_t lds = (size_t)BW_LDS_FLOATS * sizeof(float);
     bool small = true;
     for (int i = 0; i < L.njobs; ++i) small = small && L.job[i].H <= 128;
-    if (small && c->tune[13] != 1)
+    if (small)
       hipLaunchKernelGGL(k_scan_cluster_bwd_s, dim3(total_wgs), dim3(BW_WAVES * 64), lds, mgr_stream(c), L);
     else
       hipLaunchKernelGGL(k_scan_cluster_bwd, dim3(total_wgs), dim3(BW_WAVES * 64), lds, mgr_stream(c), L);
