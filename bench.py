@@ -161,9 +161,6 @@ def main():
     if args.scan_path:
         dev.call("mgr_tune", 0, args.scan_path)
 
-    if os.environ.get("MGR_TUNE"):
-        kv = os.environ["MGR_TUNE"].split()
-        dev.call("mgr_tune", int(kv[0]), int(kv[1]))
     comm = None
     if world > 1:
         if args.comm == "host":

@@ -279,78 +279,6 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
         xcd = tot <= 2 * c->cu_count && (size_t)tot * sizeof(unsigned) <= kScanHdrBytes - 256;
       }
     }
-    // ---- dual-chain form: the launch consists of PAIRS of recurrences of two widths (audio + skeletal of one encoder depth: same
-    // direction, batch and length pairwise) and one workgroup per CU holds a pair's worth of both - lstm_cluster.hip,
-    // cluster_run_dual.  PROBE, off unless tune key 14 = 2 (slower than two launches side by side: profiles/r03_dual_chain_probe.txt).
-    int pairA[MGR_MAX_SCAN_JOBS / 2], pairB[MGR_MAX_SCAN_JOBS / 2], npair = 0;
-    bool dual = ks_ok && c->tune[14] == 2 && P.exchange && njobs >= 2 && njobs % 2 == 0;
-    if (dual) {
-      int ha = 0, hb = 0, na = 0, nbn = 0;
-      for (int i = 0; i < njobs && dual; ++i) {
-        dual = P.cluster[i] && P.cfg[i].nw == 4 && P.cfg[i].tpw == 1 && P.G[i] > 1;
-        if (ha == 0 || jobs[i].H == ha) ha = jobs[i].H;
-        else if (hb == 0 || jobs[i].H == hb) hb = jobs[i].H;
-        else dual = false;
-      }
-      if (dual && hb > ha) std::swap(ha, hb);
-      dual = dual && hb > 0 && mgr_cluster_dual_supported(ha / 4, hb / 4);
-      for (int i = 0; i < njobs && dual; ++i) {
-        if (jobs[i].H == ha) pairA[na++] = i; else pairB[nbn++] = i;
-        dual = na <= njobs / 2 && nbn <= njobs / 2;
-      }
-      dual = dual && na == nbn;
-      npair = na;
-      for (int p = 0; p < npair && dual; ++p) {
-        const mgr_scan_job &a = jobs[pairA[p]], &b = jobs[pairB[p]];
-        dual = a.B == b.B && a.T == b.T && a.reverse == b.reverse && P.nbg[pairA[p]] == P.nbg[pairA[0]];
-      }
-      if (dual) {
-        const int ga = P.G[pairA[0]], ncl = npair * P.nbg[pairA[0]];
-        const bool oct = c->tune[3] == 0;
-        const int grid = ga * (oct ? (ncl + 7) / 8 * 8 : ncl);
-        dual = grid <= c->cu_count && (size_t)grid * sizeof(unsigned) <= kScanHdrBytes - 256;
-      }
-    }
-    if (dual) {
-      const int ga = P.G[pairA[0]], nbg0 = P.nbg[pairA[0]], ncl = npair * nbg0;
-      L.xcd_local = c->tune[3] == 0;
-      L.ksplit = 2;
-      for (int p = 0; p < npair; ++p) {
-        for (int side = 0; side < 2; ++side) {
-          const int i = side ? pairB[p] : pairA[p];
-          const mgr_scan_job& j = jobs[i];
-          ClusterJob& cj = L.job[L.njobs++];
-          const int ks = j.H / 4;
-          const size_t img = (size_t)((ks + 3) / 4) * 256;
-          cj.Z = j.Z; cj.Up = j.Up; cj.Y = j.Y; cj.R = j.R; cj.G = j.gates; cj.Cs = j.cs;
-          cj.ldy = j.ldy; cj.ldr = j.ldr; cj.B = j.B; cj.T = j.T; cj.H = j.H; cj.reverse = j.reverse;
-          cj.ks = ks; cj.tpw = 1; cj.nw = 4;
-          cj.G_ = P.G[i]; cj.nbg = nbg0;
-          cj.cls_begin = 0; cj.cls_nclusters = ncl; cj.cls_cluster0 = p * nbg0; cj.cls_rot = 0;
-          cj.YT = j.YT; cj.ytb = j.ytb; cj.ldt = j.ldt;
-          yt_done[i] = j.YT != nullptr;
-          cj.xbuf = reinterpret_cast<float*>(w);
-          w += mgr_align_up((size_t)nbg0 * 2 * img * sizeof(float), 256);
-        }
-      }
-      const int grid = ga * (L.xcd_local ? (ncl + 7) / 8 * 8 : ncl);
-      if (c->tune[2]) fprintf(stderr, "[mgr scan plan] dual-chain: %d pairs H=%d+%d, %d workgroups (one per CU), xcd_local=%d\n", npair,
-                              jobs[pairA[0]].H, jobs[pairB[0]].H, grid, L.xcd_local);
-      L.cm.status = status;
-      L.cm.sticky = mgr_status_block(c);
-      L.cm.resident = c->sticky_status + 1;
-      L.cm.total_wgs = grid;
-      // one 4-wave workgroup per CU that leaves wave slots, registers and LDS for a second (small) persistent workgroup: the
-      // ledger counts it like a two-per-CU launch (512 slots), so that the fusion layer's scan / BPTT may run beside it
-      r = mgr_persist_admit(c, grid, 4, 2, &L.cm.seq);
-      if (r) return r;
-      MGR_HIP(hipMemsetAsync(base, 0, (size_t)(w - base), mgr_stream(c)));
-      r = mgr_cluster_dual_launch(c, L, grid);
-      if (r) return r;
-      r = mgr_persist_commit(c, grid, 4, 2);
-      if (r) return r;
-      for (int i = 0; i < njobs; ++i) P.cluster[i] = true;
-    } else {
     int cb[MGR_MAX_SCAN_JOBS], cn[MGR_MAX_SCAN_JOBS], c0[MGR_MAX_SCAN_JOBS], cr[MGR_MAX_SCAN_JOBS];
     P.total = layout_classes(
         njobs, P.cluster,
@@ -403,7 +331,6 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     if (r) return r;
     r = mgr_persist_commit(c, P.total, waves, per_cu);
     if (r) return r;
-    }
   }
   for (int i = 0; i < njobs; ++i) {
     if (P.cluster[i]) continue;

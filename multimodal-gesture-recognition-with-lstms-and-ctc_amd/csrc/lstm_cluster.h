@@ -64,9 +64,6 @@ bool mgr_cluster_ks_supported(int ks);
 void mgr_cluster_geometry(const ClusterLaunch& L, bool any_exchange, int* waves, int* per_cu);
 bool mgr_cluster_uses_ks(const ClusterLaunch& L, bool any_exchange);   // the launch will run the K-split kernel (which honours ClusterJob::YT)
 int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool any_exchange);
-// dual-chain K-split launch (lstm_cluster.hip): pairs of recurrences (job[2p], job[2p + 1]) served by one workgroup per CU
-bool mgr_cluster_dual_supported(int ksa, int ksb);
-int mgr_cluster_dual_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs);
 
 // ---- backward (lstm_cluster_bwd.hip)
 struct ClusterBwdJob {

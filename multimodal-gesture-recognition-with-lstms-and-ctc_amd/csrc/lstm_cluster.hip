@@ -552,433 +552,6 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// DUAL-CHAIN K-split step (round 3): ONE 4-wave workgroup per CU serves a workgroup's worth of TWO independent recurrences - chain
-// A (the wider layer: audio, H = 500) and chain B (skeletal, H = 300) of the same direction and batch group.  The f32 MFMA issues
-// at 32 cycles per SIMD: a wave's 128 (80) MFMAs of a step of chain A (B) keep its matrix pipe busy for 4096 (2560) cycles, and
-// the hand-off of a step (partial sums -> barrier -> cell -> publish -> the peers' gather; ~2000 cycles of latencies plus the
-// exchange) leaves it idle.  Two single-chain workgroups per CU overlap the two by hardware wave interleave only by chance
-// (profiles/r03_dual_chain_probe.txt).  Here ONE instruction stream does it by construction:
-//     phase 1:  MFMA A(t)  with the hand-off of B(t - 1) issued piece by piece between its MFMA groups, B's gather for t at the end
-//     phase 2:  MFMA B(t)  with the hand-off of A(t)     ...                                            A's gather for t + 1 ...
-// Every piece of the hand-off is branch-free (stores predicated through out-of-range buffer offsets; the rare branches - a flush
-// of the transposed-output staging tile, the non-finite latch - run behind the MFMA stream), the gathers are hand-issued
-// (no compiler wait: see land()), and __builtin_amdgcn_sched_barrier pins the interleave.
-// Both chains use the K-split decomposition, unit order, exchange slots and parity words of cluster_run_ks; results are bit-identical.
-template <int KS>
-struct KsChain {
-  static constexpr int H = 4 * KS, N = 4 * H, QN = (KS + 3) / 4, IMG = QN * 256, NBW = (QN + 3) / 4, NS = NBW * 4;
-  static constexpr int LDS_FLOATS = KS_LDS_FLOATS;   // per chain, laid out as cluster_run_ks's
-  // where in the OTHER chain's stream of NS' MFMA groups the pieces go is the driver's business (DualPlan)
-  bool active;              // this workgroup owns tiles of the chain (unit group < workgroups of the chain's cluster)
-  int lane, wave, ug, T, reverse, nb, qb, unit, red_off;
-  bool cvalid, ovalid, fast, nonfinite, latched;
-  float c;
-  float uf[4][NBW * 4];
-  u32x4 v[NBW];             // the gathered blocks the MFMA chain consumes
-  const float *Z, *Rq;     // Rq: the residual input, or Z where the launch has none
-  bool has_r;
-  int ldr;
-  float *ytrow, *red, *stg, *zring, *rring;
-  unsigned zring_lds, rring_lds, zvoff, rvoff, yoff, goff, coff, ystep, pub_off;
-  unsigned* sticky;
-  __amdgpu_buffer_rsrc_t rs, rsY, rsG, rsC;
-  u32x4 rsv;                // rs as plain words, for the hand-issued loads
-  // values carried between the pieces of one hand-off
-  f32x4 part[4], zt, gv;
-  float rt, yo, hcell;
-  unsigned hbits, wpub;
-
-  static __device__ __forceinline__ int unit_of(int tile, int u) {
-    const int q = tile >> 2, nv = (KS - 4 * q) < 4 ? (KS - 4 * q) : 4;
-    return 16 * q + nv * u + (tile & 3);
-  }
-
-  __device__ __forceinline__ void init(const ClusterJob& jb, const ClusterCommon& cm, int bg, int ug_, float* smem, bool fast_) {
-    const int tid = threadIdx.x;
-    lane = tid & 63;
-    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    ug = ug_;
-    fast = fast_;
-    active = ug < jb.G_;
-    sticky = cm.sticky;
-    const int j = lane & 15, uq = lane >> 4;
-    T = jb.T;
-    reverse = jb.reverse;
-    const int b = bg * 16 + j;
-    const bool bvalid = b < jb.B;
-    const int bc = bvalid ? b : jb.B - 1;
-    Z = jb.Z;
-    has_r = jb.R != nullptr;
-    Rq = has_r ? jb.R : jb.Z;
-    ldr = has_r ? jb.ldr : 0;
-    asm volatile("" : "+s"(Z), "+s"(Rq), "+s"(ldr));
-    qb = wave * NBW;
-    int n = QN - qb;
-    n = n < 0 ? 0 : (n > NBW ? NBW : n);
-    nb = __builtin_amdgcn_readfirstlane(active ? n : 0);
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      const int gt = ug * 4 + tt;
-#pragma unroll
-      for (int sl = 0; sl < NBW * 4; ++sl) {
-        const int s = qb * 4 + sl;
-        uf[tt][sl] = (active && gt < KS && s < KS) ? jb.Up[(size_t)unit_of(s, uq) * N + unit_of(gt, j >> 2) * 4 + (j & 3)] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NBW; ++i) v[i] = (u32x4){0u, 0u, 0u, 0u};
-    const int ftile = ug * 4 + uq;
-    cvalid = active && ftile < KS;
-    ovalid = cvalid && bvalid;
-    unit = cvalid ? unit_of(ftile, wave) : 0;
-    red_off = ((uq * 4) * 64 + wave * 16 + j) * 4;
-    red = smem;
-    stg = smem + 2 * 16 * 64 * 4 + wave * (KS_STG * 64);
-    zring = smem + 2 * 16 * 64 * 4 + 4 * KS_STG * 64 + wave * (2 * 256);
-    rring = smem + 2 * 16 * 64 * 4 + 4 * KS_STG * 64 + 4 * 2 * 256 + wave * (2 * 64);
-    zring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)zring);
-    rring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)rring);
-    ytrow = nullptr;
-    if (jb.YT && ovalid) ytrow = jb.YT + (size_t)b * jb.ytb + (size_t)unit * jb.ldt;
-#pragma unroll
-    for (int i = 0; i < KS_STG; ++i) stg[i * 64 + lane] = 0.f;
-    float* xb = jb.xbuf + (size_t)bg * 2 * IMG;
-    rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, 2 * IMG * 4, 0x00020000);
-    const unsigned long long xa = (unsigned long long)(uintptr_t)xb;
-    rsv = (u32x4){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xa),
-                  (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(xa >> 32) & 0xFFFFu)), (unsigned)(2 * IMG * 4), 0x00020000u};
-    // output rows through buffer descriptors: a lane without a row, or a tensor the caller did not ask for (null: zero records),
-    // stores at an offset the range check drops - no branch around a store.  The launcher admits only outputs below 4 GiB.
-    const size_t rows = (size_t)jb.B * T;
-    rsY = __builtin_amdgcn_make_buffer_rsrc(jb.Y, 0, (int)(unsigned)(((rows - 1) * jb.ldy + H) * sizeof(float)), 0x00020000);
-    rsG = __builtin_amdgcn_make_buffer_rsrc(jb.G, 0, jb.G ? (int)(unsigned)(rows * N * sizeof(float)) : 0, 0x00020000);
-    rsC = __builtin_amdgcn_make_buffer_rsrc(jb.Cs, 0, jb.Cs ? (int)(unsigned)(rows * H * sizeof(float)) : 0, 0x00020000);
-    yoff = (unsigned)(((size_t)bc * T * jb.ldy + unit) * sizeof(float));
-    goff = (unsigned)(((size_t)bc * T * H + unit) * 4 * sizeof(float));
-    coff = (unsigned)(((size_t)bc * T * H + unit) * sizeof(float));
-    ystep = (unsigned)(jb.ldy * sizeof(float));
-    asm volatile("" : "+s"(ystep));
-    pub_off = (unsigned)(((ug * 4 + wave) * 64 + lane) * 4);
-    zvoff = (unsigned)(((size_t)bc * T * N + (size_t)unit * 4) * sizeof(float));
-    rvoff = has_r ? (unsigned)(((size_t)bc * T * ldr + unit) * sizeof(float)) : 0u;
-    c = 0.f;
-    nonfinite = latched = false;
-  }
-
-  // Z_t / R_t of step `step` -> ring slot step & 1 (LDS-DMA: no register destination, nothing for hipcc to wait for)
-  // (branch-free, for the dual stream: the chain is active, step < T, and a launch without a residual input reads Z instead -
-  //  fin2 discards the value)
-  __device__ __forceinline__ void prefetch_z(int step) {
-    const int sc = step < T ? step : T - 1;        // (past the end: the last step once more, into the slot nobody reads)
-    const int t = reverse ? T - 1 - sc : sc;
-    mgr_dma_b128(Z + (size_t)t * N, zvoff, zring_lds + (step & 1) * 1024);
-  }
-  __device__ __forceinline__ void prefetch_r(int step) {
-    const int sc = step < T ? step : T - 1;
-    const int t = reverse ? T - 1 - sc : sc;
-    mgr_dma_b32(Rq + (size_t)t * ldr, rvoff, rring_lds + (step & 1) * 256);
-  }
-  __device__ __forceinline__ void prefetch(int step) {
-    if (active && step < T) {
-      prefetch_z(step);
-      prefetch_r(step);
-    }
-  }
-
-  // the image blocks of this wave's K range as published at step - 1, straight into registers (compiler-visible form: the
-  // single-chain loop of workgroups without tiles of chain B)
-  __device__ __forceinline__ void issue_gather(int step) {
-    const int slot = (step - 1) & 1;
-#pragma unroll
-    for (int i = 0; i < NBW; ++i)   // (blocks beyond nb - wave-uniform - re-read a valid block: they meet zero weights)
-      v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (slot * IMG + (qb + (i < nb ? i : 0)) * 256 + lane * 4) * 4, 0, 16);   // sc1
-  }
-  // The same HAND-ISSUED: hipcc does not see a pending load, so it places no s_waitcnt vmcnt(0) of its own at the loop heads and
-  // joins behind it.  land() is the matching wait: the gather is the last vector memory operation of its phase.
-  __device__ __forceinline__ void issue_gather_asm(int step) {
-    const int slot = (step - 1) & 1;
-#pragma unroll
-    for (int i = 0; i < NBW; ++i) {
-      const unsigned off = (unsigned)((slot * IMG + (qb + (i < nb ? i : 0)) * 256 + lane * 4) * 4);
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc1" : "=v"(v[i]) : "v"(off), "s"(rsv));
-    }
-  }
-  // YOUNGER: vector memory operations issued behind the gather (they may stay in flight: operations complete in issue order)
-  template <int YOUNGER>
-  __device__ __forceinline__ void land() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
-#pragma unroll
-    for (int i = 0; i < NBW; ++i) asm volatile("" : "+v"(v[i]));
-  }
-
-  // every word shows the parity of epoch step - 1 (wave-uniform)
-  __device__ __forceinline__ bool gather_fresh(int step) const {
-    const unsigned par = ((((unsigned)(step - 1)) >> 1) & 1u) ^ 1u;
-    unsigned a_and = 0xFFFFFFFFu, a_or = 0u;
-#pragma unroll
-    for (int i = 0; i < NBW; ++i) {
-      a_and &= v[i].x & v[i].y & v[i].z & v[i].w;
-      a_or |= v[i].x | v[i].y | v[i].z | v[i].w;
-    }
-    return __all(par ? (a_and & 1u) != 0u : (a_or & 1u) == 0u);
-  }
-
-  // MFMA group Q of the step: k-quad Q & 3 of image block Q >> 2, all four gate tiles
-  template <int Q>
-  __device__ __forceinline__ void mfma_group(f32x4 (&acc)[4]) const {
-    constexpr int I = Q >> 2, R = Q & 3;
-    const float hv = __uint_as_float(R == 0 ? v[I].x : R == 1 ? v[I].y : R == 2 ? v[I].z : v[I].w);
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[tt][Q], hv, acc[tt], 0, 0, 0);
-  }
-
-  // ---- the hand-off of step `step` in pieces (each a few instructions; fin6 holds the rare branches)
-  __device__ __forceinline__ void fin0(int step, const f32x4 (&acc)[4]) {      // partial sums -> LDS
-    float* rbuf = red + (step & 1) * (16 * 64 * 4);
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(rbuf + ((tt * 4 + wave) * 64 + lane) * 4) = acc[tt];
-  }
-  __device__ __forceinline__ void fin1() {                                      // all four waves' partial sums are there
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-  __device__ __forceinline__ void fin2(int step) {                              // this lane's cell: 4 partial sums, Z_t, R_t
-    const float* mine = red + (step & 1) * (16 * 64 * 4) + red_off;
-#pragma unroll
-    for (int src = 0; src < 4; ++src) part[src] = *reinterpret_cast<const f32x4*>(mine + src * 64 * 4);
-    zt = *reinterpret_cast<const f32x4*>(zring + (step & 1) * 256 + lane * 4);
-    rt = rring[(step & 1) * 64 + lane];
-  }
-  __device__ __forceinline__ void fin3a() {                                     // cell
-    f32x4 tot = zt;
-#pragma unroll
-    for (int src = 0; src < 4; ++src) tot += part[src];
-    float4 g4;
-    hcell = mgr_cell_fwd(tot[0], tot[1], tot[2], tot[3], c, g4);
-    gv = (f32x4){g4.x, g4.y, g4.z, g4.w};
-  }
-  __device__ __forceinline__ void fin3b(int step) {                             // parity word, transpose for the publish
-    const unsigned par = (((unsigned)step >> 1) & 1u) ^ 1u;
-    float h = hcell;
-    if (!(fabsf(h) < 2.f)) nonfinite = true;        // (latched by fin6)
-    nonfinite = nonfinite && cvalid;
-    h = nonfinite ? 0.f : h;
-    c = nonfinite ? 0.f : c;
-    hbits = cvalid ? ((__float_as_uint(h) & ~1u) | par) : par;
-    const float yv = nonfinite ? __uint_as_float(0x7FC00000u) : __uint_as_float(hbits);
-    yo = (cvalid ? yv : 0.f) + (has_r ? rt : 0.f);
-    wpub = __builtin_amdgcn_ds_bpermute((((lane & 3) << 4) | (lane >> 2)) << 2, hbits);
-    const unsigned t = (unsigned)(reverse ? T - 1 - step : step);
-    stg[(t & (KS_STG - 1)) * 64 + lane] = yo;
-  }
-  __device__ __forceinline__ void fin4(int step) {                              // publish (not after the last step)
-    // plain store into the shared L2 (members on one XCD) or write-through: both are issued, the range check drops one
-    const unsigned off = (unsigned)((step & 1) * IMG * 4) + pub_off;
-    const bool pub = step + 1 < T;
-    asm volatile("buffer_store_dword %0, %1, %2, 0 offen" ::"v"(wpub), "v"(pub && fast ? off : 0xFFFFFFF0u), "s"(rsv) : "memory");
-    asm volatile("buffer_store_dword %0, %1, %2, 0 offen sc1" ::"v"(wpub), "v"(pub && !fast ? off : 0xFFFFFFF0u), "s"(rsv) : "memory");
-  }
-  // The three output stores are ALWAYS issued (a lane or tensor without a row: dropped by the range check), behind the gather:
-  // land<3>() leaves exactly them in flight, so nobody waits for the acknowledgement of 16 scattered partial-line writes.
-  __device__ __forceinline__ void fin5a(int step) {                             // output row
-    const unsigned t = (unsigned)(reverse ? T - 1 - step : step);
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yo), rsY, ovalid ? yoff + t * ystep : 0xFFFFFFF0u, 0, 0);
-  }
-  __device__ __forceinline__ void fin5b(int step) {                             // activated gates (training)
-    const unsigned t = (unsigned)(reverse ? T - 1 - step : step);
-    __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(gv[0]), __float_as_uint(gv[1]), __float_as_uint(gv[2]), __float_as_uint(gv[3])},
-                                           rsG, ovalid ? goff + t * (unsigned)(N * 4) : 0xFFFFFFF0u, 0, 0);
-  }
-  __device__ __forceinline__ void fin5c(int step) {                             // cell state (training)
-    const unsigned t = (unsigned)(reverse ? T - 1 - step : step);
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c), rsC, ovalid ? coff + t * (unsigned)(H * 4) : 0xFFFFFFF0u, 0, 0);
-  }
-  __device__ __forceinline__ void fin6(int step) {                              // rare: flush the staging tile, latch a non-finite state
-    const int t = reverse ? T - 1 - step : step;
-    const bool flush = reverse ? (t & (KS_STG - 1)) == 0 : ((t & (KS_STG - 1)) == KS_STG - 1 || t == T - 1);
-    const bool latch = __any(nonfinite && !latched);
-    if (__builtin_expect(flush || latch, 0)) {
-      if (flush) {
-        if (ytrow) {
-          typedef __attribute__((address_space(1))) f32x4 gf32x4;
-          float* dst = ytrow + (t & ~(KS_STG - 1));
-          f32x4 o0, o1;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            o0[i] = stg[i * 64 + lane];
-            o1[i] = stg[(4 + i) * 64 + lane];
-          }
-          *(gf32x4*)dst = o0;
-          *(gf32x4*)(dst + 4) = o1;
-        }
-#pragma unroll
-        for (int i = 0; i < KS_STG; ++i) stg[i * 64 + lane] = 0.f;
-      }
-      if (nonfinite && !latched) __hip_atomic_fetch_or(sticky, MGR_ST_NONFINITE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      latched = latched || nonfinite;
-    }
-  }
-  // the whole hand-off in one piece (first and last steps, the single-chain loop)
-  __device__ __forceinline__ void finish(int step, const f32x4 (&acc)[4]) {
-    fin0(step, acc);
-    fin1();
-    fin2(step);
-    fin3a();
-    fin3b(step);
-    fin4(step);
-    fin5a(step);
-    fin5b(step);
-    fin5c(step);
-    fin6(step);
-  }
-
-  __device__ __forceinline__ void tail() {
-    if (ytrow) {
-      typedef __attribute__((address_space(1))) f32x4 gf32x4;
-      for (int t0 = (T + KS_STG - 1) / KS_STG * KS_STG; t0 + 4 <= ldt_; t0 += 4) *(gf32x4*)(ytrow + t0) = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-  }
-  int ldt_;
-};
-
-// MFMA groups of chain X's step with the hand-off of chain Y's step `ystep` between them: Y's Z / R prefetch for ystep + 1 (it
-// has the whole next phase to land), Y's gather for `ygather` four groups before the end, and behind it the three output stores
-#define DUAL_ABL 0
-template <class CX, class CY>
-__device__ __forceinline__ void dual_phase(CX& X, CY& Y, f32x4 (&accx)[4], const f32x4 (&accy)[4], int ystep, int ygather) {
-  constexpr int NS = CX::NS;
-  // Positions of the pieces in the stream of NS groups.  An in-order wave keeps its matrix pipe busy only while it keeps issuing
-  // MFMAs: the ~100 issue cycles a group of four leaves are what a piece may use, and a wait must sit a latency's worth of
-  // MFMA groups behind what it waits for (a barrier, two LDS round trips and the cell lie between P1 and P4).
-  constexpr bool W = NS >= 16;
-  constexpr int P1 = 1, P2 = 2, PZ = 3, PR = W ? 4 : 3, P3A = W ? 5 : 4, P3B = W ? 6 : 4, P4 = W ? 8 : 5, PG = W ? NS - 4 : 6,
-                P5A = W ? NS - 3 : 7, P5B = W ? NS - 2 : 7, P5C = NS - 1;
-  static_assert(NS >= 8, "at least two image blocks per wave");
-#pragma unroll
-  for (int tt = 0; tt < 4; ++tt) accx[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  Y.fin0(ystep, accy);
-#define DUAL_GROUP(Q)                                \
-  if constexpr (Q < NS) {                            \
-    if constexpr (Q == P1 && !(DUAL_ABL & 16)) Y.fin1();                 \
-    if constexpr (Q == P1 && (DUAL_ABL & 16)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
-    if constexpr (Q == P2) Y.fin2(ystep);            \
-    if constexpr (Q == PZ && !(DUAL_ABL & 4)) Y.prefetch_z(ystep + 1);  \
-    if constexpr (Q == PR && !(DUAL_ABL & 4)) Y.prefetch_r(ystep + 1);  \
-    if constexpr (Q == P3A) Y.fin3a();               \
-    if constexpr (Q == P3B) Y.fin3b(ystep);          \
-    if constexpr (Q == P4 && !(DUAL_ABL & 2)) Y.fin4(ystep);            \
-    if constexpr (Q == PG && !(DUAL_ABL & 8)) Y.issue_gather_asm(ygather); \
-    if constexpr (Q == P5A && !(DUAL_ABL & 1)) Y.fin5a(ystep);          \
-    if constexpr (Q == P5B && !(DUAL_ABL & 64)) Y.fin5b(ystep);          \
-    if constexpr (Q == P5C && !(DUAL_ABL & 128)) Y.fin5c(ystep);          \
-    X.template mfma_group<(Q < NS ? Q : 0)>(accx);   \
-    __builtin_amdgcn_sched_barrier(0);               \
-  }
-  DUAL_GROUP(0) DUAL_GROUP(1) DUAL_GROUP(2) DUAL_GROUP(3) DUAL_GROUP(4) DUAL_GROUP(5) DUAL_GROUP(6) DUAL_GROUP(7)
-  DUAL_GROUP(8) DUAL_GROUP(9) DUAL_GROUP(10) DUAL_GROUP(11) DUAL_GROUP(12) DUAL_GROUP(13) DUAL_GROUP(14) DUAL_GROUP(15)
-  DUAL_GROUP(16) DUAL_GROUP(17) DUAL_GROUP(18) DUAL_GROUP(19) DUAL_GROUP(20) DUAL_GROUP(21) DUAL_GROUP(22) DUAL_GROUP(23)
-  DUAL_GROUP(24) DUAL_GROUP(25) DUAL_GROUP(26) DUAL_GROUP(27) DUAL_GROUP(28) DUAL_GROUP(29) DUAL_GROUP(30) DUAL_GROUP(31)
-#undef DUAL_GROUP
-  Y.fin6(ystep);
-}
-
-template <int KSA, int KSB>
-__device__ __forceinline__ void cluster_run_dual(const ClusterJob& ja, const ClusterJob& jbb, const ClusterCommon& cm, int bg, int ug, float* smem,
-                                                 bool fast) {
-  typedef KsChain<KSA> CA;
-  typedef KsChain<KSB> CB;
-  CA A;
-  CB Bc;
-  A.init(ja, cm, bg, ug, smem, fast);
-  A.ldt_ = ja.ldt;
-  Bc.init(jbb, cm, bg, ug, smem + CA::LDS_FLOATS, fast);
-  Bc.ldt_ = jbb.ldt;
-  const int T = A.T, lane = A.lane;
-  unsigned* status = cm.status;
-  A.prefetch(0);
-  Bc.prefetch(0);
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the scoreboard enters the time loop empty (cluster_run_ks)
-  bool failed = false;
-  unsigned rounds = 0;
-  auto tick = [&]() {
-    ++rounds;
-    if ((rounds & 255u) == 0) {
-      unsigned st;
-      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(st) : "v"(status) : "memory");
-      if (__builtin_amdgcn_readfirstlane(st) != 0u) failed = true;
-    }
-    if (rounds > KS_ROUND_LIMIT) {
-      failed = true;
-      if (lane == 0) __hip_atomic_store(status, MGR_ST_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
-#define DUAL_VERIFY(CH, STEP)                                   \
-  if (__builtin_expect(!(DUAL_ABL & 32) && !CH.gather_fresh(STEP), 0)) {            \
-    do {                                                        \
-      tick();                                                   \
-      CH.issue_gather_asm(STEP);                                \
-      CH.template land<0>();                                    \
-    } while (!(CH.gather_fresh(STEP) || failed));               \
-  }
-  f32x4 acca[4], accb[4];
-#pragma unroll
-  for (int tt = 0; tt < 4; ++tt) acca[tt] = accb[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // Step 0 has no recurrent term.  Chain A's is handed off here; chain B's inside A's first MFMA stream (accb = 0).
-  A.finish(0, acca);
-  if (Bc.active) {
-    A.prefetch(1);      // (the loop prefetches a chain's Z / R one phase pair ahead of its hand-off)
-    if (T > 1) {
-      A.issue_gather_asm(1);
-      A.template land<0>();
-      DUAL_VERIFY(A, 1)
-    }
-    // An iteration starts with chain A's blocks of `step` landed and verified.  Every gather is the last vector memory operation
-    // of its phase, so the wait that lands it also covers the Z / R prefetch issued in the same phase and the stores of the
-    // hand-off (issued thousands of cycles earlier).
-    for (int step = 1; step < T; ++step) {
-      dual_phase(A, Bc, acca, accb, step - 1, step);       // MFMA A(step)  |  hand-off B(step - 1), gather B(step)
-      Bc.template land<3 - (DUAL_ABL & 1) - ((DUAL_ABL >> 6) & 1) - ((DUAL_ABL >> 7) & 1)>();
-      DUAL_VERIFY(Bc, step)
-      dual_phase(Bc, A, accb, acca, step, step + 1);       // MFMA B(step)  |  hand-off A(step),     gather A(step + 1)
-      A.template land<3 - (DUAL_ABL & 1) - ((DUAL_ABL >> 6) & 1) - ((DUAL_ABL >> 7) & 1)>();
-      if (__builtin_expect(step + 1 < T, 1)) {                   // (the last gather reads a slot nobody consumes)
-        DUAL_VERIFY(A, step + 1)
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Z / R of chain B's last step (prefetched in the last phase)
-    Bc.finish(T - 1, accb);
-  } else {
-    // no tiles of chain B here (chain B's cluster has fewer workgroups): chain A alone, as in cluster_run_ks - Z / R one step
-    // ahead, issued behind the verified gather so that the wait for the NEXT gather covers them
-    A.prefetch(1);
-    for (int step = 1; step < T; ++step) {
-      for (;;) {
-        A.issue_gather(step);
-        if (A.gather_fresh(step) || failed || (DUAL_ABL & 32)) break;
-        tick();
-      }
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) acca[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#define DUAL_GROUP(Q)                                  \
-  if constexpr (Q < CA::NS) {                          \
-    if constexpr (Q == 4) A.prefetch(step + 1);        \
-    A.template mfma_group<(Q < CA::NS ? Q : 0)>(acca); \
-  }
-      DUAL_GROUP(0) DUAL_GROUP(1) DUAL_GROUP(2) DUAL_GROUP(3) DUAL_GROUP(4) DUAL_GROUP(5) DUAL_GROUP(6) DUAL_GROUP(7)
-      DUAL_GROUP(8) DUAL_GROUP(9) DUAL_GROUP(10) DUAL_GROUP(11) DUAL_GROUP(12) DUAL_GROUP(13) DUAL_GROUP(14) DUAL_GROUP(15)
-      DUAL_GROUP(16) DUAL_GROUP(17) DUAL_GROUP(18) DUAL_GROUP(19) DUAL_GROUP(20) DUAL_GROUP(21) DUAL_GROUP(22) DUAL_GROUP(23)
-      DUAL_GROUP(24) DUAL_GROUP(25) DUAL_GROUP(26) DUAL_GROUP(27) DUAL_GROUP(28) DUAL_GROUP(29) DUAL_GROUP(30) DUAL_GROUP(31)
-#undef DUAL_GROUP
-      A.finish(step, acca);
-    }
-  }
-#undef DUAL_VERIFY
-  A.tail();
-  Bc.tail();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the wave ends
-}
-
 #define CLKS_FOREACH(X) X(125) X(75) X(32) X(25)
 
 #define CL_FOREACH(X) \
@@ -1062,58 +635,7 @@ __global__ __launch_bounds__(256, 2) void k_scan_cluster_ks_s(ClusterLaunch L) {
   scan_cluster_ks_body<true>(L, smem);
 }
 
-// Dual-chain launch: job[2p] = chain A, job[2p + 1] = chain B of pair p (same direction, batch, T); ONE class of clusters laid out
-// with chain A's workgroup count: cluster = (pair, batch group), one workgroup per CU
-#define CLDUAL_FOREACH(X) X(125, 75) X(32, 25)
-__global__ __launch_bounds__(256, 1) void k_scan_cluster_dual(ClusterLaunch L) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  mgr_cluster_enter(L.cm);
-  const int G = L.job[0].G_, ncl = L.job[0].cls_nclusters, nbg = L.job[0].nbg;
-  const int w_ = (int)blockIdx.x;
-  int cl, ug;
-  bool same = false;
-  if (L.xcd_local) {
-    if (w_ >= (ncl + 7) / 8 * 8 * G) return;
-    same = mgr_cluster_octet(L.cm, 0, G, 0, w_, cl, ug);
-  } else {
-    cl = w_ / G;
-    ug = w_ % G;
-  }
-  if (cl >= ncl) return;
-  const int mypair = cl / nbg, bg = cl % nbg;
-#pragma unroll
-  for (int p = 0; p < MGR_MAX_SCAN_JOBS / 2; ++p) {   // (constant indices into the kernel argument: no copy of it to scratch memory)
-    if (p != mypair) continue;
-    const ClusterJob& ja = L.job[2 * p];
-    const ClusterJob& jb = L.job[2 * p + 1];
-#define CLDUAL_CASE(KA, KB) \
-  if (ja.ks == KA && jb.ks == KB) { cluster_run_dual<KA, KB>(ja, jb, L.cm, bg, ug, smem, same); return mgr_cluster_exit(L.cm); }
-    CLDUAL_FOREACH(CLDUAL_CASE)
-#undef CLDUAL_CASE
-  }
-}
-
 }  // namespace
-
-bool mgr_cluster_dual_supported(int ksa, int ksb) {
-#define CLDUAL_CASE(KA, KB) \
-  if (ksa == KA && ksb == KB) return true;
-  CLDUAL_FOREACH(CLDUAL_CASE)
-#undef CLDUAL_CASE
-  return false;
-}
-
-int mgr_cluster_dual_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs) {
-  MGR_REQUIRE(total_wgs <= c->cu_count, "dual-chain scan needs %d co-resident workgroups (one per CU) but the device has %d CUs", total_wgs, c->cu_count);
-  if (!(c->attr_done & 8u)) {
-    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_dual), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    c->attr_done |= 8u;
-  }
-  // both chains' partial sums, staging tiles and Z / R rings: 100 KiB - one workgroup per CU by its LDS request as well
-  hipLaunchKernelGGL(k_scan_cluster_dual, dim3(total_wgs), dim3(256), 2 * KS_LDS_FLOATS * sizeof(float), mgr_stream(c), L);
-  MGR_LAUNCH_CHECK();
-  return 0;
-}
 
 bool mgr_cluster_supported(int ks, int tpw) {
 #define CL_CASE(KS, TPW) \

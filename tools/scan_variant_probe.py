@@ -43,7 +43,6 @@ for hs in ((500,), (300,), (500, 300)):
             y = np.concatenate([keep[2 + 3 * i].download().ravel() for i in range(0, len(jobs), 2)])
             if ref is None: ref = y
             print("H=%-10s tune %-14s : %7.3f ms  %5.2f us/step  status=%d  maxdiff=%.2e" % (hs, s or "-", ms, ms * 1e3 / T, int(ws.download().view(np.uint32)[0]), float(np.abs(y - ref).max())), flush=True)
-            if len(hs) == 2 and kv: print(ws.download().view(np.uint32)[512:1024].reshape(32, 16)[:4])
         except _capi.MgrError as e:
             print("H=%-10s tune %-14s : FAILED %s" % (hs, s, e), flush=True)
         for k, v in kv:
