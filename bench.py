@@ -22,10 +22,13 @@ import os
 import sys
 import time
 
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (importing the package sizes the BLAS / OpenMP pools to the cgroup CPU quota BEFORE numpy starts them: _hostenv.py)
+import mgr_amd  # noqa: E402,F401
+from mgr_amd._hostenv import effective_cores  # noqa: E402
+import numpy as np  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 MFMA
 
@@ -202,9 +205,10 @@ def main():
         comm.barrier()
     dev.sync()
     t0 = time.perf_counter()
-    losses = []
+    losses, marks = [], [t0]
     for i in range(args.steps):
         losses.append(step(i + 1 < args.steps))
+        marks.append(time.perf_counter())     # (the moment the host has step i's loss: diagnostic only, `value` is frames / dt)
     dev.sync()
     if comm:
         comm.barrier()
@@ -267,7 +271,7 @@ def main():
         cpu = None
         if not args.no_cpu and world == 1:   # the CPU leg is reported at N=1 only (torchrun also pins OMP_NUM_THREADS=1)
             v, sec, _ = cpu_baseline(spec.to_dict(), 7, args.cpu_T, args.cpu_B)
-            cpu = {"value": round(v, 2), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+            cpu = {"value": round(v, 2), "unit": "frames/s", "cores": effective_cores(), "kind": "port",
                    "sample": "one full train step of the same network, B=%d T=%d, numpy/OpenBLAS fp32 oracle, %.1f s"
                              % (args.cpu_B, args.cpu_T, sec)}
         out = {"metric": "train frames/sec, fusion BiLSTM+CTC" if args.config == "F" else "train frames/sec, config " + args.config,
@@ -287,6 +291,9 @@ def main():
                "whole_step_frac_of_mfma_peak_executed": round(whole_ex / MFMA_F32_PEAK_TFLOPS, 5),
                "persistent_launches": {"total": n_persist.value, "serialised_by_admission": n_serial.value},
                "loss": losses[-1], "ctc_loss_parity": parity, "kernel_ms": fam,
+               "host_step_ms": {"median": round(sorted(b - a for a, b in zip(marks, marks[1:]))[len(marks) // 2 - 1 if len(marks) > 1 else 0] * 1e3, 3),
+                                "max": round(max(b - a for a, b in zip(marks, marks[1:])) * 1e3, 3),
+                                "argmax": int(max(range(len(marks) - 1), key=lambda i: marks[i + 1] - marks[i]))},
                "speedup_vs_cpu": round(value / cpu["value"], 1) if cpu else None}
         print(json.dumps(out))
     if comm:

@@ -4,7 +4,11 @@ Layout: csrc/ (HIP kernels + C ABI, built to libmgr.so), _capi.py (ctypes), engi
 keras_like.py (Keras-shaped façade), and the reference's three script packages
 (audio_network, skeletal_network, multimodal_fusion) with the same module and symbol names.
 """
-from .spec import NetworkSpec  # noqa: F401
+from ._hostenv import bound_thread_pools
+
+bound_thread_pools()   # before anything below imports numpy
+
+from .spec import NetworkSpec  # noqa: E402,F401
 
 __all__ = ["NetworkSpec"]
 __version__ = "0.1.0"

@@ -10,6 +10,8 @@
 
 constexpr int MGR_MAX_PERSIST = 8;
 
+constexpr size_t MGR_SMALL_D2H = 4096;
+
 struct mgr_ctx {
   int device;
   int cu_count;
@@ -31,6 +33,7 @@ struct mgr_ctx {
   float prof_ms[MGR_K_COUNT];
   int prof_launches[MGR_K_COUNT];
   int tune[MGR_TUNE_COUNT];
+  void* h_small_pinned;     // page-locked scratch of MGR_SMALL_D2H bytes for small blocking read-backs (mgr_d2h)
   unsigned* sticky_status;  // device words: [0] status bits of every persistent launch since the last clear, [1] resident seq,
                             // [2] optimizer updates skipped by the update gate (mgr_update_gate_*)
   unsigned* status_bound;   // mgr_scan_status_bind: the block [0] and [2] live in instead (one per engine sharing the context)

@@ -43,6 +43,7 @@ int mgr_ctx_create(int device, mgr_ctx** out) {
   for (int i = 0; i < MGR_NUM_STREAMS; ++i) MGR_HIP(hipStreamCreateWithFlags(&c->streams[i], hipStreamNonBlocking));
   for (int i = 0; i < MGR_NUM_EVENTS; ++i) MGR_HIP(hipEventCreate(&c->events[i]));
   for (int i = 0; i < 64; ++i) MGR_HIP(hipEventCreateWithFlags(&c->xev[i], hipEventDisableTiming));
+  MGR_HIP(hipHostMalloc(&c->h_small_pinned, MGR_SMALL_D2H, hipHostMallocDefault));
   MGR_HIP(hipMalloc(&c->sticky_status, 256));
   MGR_HIP(hipMemset(c->sticky_status, 0, 256));
   *out = c;
@@ -57,6 +58,7 @@ int mgr_ctx_destroy(mgr_ctx* c) {
   for (int i = 0; i < MGR_NUM_EVENTS; ++i) hipEventDestroy(c->events[i]);
   for (int i = 0; i < 64; ++i) hipEventDestroy(c->xev[i]);
   if (c->sticky_status) hipFree(c->sticky_status);
+  if (c->h_small_pinned) hipHostFree(c->h_small_pinned);
   for (int i = 0; i < MGR_MAX_PERSIST; ++i)
     if (c->persist[i].done) hipEventDestroy(c->persist[i].done);
   for (int f = 0; f < MGR_K_COUNT; ++f) {
@@ -132,6 +134,21 @@ int mgr_h2d_async(mgr_ctx* c, void* d, const void* h_pinned, size_t n) {
 
 int mgr_d2h(mgr_ctx* c, void* h, const void* d, size_t n) {
   MGR_REQUIRE(c && d && h, "null argument");
+  if (n <= MGR_SMALL_D2H && c->h_small_pinned) {
+    // Small read-backs (the loss, a status block) are what the host waits for once per step.  A copy into pageable memory
+    // waits inside the runtime, whose blocked wait now and then wakes 20-45 ms late (round 3: one step in ten of a 5 ms
+    // step); a copy into page-locked scratch is asynchronous and the host polls the stream itself.
+    hipStream_t st = mgr_stream(c);
+    MGR_HIP(hipMemcpyAsync(c->h_small_pinned, d, n, hipMemcpyDeviceToHost, st));
+    for (;;) {
+      hipError_t q = hipStreamQuery(st);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) MGR_HIP(q);
+      __builtin_ia32_pause();
+    }
+    memcpy(h, c->h_small_pinned, n);
+    return 0;
+  }
   MGR_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, mgr_stream(c)));
   MGR_HIP(hipStreamSynchronize(mgr_stream(c)));
   return 0;
@@ -146,7 +163,14 @@ int mgr_d2h_async(mgr_ctx* c, void* h_pinned, const void* d, size_t n) {
 
 int mgr_event_sync(mgr_ctx* c, int ev) {
   MGR_REQUIRE(c && ev >= 0 && ev < MGR_NUM_EVENTS, "bad event index");
-  MGR_HIP(hipEventSynchronize(c->events[ev]));
+  // polled, not hipEventSynchronize: what the host waits for here (a loss, a decoded batch) gates the next step's enqueue, and a
+  // blocked wait of the runtime wakes late now and then
+  for (;;) {
+    hipError_t q = hipEventQuery(c->events[ev]);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) MGR_HIP(q);
+    __builtin_ia32_pause();
+  }
   return 0;
 }
 
@@ -260,8 +284,30 @@ int mgr_event_elapsed_ms(mgr_ctx* c, int ev0, int ev1, float* ms) {
   return 0;
 }
 
+static int prof_reserve(mgr_ctx* c, int f, int ncap) {
+  if (ncap <= c->prof_cap[f]) return 0;
+  mgr_ctx::ProfPair* np = new mgr_ctx::ProfPair[ncap];
+  for (int i = 0; i < c->prof_cap[f]; ++i) np[i] = c->prof_pairs[f][i];
+  for (int i = c->prof_cap[f]; i < ncap; ++i) {
+    MGR_HIP(hipEventCreate(&np[i].a));
+    MGR_HIP(hipEventCreate(&np[i].b));
+  }
+  delete[] c->prof_pairs[f];
+  c->prof_pairs[f] = np;
+  c->prof_cap[f] = ncap;
+  return 0;
+}
+
 int mgr_prof_enable(mgr_ctx* c, int family_mask) {
   MGR_REQUIRE(c, "null ctx");
+  // the event pairs of the enabled families are created HERE, not at the launch that first needs them: creating a few hundred
+  // events costs tens of milliseconds, and it used to land inside whatever region the caller was timing (round 3: one step in ten
+  // of the small configurations took 20-45 ms instead of 5)
+  for (int f = 0; f < MGR_K_COUNT; ++f) {
+    if (!(family_mask & (1 << f))) continue;
+    int r = prof_reserve(c, f, 1024);
+    if (r) return r;
+  }
   c->prof_mask = family_mask;
   return 0;
 }
@@ -315,16 +361,8 @@ int mgr_prof_begin(mgr_ctx* c, int f) {
       r = prof_collect(c);
       if (r) return r;
     } else {
-      int ncap = c->prof_cap[f] ? c->prof_cap[f] * 2 : 64;
-      mgr_ctx::ProfPair* np = new mgr_ctx::ProfPair[ncap];
-      for (int i = 0; i < c->prof_cap[f]; ++i) np[i] = c->prof_pairs[f][i];
-      for (int i = c->prof_cap[f]; i < ncap; ++i) {
-        MGR_HIP(hipEventCreate(&np[i].a));
-        MGR_HIP(hipEventCreate(&np[i].b));
-      }
-      delete[] c->prof_pairs[f];
-      c->prof_pairs[f] = np;
-      c->prof_cap[f] = ncap;
+      int r = prof_reserve(c, f, c->prof_cap[f] ? c->prof_cap[f] * 2 : 64);
+      if (r) return r;
     }
   }
   MGR_HIP(hipEventRecord(c->prof_pairs[f][c->prof_n[f]].a, mgr_stream(c)));

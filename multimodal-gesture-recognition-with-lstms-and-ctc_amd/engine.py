@@ -132,6 +132,8 @@ class Engine:
         self.params = dev.zeros((max(off, 4),))
         # this engine's own scan-status block (several engines may share one Device): [0] status bits, [2] skipped updates
         self.status = dev.zeros((16,), np.uint32)
+        self.loss_host = dev.pinned((4,), np.float32)
+        self.status_host = dev.pinned((4,), np.uint32)
         if not self.inference_only:
             # the 4 floats behind the gradients carry the update-gate flag through the gradient all-reduce (apply_gradients)
             self.grads = dev.zeros((max(off, 4) + 4,))
@@ -587,23 +589,26 @@ class Engine:
         _capi.check(self.lib.mgr_lstm_scan_fwd_multi(self.dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes))
 
     # ------------------------------------------------------------------------------------------ public
-    def scan_health(self):
+    def scan_health(self, snapshot=None):
         """(status bits, optimizer updates skipped by the update gate) of THIS engine since the last clear_scan_status(),
-        read on the current stream; never raises."""
+        read on the current stream (or taken from `snapshot`, the words a step copied to the host with its loss); never raises."""
         st = (C.c_uint * 4)()
-        self._bind()
-        self.dev.call("mgr_scan_status_ex", st)
+        if snapshot is not None:
+            st[0], st[2] = int(snapshot[0]), int(snapshot[2])
+        else:
+            self._bind()
+            self.dev.call("mgr_scan_status_ex", st)
         self.updates_skipped = int(st[2])
         if st[0] & _capi.SCAN_NONFINITE:
             self.nonfinite_seen = True
         return int(st[0]), int(st[2])
 
-    def _check_scans(self, step=None):
+    def _check_scans(self, step=None, snapshot=None):
         """Raises if a persistent scan of this engine gave up on a bounded spin (its outputs are garbage; the update gate keeps
         that step's gradients away from the weights, apply_gradients); a non-finite hidden state is not an error of the
         engine - the outputs / loss carry the NaN like the reference's would - and is remembered in `nonfinite_seen` until
         clear_scan_status().  `updates_skipped` counts the optimizer steps the gate has dropped since then."""
-        bits, skipped = self.scan_health()
+        bits, skipped = self.scan_health(snapshot)
         if bits & ~_capi.SCAN_NONFINITE:
             where = "" if step is None else " (noticed with the loss of training step %d)" % step
             raise _capi.MgrError("a persistent scan gave up on a bounded spin (status %d)%s: the outputs of that pass are invalid and "
@@ -818,19 +823,17 @@ class Engine:
                                 prefetch_next=next_inputs is not None, next_inputs=next_inputs)
         return self.read_loss()
 
-    LOSS_STREAM = 6
+    LOSS_STREAM = 6   # (pipelined inference: decode / result copies)
+    EV_LOSS = 52      # the loss and the scan status of the step enqueued last have reached their page-locked host words
 
     def read_loss(self):
-        """Mean CTC loss of the step enqueued last.  Read on its own stream, which only waits for the loss kernels - not
-        for the gradient GEMMs / optimizer queued behind them - so the host can enqueue the next step early."""
+        """Mean CTC loss of the step enqueued last: waits for the event behind the loss kernels and their read-back - not for
+        the gradient GEMMs / optimizer queued behind them - so the host can enqueue the next step early."""
         dev = self.dev
-        dev.stream(self.LOSS_STREAM)
-        v = float(self.loss_mean.download()[0])
+        dev.event_sync(self.EV_LOSS)
+        v = float(self.loss_host[0])
         self._synced_step = self._step_id - 1
-        try:
-            self._check_scans(step=self._step_id - 1)   # raises if a persistent scan ever gave up: results would be garbage
-        finally:
-            dev.stream(0)
+        self._check_scans(step=self._step_id - 1, snapshot=self.status_host)   # raises if a persistent scan gave up: results would be garbage
         if self.nonfinite_seen:
             # a hidden state went NaN / Inf: in the reference every later op propagates the NaN into the loss.  Here a NaN
             # feature that input dropout happens to drop is SKIPPED by the dropout-aware kernels (no 0 x NaN), so the number
@@ -899,7 +902,13 @@ class Engine:
                  self.ws_ctc, self.ws_ctc.nbytes)
         dev.call("mgr_mean", self.loss_b, B, self.loss_mean)
         dev.record(self.EV_LAB[self._lab_slot])
-        dev.wait(self.LOSS_STREAM, 0)
+        # The loss and this engine's scan status go to page-locked host words from THIS stream, an event behind them: the host
+        # polls that event (read_loss) while the backward pass queued behind it runs.  Round 2 read them on a stream of their own
+        # that waited for stream 0 - a copy on an otherwise idle hardware queue now and then started 20-45 ms after the event
+        # it waited for (one step in ten of a 5 ms step; profiles/r03_loss_readback_stall.txt).
+        dev.d2h_async(self.loss_host, self.loss_mean)
+        dev.d2h_async(self.status_host, self.status)
+        dev.record(self.EV_LOSS)
         this_step = self._step_id
         self._step_id += 1
         self._lab_user[self._lab_slot] = this_step

@@ -6,6 +6,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+import mgr_amd  # noqa: E402,F401  (first: sizes the BLAS pools to the CPU quota before a test module imports numpy - _hostenv.py)
 
 
 def pytest_configure(config):

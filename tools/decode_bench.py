@@ -16,10 +16,10 @@ import os
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import mgr_amd  # noqa: E402,F401  (before numpy: _hostenv.py)
+import numpy as np  # noqa: E402
 
 
 def peaky_posteriors(N, T, C, seed):

@@ -4,8 +4,8 @@ skeletal alone, all four in ONE launch - under mgr_tune settings given on the co
 Prints ms per launch, us per time step, the launch's give-up word and the largest difference to the first setting."""
 import os, sys
 sys.path.insert(0, os.getcwd())
+import mgr_amd   # (before numpy: _hostenv.py)
 import numpy as np
-import mgr_amd
 from mgr_amd import _capi
 dev = _capi.Device(0); lib = dev.lib
 B, T = 64, 1900
