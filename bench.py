@@ -58,6 +58,8 @@ def _spawn_ranks(n):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        for v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):   # the ranks share the host's CPU quota
+            env[v] = str(max(1, effective_cores() // n))
         procs.append(subprocess.Popen([sys.executable] + sys.argv, env=env))
     rc = 0
     live = list(procs)
