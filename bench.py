@@ -105,7 +105,7 @@ class Watchdog:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="F")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
