@@ -1,4 +1,5 @@
 // Context, memory, streams, events, profiling brackets.
+#include <time.h>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -132,6 +133,17 @@ int mgr_h2d_async(mgr_ctx* c, void* d, const void* h_pinned, size_t n) {
   return 0;
 }
 
+// host-side polling: spin for the first ~100 us (what a short kernel takes), then sleep 50 us between polls - a rank that waits
+// 25 ms for its step's loss must not burn a core of a CPU-quota'd box (profiles/r03_host_stalls.txt) for it
+static inline void mgr_poll_backoff(unsigned spins) {
+  if (spins < 2000) {
+    __builtin_ia32_pause();
+  } else {
+    struct timespec ts = {0, 50000};
+    nanosleep(&ts, nullptr);
+  }
+}
+
 int mgr_d2h(mgr_ctx* c, void* h, const void* d, size_t n) {
   MGR_REQUIRE(c && d && h, "null argument");
   if (n <= MGR_SMALL_D2H && c->h_small_pinned) {
@@ -140,11 +152,11 @@ int mgr_d2h(mgr_ctx* c, void* h, const void* d, size_t n) {
     // step); a copy into page-locked scratch is asynchronous and the host polls the stream itself.
     hipStream_t st = mgr_stream(c);
     MGR_HIP(hipMemcpyAsync(c->h_small_pinned, d, n, hipMemcpyDeviceToHost, st));
-    for (;;) {
+    for (unsigned spins = 0;; ++spins) {
       hipError_t q = hipStreamQuery(st);
       if (q == hipSuccess) break;
       if (q != hipErrorNotReady) MGR_HIP(q);
-      __builtin_ia32_pause();
+      mgr_poll_backoff(spins);
     }
     memcpy(h, c->h_small_pinned, n);
     return 0;
@@ -165,11 +177,11 @@ int mgr_event_sync(mgr_ctx* c, int ev) {
   MGR_REQUIRE(c && ev >= 0 && ev < MGR_NUM_EVENTS, "bad event index");
   // polled, not hipEventSynchronize: what the host waits for here (a loss, a decoded batch) gates the next step's enqueue, and a
   // blocked wait of the runtime wakes late now and then
-  for (;;) {
+  for (unsigned spins = 0;; ++spins) {
     hipError_t q = hipEventQuery(c->events[ev]);
     if (q == hipSuccess) break;
     if (q != hipErrorNotReady) MGR_HIP(q);
-    __builtin_ia32_pause();
+    mgr_poll_backoff(spins);
   }
   return 0;
 }
