@@ -317,3 +317,28 @@ def test_bench_launcher_terminates_the_other_ranks_when_one_fails(tmp_path, monk
     for k in range(3):
         pid = int(open(tmp_path / ("pid%d" % k)).read())
         assert not os.path.exists("/proc/%d" % pid) or open("/proc/%d/stat" % pid).read().split()[2] == "Z", k
+
+
+def test_effective_cores_honours_the_cgroup_quota_and_import_caps_blas_pools(tmp_path):
+    """mgr_amd/_hostenv.py: the GPU boxes show 256 cores and grant 16 cores' worth of CPU time; a BLAS pool sized by the core
+    count got the whole process frozen for tens of ms (profiles/r03_host_stalls.txt).  Importing the package (before numpy
+    starts its pools) caps OPENBLAS / OMP / MKL_NUM_THREADS at the quota unless the caller has chosen a size."""
+    import subprocess
+    import sys as _sys
+    from mgr_amd import _hostenv
+    n = _hostenv.effective_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            assert n <= max(1, int(quota) // int(period))
+    except OSError:
+        pass
+    code = ("import os, sys; sys.path.insert(0, %r); import mgr_amd; "
+            "print(os.environ['OPENBLAS_NUM_THREADS'], os.environ['OMP_NUM_THREADS'])" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+    out = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == [str(n), str(n)]
+    env["OMP_NUM_THREADS"] = "3"       # a caller's own choice stays
+    out = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == [str(n), "3"]
