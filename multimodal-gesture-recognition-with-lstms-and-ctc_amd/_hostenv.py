@@ -32,6 +32,19 @@ def effective_cores():
     return n
 
 
+def local_world_size():
+    """Rank processes that share this host (torchrun's LOCAL_WORLD_SIZE, else WORLD_SIZE on a single node, else 1)."""
+    for v in ("LOCAL_WORLD_SIZE", "WORLD_SIZE"):
+        try:
+            n = int(os.environ.get(v, ""))
+            if n >= 1:
+                return n
+        except ValueError:
+            pass
+    return 1
+
+
 def bound_thread_pools():
+    n = max(1, effective_cores() // local_world_size())     # the ranks of a node share its quota
     for v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
-        os.environ.setdefault(v, str(effective_cores()))
+        os.environ.setdefault(v, str(n))

@@ -336,9 +336,14 @@ def test_effective_cores_honours_the_cgroup_quota_and_import_caps_blas_pools(tmp
         pass
     code = ("import os, sys; sys.path.insert(0, %r); import mgr_amd; "
             "print(os.environ['OPENBLAS_NUM_THREADS'], os.environ['OMP_NUM_THREADS'])" % ROOT)
-    env = {k: v for k, v in os.environ.items() if k not in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS", "LOCAL_WORLD_SIZE", "WORLD_SIZE")}
     out = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
     assert out == [str(n), str(n)]
     env["OMP_NUM_THREADS"] = "3"       # a caller's own choice stays
     out = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
     assert out == [str(n), "3"]
+    del env["OMP_NUM_THREADS"]
+    env["LOCAL_WORLD_SIZE"] = "4"      # the ranks of a node share the quota
+    out = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == [str(max(1, n // 4))] * 2
