@@ -266,7 +266,9 @@ int mgr_dense_bwd(mgr_ctx* ctx, const float* A, int lda, const float* dmask, flo
 /* ---- K6: ctc_lambda_func (multimodal_fusion/losses.py:4-15 -> K.ctc_batch_cost -> tf.nn.ctc_loss) ---- */
 /* CTC on P[:, skip:, :] with y = softmax(log(P+eps)); labels int32 [B,Lmax] padded -1; blank = C-1 in the
  * reference.  loss[B] = -log p(l|x).  dLogits[B,T,C] (may be NULL) = gscale * dloss_b/d(Dense logits),
- * zero on dropped / out-of-length frames. */
+ * zero on dropped / out-of-length frames.  Edge cases: label_len 0 is accepted (the single state is the blank, as in
+ * tf.nn.ctc_loss); a label sequence that does not fit its input length (tf.nn.ctc_loss raises "Not enough time for target
+ * transition sequence") yields loss = +inf and a ZERO gradient for that sample, the other samples of the batch are unaffected. */
 size_t mgr_ctc_ws_bytes(int B, int T, int C, int Lmax);
 int mgr_ctc_loss_grad(mgr_ctx* ctx, const float* P, const int32_t* labels, const int32_t* input_len,
                       const int32_t* label_len, int B, int T, int C, int Lmax, int skip, int blank, float eps,

@@ -259,7 +259,7 @@ def ctc_loss_grad(P, labels, input_length, label_length, skip=2, blank=None, eps
         for t in range(1, Tp):
             a = alpha[t - 1]
             a1 = np.concatenate(([NEG_INF], a[:-1]))
-            a2 = np.concatenate(([NEG_INF, NEG_INF], a[:-2]))
+            a2 = np.concatenate(([NEG_INF, NEG_INF], a[:-2]))[:S]     # (an empty label sequence has the single state "blank")
             a2 = np.where(can_skip, a2, NEG_INF)
             alpha[t] = em[t] + _lse3(a, a1, a2)
         if S > 1:
@@ -277,8 +277,8 @@ def ctc_loss_grad(P, labels, input_length, label_length, skip=2, blank=None, eps
         for t in range(Tp - 2, -1, -1):
             nb = beta[t + 1] + em[t + 1]
             n1 = np.concatenate((nb[1:], [NEG_INF]))
-            n2 = np.concatenate((nb[2:], [NEG_INF, NEG_INF]))
-            cs2 = np.concatenate((can_skip[2:], [False, False]))
+            n2 = np.concatenate((nb[2:], [NEG_INF, NEG_INF]))[:S]
+            cs2 = np.concatenate((can_skip[2:], [False, False]))[:S]
             n2 = np.where(cs2, n2, NEG_INF)
             beta[t] = _lse3(nb, n1, n2)
         ab = alpha + beta  # (Tp,S) log prob of all paths through (t,u)

@@ -221,3 +221,30 @@ def test_hard_sigmoid_vector_pins_the_oracle():
         assert np.allclose(np.clip(0.2 * x + 0.5, 0.0, 1.0), want, rtol=1e-12)          # the vector is the published formula
         np.testing.assert_allclose(kr.hard_sigmoid(x), want, rtol=k["rtol"])
         np.testing.assert_allclose(kr.hard_sigmoid(x.astype(np.float32)), want, rtol=k["rtol"])
+
+
+def test_oracle_ctc_accepts_an_empty_label_sequence():
+    """oracle/keras_ref.py::ctc_loss_grad with label_length 0 (TF's ctc_loss accepts it): closed form - sum_t log y_t(blank), and
+    the gradient matches central differences."""
+    rng = np.random.default_rng(0)
+    B, T, Cn, Lmax = 2, 12, 6, 4
+    z = rng.standard_normal((B, T, Cn))
+
+    def probs(zz):
+        e = np.exp(zz - zz.max(-1, keepdims=True))
+        return e / e.sum(-1, keepdims=True)
+    labels = -np.ones((B, Lmax))
+    labels[1, :2] = [1, 3]
+    ll, il = np.array([0, 2]), np.full(B, T - 2)
+    loss, dz = kr.ctc_loss_grad(probs(z), labels, il, ll)
+    u = probs(z)[0, 2:2 + il[0]] + 1e-8
+    assert abs(loss[0] + np.log(u[:, Cn - 1] / u.sum(-1)).sum()) < 1e-10
+    g = np.zeros((T, Cn))
+    for t in range(T):
+        for c in range(Cn):
+            zp, zm = z.copy(), z.copy()
+            zp[0, t, c] += 1e-6
+            zm[0, t, c] -= 1e-6
+            g[t, c] = (kr.ctc_loss_grad(probs(zp), labels, il, ll, need_grad=False)[0].sum()
+                       - kr.ctc_loss_grad(probs(zm), labels, il, ll, need_grad=False)[0].sum()) / 2e-6
+    assert np.abs(g - dz[0]).max() < 1e-7

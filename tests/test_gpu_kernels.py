@@ -66,6 +66,42 @@ def test_ctc_random(device, B, T, Cn, Lmax, lo, hi):
     assert np.array_equal(loss, loss2)
 
 
+def test_ctc_empty_label_sequence(device):
+    """A sample without labels (TF's ctc_loss accepts it; the reference's generator never emits one): the single state is the
+    blank, loss = - sum_t log y_t(blank) in closed form, and its neighbours in the batch are not disturbed."""
+    rng = np.random.default_rng(11)
+    for B, T, Cn, Lmax in ((3, 12, 6, 4), (2, 300, 22, 35)):
+        P = _rand_probs(rng, B, T, Cn)
+        labels = -np.ones((B, Lmax))
+        labels[1, :2] = [1, 3]
+        ll = np.zeros(B, np.int64)
+        ll[1] = 2
+        il = np.full(B, T - 2)
+        ref_loss, ref_dz = kr.ctc_loss_grad(P.astype(np.float64), labels, il, ll)
+        u = P[0, 2:2 + il[0]].astype(np.float64) + 1e-8
+        closed = -np.log(u[:, Cn - 1] / u.sum(-1)).sum()
+        assert abs(ref_loss[0] - closed) < 1e-9 * closed
+        loss, dz = _run_ctc(device, P, labels, il, ll)
+        assert np.allclose(loss, ref_loss, rtol=1e-5), (loss, ref_loss)
+        assert np.isfinite(dz).all() and rel_err(dz, ref_dz) < 5e-4
+
+
+def test_ctc_label_sequence_that_does_not_fit_its_input(device):
+    """tf.nn.ctc_loss raises for it; here (mgr.h) the sample's loss is +inf, its gradient zero, and its neighbour exact."""
+    rng = np.random.default_rng(12)
+    B, T, Cn, Lmax = 2, 6, 6, 4
+    P = _rand_probs(rng, B, T, Cn)
+    labels = -np.ones((B, Lmax))
+    labels[0, :3] = [1, 1, 1]          # needs 5 frames, has T - 2 = 4
+    labels[1, :2] = [1, 3]
+    ll, il = np.array([3, 2]), np.full(B, T - 2)
+    ref_loss, ref_dz = kr.ctc_loss_grad(P.astype(np.float64), labels, il, ll)
+    loss, dz = _run_ctc(device, P, labels, il, ll)
+    assert np.isinf(loss[0]) and loss[0] > 0 and np.isinf(ref_loss[0])
+    assert np.isfinite(dz).all() and not dz[0].any()
+    assert np.allclose(loss[1], ref_loss[1], rtol=1e-5) and rel_err(dz[1], ref_dz[1]) < 5e-4
+
+
 def test_ctc_long_T_relative(device):
     """BASELINE shape T=1900 (B reduced): loss ~ thousands, must match 1e-4 relative."""
     rng = np.random.default_rng(5)
