@@ -277,7 +277,8 @@ def test_adam_maxnorm_noise_argmax(device):
 
 
 @pytest.mark.parametrize("B,T,H,path", [(5, 9, 32, 3), (33, 6, 32, 3), (17, 7, 100, 3), (17, 7, 100, 4), (20, 5, 300, 0), (40, 7, 32, 5), (64, 6, 100, 5), (33, 5, 500, 5), (64, 4, 300, 5),
-                                        (18, 5, 500, 0), (64, 4, 500, 3), (3, 6, 12, 3)])
+                                        (18, 5, 500, 0), (64, 4, 500, 3), (3, 6, 12, 3),
+                                        (5, 1, 100, 0), (17, 2, 500, 0), (33, 1, 300, 0), (64, 2, 128, 0), (16, 1, 500, 0)])   # T = 1, 2: no / one hand-off
 def test_cluster_scan_matches_oracle(device, B, T, H, path):
     """Persistent multi-CU scan (per-step sc1 hand-off between workgroups) vs the oracle, both directions in ONE launch."""
     from mgr_amd import _capi
@@ -384,7 +385,8 @@ def test_scan_paths_agree(device, path):
         dev.call("mgr_tune", 1, 0)
 
 
-@pytest.mark.parametrize("B,T,H,path", [(5, 9, 32, 0), (33, 6, 100, 0), (17, 7, 128, 0), (20, 5, 16, 0), (3, 6, 8, 0), (19, 8, 100, 2), (18, 5, 300, 0), (33, 4, 500, 0)])
+@pytest.mark.parametrize("B,T,H,path", [(5, 9, 32, 0), (33, 6, 100, 0), (17, 7, 128, 0), (20, 5, 16, 0), (3, 6, 8, 0), (19, 8, 100, 2), (18, 5, 300, 0), (33, 4, 500, 0),
+                                        (7, 1, 100, 0), (20, 2, 500, 0), (33, 1, 300, 0), (64, 2, 128, 0)])   # T = 1, 2
 def test_bwd_multi_matches_oracle(device, B, T, H, path):
     """BPTT of both directions in one call (multi-CU clusters exchanging dz_t when path == 0) vs the oracle."""
     from mgr_amd import _capi
