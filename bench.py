@@ -57,7 +57,8 @@ def _spawn_ranks(n):
         port = s.getsockname()[1]
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
         for v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):   # the ranks share the host's CPU quota
             env[v] = str(max(1, effective_cores() // n))
         procs.append(subprocess.Popen([sys.executable] + sys.argv, env=env))
@@ -115,9 +116,10 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the next step's frozen-encoder pass")
     ap.add_argument("--scan-path", type=int, default=0, help="0 auto, 3/4 clusters of 4/8 tiles per workgroup")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--exclusive-narrow", action="store_true", help="narrow trainable layer: single-CU scans on CUs of their own")
     ap.add_argument("--no-transposed", action="store_true", help="dropout-aware projections gather columns of the row-major input")
-    ap.add_argument("--cpu-T", type=int, default=400)
-    ap.add_argument("--cpu-B", type=int, default=64)
+    ap.add_argument("--cpu-T", type=int, default=0, help="T of the CPU leg's sample; 0 (default) = the configuration's own T: the full step")
+    ap.add_argument("--cpu-B", type=int, default=0, help="batch of the CPU leg's sample; 0 (default) = the configuration's own")
     ap.add_argument("--comm", choices=("rccl", "host"), default="rccl",
                     help="gradient all-reduce: RCCL over xGMI (one GPU per rank) or summed on the host (ranks may share a GPU)")
     ap.add_argument("--rccl-channels", type=int, default=8,
@@ -165,6 +167,9 @@ def main():
         dev.call("mgr_tune", 2, 1)
     if args.scan_path:
         dev.call("mgr_tune", 0, args.scan_path)
+    if args.exclusive_narrow:
+        dev.call("mgr_tune", 0, 6)
+        dev.call("mgr_tune", 12, 1)
 
     comm = None
     if world > 1:
@@ -179,7 +184,7 @@ def main():
 
     from mgr_amd.engine import Schedule
     eng = Engine(spec, B, T, Lmax, device=dev, seed=1000 + rank, comm=comm, world=world,
-                 schedule=Schedule(transposed_inputs=not args.no_transposed))
+                 schedule=Schedule(transposed_inputs=not args.no_transposed, exclusive_narrow_scans=args.exclusive_narrow))
     eng.set_weights(synthetic_weights(spec, 20131900 + 3))
     xs, labels, il, ll = synthetic_arrays(spec, B, T, Lmax, 20131900 + 3 + 17 * rank)
     eng._upload_inputs(xs, None, True)
@@ -193,7 +198,9 @@ def main():
         # not prefetch, so exactly K complete steps - K encoder passes, K fusion passes - lie inside the timed region.
         eng.enqueue_train_step(None, None, None, None, rand=None, apply_update=True, upload=False,
                                prefetch_next=prefetch and not args.no_pipeline)
-        loss = eng.read_loss()
+        # (world > 1: the global loss arrives with the gradient all-reduce at the end of the step; the loop paces itself on the
+        # rank's own loss - one read-back per step, like N = 1 - and the line reports the global loss of the last step)
+        loss = eng.read_loss(local=True)
         dog.beat("step %d" % (eng._step_id - 1))
         if eng._step_id - 1 == args.stall_at_step:
             time.sleep(1e6)
@@ -215,6 +222,8 @@ def main():
     if comm:
         comm.barrier()
     dt = time.perf_counter() - t0
+    if comm and world > 1:
+        losses[-1] = eng.read_global_loss()     # mean over the global batch, identical on every rank
     if comm:
         dt = comm.allreduce_max_scalar(dt)
     dog.beat("timed region done")
@@ -272,10 +281,13 @@ def main():
             parity = loss_parity(spec, dev, T)
         cpu = None
         if not args.no_cpu and world == 1:   # the CPU leg is reported at N=1 only (torchrun also pins OMP_NUM_THREADS=1)
-            v, sec, _ = cpu_baseline(spec.to_dict(), 7, args.cpu_T, args.cpu_B)
+            cpu_T = args.cpu_T or T
+            cpu_B = args.cpu_B or B
+            v, sec, _ = cpu_baseline(spec.to_dict(), 7, cpu_T, cpu_B)
+            full = cpu_T == T and cpu_B == B
             cpu = {"value": round(v, 2), "unit": "frames/s", "cores": effective_cores(), "kind": "port",
-                   "sample": "one full train step of the same network, B=%d T=%d, numpy/OpenBLAS fp32 oracle, %.1f s"
-                             % (args.cpu_B, args.cpu_T, sec)}
+                   "sample": "%s: one train step of the same network, B=%d T=%d, numpy/OpenBLAS fp32 oracle, %.1f s"
+                             % ("full" if full else "sub-sample (--cpu-T / --cpu-B)", cpu_B, cpu_T, sec)}
         out = {"metric": "train frames/sec, fusion BiLSTM+CTC" if args.config == "F" else "train frames/sec, config " + args.config,
                "value": round(value, 1), "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),

@@ -20,7 +20,7 @@ class DataGenerator(BaseDataGenerator):
 
     def __init__(self, minibatch_size, numfeats, maxlen, nb_classes, dataset, val_split=0.2,
                  absolute_max_sequence_len=150, data_root='../data', synthetic_files=None, seed=20131901,
-                 word_level=True):
+                 word_level=True, rank=0, world=1):
         self.numfeats = numfeats
         self.word_level = word_level
         names = {'train': ('train_audio', 'training_oov.csv'), 'val': ('val_audio', 'validation.csv'),
@@ -33,7 +33,7 @@ class DataGenerator(BaseDataGenerator):
             # label rows are gesture classes 0..20; the word expansion below maps them into the 44-word space
             store = SyntheticStore(n, {'audio': (numfeats, 3.0)}, maxlen, 22 if word_level else nb_classes, seed=seed,
                                    lmax=20)
-        self._setup(minibatch_size, maxlen, nb_classes, dataset, val_split, absolute_max_sequence_len, store)
+        self._setup(minibatch_size, maxlen, nb_classes, dataset, val_split, absolute_max_sequence_len, store, rank=rank, world=world)
 
     def sent_2_words(self, lab_seq):
         """Gesture-class label sequence -> word-level label sequence."""

@@ -10,7 +10,7 @@
 
 int mgr_scan_fwd_simple(mgr_ctx*, const float*, const float*, float*, int, const float*, int, float*, float*, int, int, int, int);
 int mgr_scan_bwd_simple(mgr_ctx*, const float*, int, const float*, const float*, const float*, float*, int, int, int, int);
-int mgr_scan_bwd_mfma(mgr_ctx*, const float*, int, const float*, const float*, const float*, float*, int, int, int, int);
+int mgr_scan_bwd_mfma_multi(mgr_ctx*, int, const mgr_scan_bwd_job*, int);
 
 namespace {
 
@@ -76,6 +76,7 @@ void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
       if (path == 3 && cur[k] != 0) feas = false;
       if (path == 4 && cur[k] != 1) feas = false;
       if (path == 2 && (f.nw * f.tpw < ks)) feas = false;  // force single-CU (no exchange)
+      if (path == 6 && j.H <= 128 && (f.nw * f.tpw < ks)) feas = false;  // narrow layers only: single-CU, wide ones as planned
       int tiles = f.nw * f.tpw;
       int G = (ks + tiles - 1) / tiles;
       if (G > 64) feas = false;
@@ -323,14 +324,24 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     L.cm.sticky = mgr_status_block(c);
     L.cm.resident = c->sticky_status + 1;
     L.cm.total_wgs = P.total;
-    r = mgr_persist_admit(c, P.total, waves, per_cu, &L.cm.seq);
-    if (r) return r;
+    // (a launch without an exchange spins on nobody: it needs no place in the ledger and is never ordered behind one)
+    if (P.exchange) {
+      r = mgr_persist_admit(c, P.total, waves, per_cu, &L.cm.seq);
+      if (r) return r;
+    } else if (c->tune[12]) {
+      // tune key 12: workgroups of a launch without an exchange take a CU of their own (LDS request) and the launch gets a sequence
+      // number, so that another stream can wait until it is resident (mgr_stream_wait_last_resident)
+      L.own_cu = 1;
+      L.cm.seq = ++c->persist_seq;
+    }
     // exchange slots + status must be zero at every launch (epochs count from 1 within the call)
     MGR_HIP(hipMemsetAsync(base, 0, (size_t)(w - base), mgr_stream(c)));
     r = mgr_cluster_launch(c, L, P.total, P.exchange);
     if (r) return r;
-    r = mgr_persist_commit(c, P.total, waves, per_cu);
-    if (r) return r;
+    if (P.exchange) {
+      r = mgr_persist_commit(c, P.total, waves, per_cu);
+      if (r) return r;
+    }
   }
   for (int i = 0; i < njobs; ++i) {
     if (P.cluster[i]) continue;
@@ -385,7 +396,7 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
     nbg[i] = (j.B + 15) / 16;
     // (the cluster kernel addresses the saved state with 32-bit byte offsets per lane: LDS-DMA prefetch)
     const bool small = (size_t)j.B * j.T * j.H * 16 < ((size_t)1 << 32) && (size_t)j.B * j.T * j.lddy * 4 < ((size_t)1 << 32);
-    use_cluster[i] = (path == 0 || path == 3) && mgr_cluster_bwd_supported(j.H) && small;
+    use_cluster[i] = (path == 0 || path == 3 || (path == 6 && j.H > 128)) && mgr_cluster_bwd_supported(j.H) && small;
     if (use_cluster[i]) total += ((j.H + 15) / 16) * nbg[i];
   }
   if (total + 8 * njobs > 2 * c->cu_count)
@@ -431,11 +442,29 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
     r = mgr_persist_commit(c, grid, waves, per_cu);
     if (r) return r;
   }
+  // the single-CU kernel takes every job that is left in ONE launch when they share a shape (the two directions of a layer)
+  bool mfma_done = false;
+  {
+    int rest = 0;
+    bool same = true;
+    mgr_scan_bwd_job left[MGR_MAX_SCAN_JOBS];
+    for (int i = 0; i < njobs; ++i) {
+      if (use_cluster[i]) continue;
+      left[rest] = jobs[i];
+      same = same && jobs[i].B == left[0].B && jobs[i].T == left[0].T && jobs[i].H == left[0].H && jobs[i].lddy == left[0].lddy;
+      ++rest;
+    }
+    if (rest > 0 && same && path != 1) {
+      r = mgr_scan_bwd_mfma_multi(c, rest, left, c->tune[12]);
+      if (r < 0) return r;
+      mfma_done = r == 1;
+    }
+  }
   for (int i = 0; i < njobs; ++i) {
-    if (use_cluster[i]) continue;
+    if (use_cluster[i] || mfma_done) continue;
     const mgr_scan_bwd_job& j = jobs[i];
     r = 0;
-    if (path != 1) r = mgr_scan_bwd_mfma(c, j.dY, j.lddy, j.gates, j.cs, j.Up, j.dZ, j.B, j.T, j.H, j.reverse);
+    if (path != 1) r = mgr_scan_bwd_mfma_multi(c, 1, &j, 0);
     if (r == 0) {
       float* UpT = reinterpret_cast<float*>(wj[i]);
       r = mgr_transpose(c, j.Up, UpT, j.H, 4 * j.H);
@@ -543,6 +572,13 @@ extern "C" {
 int mgr_stream_wait_next_resident(mgr_ctx* c, int timeout_us) {
   MGR_REQUIRE(c && timeout_us >= 0 && timeout_us <= 100000, "timeout_us must be in [0, 100000]");
   hipLaunchKernelGGL(k_wait_resident, dim3(1), dim3(1), 0, mgr_stream(c), c->sticky_status + 1, c->persist_seq + 1, (unsigned)timeout_us);
+  MGR_LAUNCH_CHECK();
+  return 0;
+}
+
+int mgr_stream_wait_last_resident(mgr_ctx* c, int timeout_us) {
+  MGR_REQUIRE(c && timeout_us >= 0 && timeout_us <= 100000, "timeout_us must be in [0, 100000]");
+  hipLaunchKernelGGL(k_wait_resident, dim3(1), dim3(1), 0, mgr_stream(c), c->sticky_status + 1, c->persist_seq, (unsigned)timeout_us);
   MGR_LAUNCH_CHECK();
   return 0;
 }

@@ -207,7 +207,12 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
     if (computer) {
       // the saved state of iterations k and k + 1 was fetched one and two steps ago; the only DMAs of this wave that may still be
       // in flight are the three of iteration k + 2: a counted wait makes the landing explicit (in practice it never waits)
-      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      // (the last two iterations issue no prefetch: the three newest operations are then older DMAs / stores, not those of
+      // iteration k + 2 - wait for everything there; two steps of 1900)
+      if (k + 2 < T)
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (computer && uvalid) {
       const float* ru = ring + (k % 3) * (BW_RING_FLOATS / 3);

@@ -3,6 +3,7 @@
 // It mirrors the forward kernel (lstm_cluster.hip) with  D[unit, sample] += U[unit, gate-col] * dz^T[gate-col, sample]:
 // A operand = U rows (stationary in VGPRs), B operand = dz_t from a double-buffered LDS image
 // [gate-col/16][gate][sample][unit%4], C/D = dh_rec for 4 consecutive units of the lane's sample.
+#include "lstm_cluster.h"
 #include "lstm_common.h"
 
 namespace {
@@ -11,11 +12,23 @@ constexpr int NW = 8;  // waves per workgroup (2 per SIMD)
 
 // Backward.  H units -> MTB = ceil(H/16) tiles of 16 units, one tile per wave; K = 4H packed gate columns,
 // i.e. H MFMA k-steps (k-step s = unit s, kk = gate).
+struct BwdMfmaJobs {
+  const float* dY[MGR_MAX_SCAN_JOBS];
+  const float* G[MGR_MAX_SCAN_JOBS];
+  const float* Cs[MGR_MAX_SCAN_JOBS];
+  const float* Up[MGR_MAX_SCAN_JOBS];
+  float* dZ[MGR_MAX_SCAN_JOBS];
+  int reverse[MGR_MAX_SCAN_JOBS];
+};
+
 template <int H>
-__global__ __launch_bounds__(NW * 64) void k_scan_bwd_mfma(const float* __restrict__ dY, int lddy,
-                                                           const float* __restrict__ G, const float* __restrict__ Cs,
-                                                           const float* __restrict__ Up, float* __restrict__ dZ, int B,
-                                                           int T, int reverse) {
+__global__ __launch_bounds__(NW * 64) void k_scan_bwd_mfma(BwdMfmaJobs J, int lddy, int B, int T) {
+  const float* __restrict__ dY = J.dY[blockIdx.y];
+  const float* __restrict__ G = J.G[blockIdx.y];
+  const float* __restrict__ Cs = J.Cs[blockIdx.y];
+  const float* __restrict__ Up = J.Up[blockIdx.y];
+  float* __restrict__ dZ = J.dZ[blockIdx.y];
+  const int reverse = J.reverse[blockIdx.y];
   constexpr int N = 4 * H;
   constexpr int MTB = (H + 15) / 16;
   constexpr int QN = (H + 3) / 4;
@@ -134,14 +147,23 @@ __global__ __launch_bounds__(NW * 64) void k_scan_bwd_mfma(const float* __restri
 
 }  // namespace
 
-// returns 1 if launched, 0 if the shape has no instantiation, <0 on error
-int mgr_scan_bwd_mfma(mgr_ctx* c, const float* dY, int lddy, const float* G, const float* Cs, const float* Up, float* dZ, int B,
-                      int T, int H, int reverse) {
-  int grid = (B + 15) / 16;
+// returns 1 if launched, 0 if the shape has no instantiation, <0 on error.  All jobs (same H, B, T, lddy) go out as ONE launch
+// (blockIdx.y = job); own_cu: request so much LDS that nothing else with an LDS footprint shares the workgroup's CU
+int mgr_scan_bwd_mfma_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs, int own_cu) {
+  BwdMfmaJobs J;
+  memset(&J, 0, sizeof(J));
+  const int B = jobs[0].B, T = jobs[0].T, H = jobs[0].H, lddy = jobs[0].lddy;
+  for (int i = 0; i < njobs; ++i) {
+    J.dY[i] = jobs[i].dY; J.G[i] = jobs[i].gates; J.Cs[i] = jobs[i].cs; J.Up[i] = jobs[i].Up; J.dZ[i] = jobs[i].dZ;
+    J.reverse[i] = jobs[i].reverse;
+  }
+  dim3 grid((B + 15) / 16, njobs);
   hipStream_t s = mgr_stream(c);
+  const size_t dyn = own_cu ? 64 * 1024 : 0;
 #define BWD_CASE(HH)                                                                                              \
   case HH:                                                                                                        \
-    hipLaunchKernelGGL((k_scan_bwd_mfma<HH>), dim3(grid), dim3(NW * 64), 0, s, dY, lddy, G, Cs, Up, dZ, B, T, reverse); \
+    if (own_cu) MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_bwd_mfma<HH>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024)); \
+    hipLaunchKernelGGL((k_scan_bwd_mfma<HH>), grid, dim3(NW * 64), dyn, s, J, lddy, B, T); \
     break;
   switch (H) {
     BWD_CASE(4)

@@ -123,9 +123,17 @@ class BaseDataGenerator(Callback):
     model_json_name = "model.json"
     model_weights_name = "weights.h5"
 
-    def _setup(self, minibatch_size, maxlen, nb_classes, dataset, val_split, absolute_max_sequence_len, store):
+    def _setup(self, minibatch_size, maxlen, nb_classes, dataset, val_split, absolute_max_sequence_len, store, rank=0, world=1):
         Callback.__init__(self)
         self.minibatch_size = minibatch_size
+        # data parallel (not in the reference): `minibatch_size` stays the GLOBAL batch - file lists, split, wrap-around
+        # and shuffles are those of the single-process generator on every rank - and get_batch assembles only this rank's
+        # contiguous slice of it: rank-aware batch == parallel.shard_batch(full batch, rank, world)
+        self.rank, self.world = int(rank), int(world)
+        if not 0 <= self.rank < self.world:
+            raise ValueError("rank %d outside world %d" % (self.rank, self.world))
+        if minibatch_size % self.world:
+            raise ValueError("global minibatch %d not divisible by world size %d" % (minibatch_size, self.world))
         self.maxlen = maxlen
         self.val_split = val_split
         self.absolute_max_sequence_len = absolute_max_sequence_len
@@ -171,6 +179,12 @@ class BaseDataGenerator(Callback):
     def get_batch(self, train):
         file_list, index = (self.train_list, self.train_index) if train else (self.val_list, self.val_index)
         batch = file_list[index:index + self.minibatch_size]
+        if self.world > 1:
+            # (a short last batch of an un-truncated list is sliced the way shard_batch would slice it)
+            if len(batch) % self.world:
+                raise ValueError("global batch %d not divisible by world size %d" % (len(batch), self.world))
+            per = len(batch) // self.world
+            batch = batch[self.rank * per:(self.rank + 1) * per]
         size = len(batch)
         # (np.ones of the reference, :178-186; rows are fully overwritten below unless the file has no label row, so the
         # buffers come from a small ring instead of 57 MB of fresh pages per call - a batch stays valid until
@@ -249,7 +263,7 @@ class BaseDataGenerator(Callback):
         self.val_index = 0
         random.shuffle(self.train_list)
         random.shuffle(self.val_list)
-        if self.model is not None:
+        if self.model is not None and getattr(self.model, "is_chief", True):    # (data parallel: rank 0 writes)
             with open(self.model_json_name, "w") as f:
                 f.write(self.model.to_json())
             self.model.save_weights(self.model_weights_name)

@@ -31,13 +31,13 @@ class DataGenerator(BaseDataGenerator):
     model_weights_name = stamp + ".h5"
 
     def __init__(self, minibatch_size, numfeats_skeletal, numfeats_speech, maxlen, val_split, nb_classes,
-                 absolute_max_sequence_len=28, store=None, synthetic_files=470, seed=20131900):
+                 absolute_max_sequence_len=28, store=None, synthetic_files=470, seed=20131900, rank=0, world=1):
         self.numfeats_speech = numfeats_speech
         self.numfeats_skeletal = numfeats_skeletal
         if store is None:
             store = SyntheticStore(synthetic_files, {'audio': (numfeats_speech, 3.0), 'skeletal': (numfeats_skeletal, 1.0)},
                                    maxlen, nb_classes, seed=seed, lmax=min(20, absolute_max_sequence_len))
-        self._setup(minibatch_size, maxlen, nb_classes, 'train', val_split, absolute_max_sequence_len, store)
+        self._setup(minibatch_size, maxlen, nb_classes, 'train', val_split, absolute_max_sequence_len, store, rank=rank, world=world)
 
 
 def build_net(maxlen=maxlen, numfeats_speech=numfeats_speech, numfeats_skeletal=numfeats_skeletal,

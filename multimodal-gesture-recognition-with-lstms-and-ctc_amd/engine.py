@@ -84,8 +84,9 @@ class Schedule:
     """
 
     def __init__(self, pipeline=True, defer_param_grads=True, encoders_run_ahead=True, resident_wait_us=2000,
-                 transposed_inputs=True):
+                 transposed_inputs=True, exclusive_narrow_scans=False):
         self.transposed_inputs = bool(transposed_inputs)
+        self.exclusive_narrow_scans = bool(exclusive_narrow_scans)
         self.pipeline = bool(pipeline)
         self.defer_param_grads = bool(defer_param_grads)
         self.encoders_run_ahead = bool(encoders_run_ahead)
@@ -112,7 +113,7 @@ class Engine:
         self.comm = comm
         self.world = int(world)
         self.inference_only = inference_only
-        self.iterations = 0   # optimizer step count (Keras `iterations`)
+        self._adam_calls = 0  # optimizer steps enqueued; `iterations` (Keras) = those the update gate did not skip
         self.rng_step = 0     # advances per forward pass that draws randomness
         self._build()
 
@@ -134,10 +135,16 @@ class Engine:
         self.status = dev.zeros((16,), np.uint32)
         self.loss_host = dev.pinned((4,), np.float32)
         self.status_host = dev.pinned((4,), np.uint32)
+        # data parallel: [gate flag, sum over ranks of the local mean losses, -, -] of step s in slot s & 1, copied from behind the
+        # all-reduced gradient buffer (apply_gradients); read by read_global_loss
+        self.gloss_host = [dev.pinned((4,), np.float32) for _ in range(2)]
+        self._gloss_step = [-1, -1]
         if not self.inference_only:
-            # the 4 floats behind the gradients carry the update-gate flag through the gradient all-reduce (apply_gradients)
+            # the 4 floats behind the gradients ride through the gradient all-reduce (apply_gradients): [0] the update-gate flag,
+            # [1] this rank's mean loss of the step ("piggy-backed as one extra float")
             self.grads = dev.zeros((max(off, 4) + 4,))
             self.gate_flag = self.grads.view(max(off, 4), (4,))
+            self.loss_slot = self.grads.view(max(off, 4) + 1, (1,))
             self.m = dev.zeros((max(off, 4),))
             self.v = dev.zeros((max(off, 4),))
         self.frozen = {}
@@ -336,8 +343,8 @@ class Engine:
     def reset_optimizer(self):
         self.m.zero()
         self.v.zero()
-        self.iterations = 0
         self.clear_scan_status()
+        self.iterations = 0
 
     # ------------------------------------------------------------------------------------------ helpers
     def _seed(self, slot):
@@ -618,12 +625,25 @@ class Engine:
     nonfinite_seen = False
     updates_skipped = 0
 
+    @property
+    def iterations(self):
+        """Optimizer updates APPLIED so far (Keras `iterations`: learning-rate decay, Adam bias correction): the steps enqueued
+        minus those the update gate skipped on the device, as far as the host knows (updates_skipped is refreshed with every
+        loss read-back and by scan_health())."""
+        return max(0, self._adam_calls - int(self.updates_skipped))
+
+    @iterations.setter
+    def iterations(self, value):
+        self._adam_calls = int(value) + int(self.updates_skipped)
+
     def clear_scan_status(self):
         """Forget recorded scan status bits (after recovering from a diverged run / a give-up)."""
-        self._bind()
+        self.scan_health()             # (the device's skipped-update count restarts at 0: fold it into the host's counter first)
+        applied = self.iterations
         self.dev.call("mgr_scan_status_clear")
         self.nonfinite_seen = False
         self.updates_skipped = 0
+        self._adam_calls = applied
 
     def predict(self, inputs):
         """Softmax output (B,T,C) with learning phase 0 (sequence_decoding.py:81)."""
@@ -632,7 +652,7 @@ class Engine:
         self._forward(False, None)
         P = self.P.download()
         self._check_scans()
-        return P
+        return self._nan_if_nonfinite(P)
 
     def forward_train_phase(self, inputs, rand=None):
         """Softmax output with learning phase 1 (dropout / noise active) - no gradient."""
@@ -641,7 +661,19 @@ class Engine:
         self._forward(True, rand)
         P = self.P.download()
         self._check_scans()
-        return P
+        return self._nan_if_nonfinite(P)
+
+    def _nan_if_nonfinite(self, out):
+        """A hidden state that went NaN / Inf is fed back as 0 by the multi-CU exchange (mgr.h, MGR_SCAN_NONFINITE): the OTHER
+        units of that sample - and everything computed from them - may look finite where the reference's whole sample would be
+        NaN.  Whoever hands out results of such a pass hands out NaN, as read_loss does."""
+        if not self.nonfinite_seen:
+            return out
+        if isinstance(out, tuple):
+            return tuple(self._nan_if_nonfinite(o) for o in out)
+        if isinstance(out, np.ndarray) and out.dtype.kind == "f":
+            return np.full_like(out, np.nan)
+        return out
 
     # ------------------------------------------------------------------------------------------ pipelined inference / validation
     EV_ENC = (46, 47)     # the encoder pass into FEAT buffer 0 / 1 is complete
@@ -704,18 +736,29 @@ class Engine:
                                          for _ in range(2)])
         else:
             pins = bufs("loss", lambda: [dev.pinned((B,), np.float32) for _ in range(2)])
+            # one device buffer per output slot, like pring: batch i's copy (its own stream, behind EV_FUSED only) must not find
+            # batch i + 1's losses in the buffer - stream 0 waits for EV_OUT[o] of batch i - 2 before it reuses slot o
+            lring = bufs("lring", lambda: [self.loss_b, self.mem.empty((B,))])
+
+        spin = bufs("status", lambda: [dev.pinned((4,), np.uint32) for _ in range(2)])
 
         def collect(i):
             o = i & 1
             dev.event_sync(self.EV_OUT[o])
+            # the engine's scan status travels with every result (no extra synchronisation): a pass over diverged weights hands
+            # out NaN, not plausible numbers (_nan_if_nonfinite)
+            if int(spin[o][0]) & _capi.SCAN_NONFINITE:
+                self.nonfinite_seen = True
             if output == "posteriors":
-                return pins[o].copy()
-            if output == "argmax":
-                return pins[o][0].copy(), pins[o][1].copy()
-            if output == "beam":
+                r = pins[o].copy()
+            elif output == "argmax":
+                r = (pins[o][0].copy(), pins[o][1].copy())
+            elif output == "beam":
                 po, pl, ps = pins[o]
-                return [[int(v) for v in po[b, :pl[b]]] for b in range(B)], ps.copy()
-            return pins[o].copy()
+                r = ([[int(v) for v in po[b, :pl[b]]] for b in range(B)], ps.copy())
+            else:
+                r = pins[o].copy()
+            return self._nan_if_nonfinite(r)
 
         n = 0
         try:
@@ -743,7 +786,7 @@ class Engine:
                 dev.stream(0)
                 if output == "loss":
                     dev.call("mgr_ctc_loss_grad", self.P, self.labels_d, self.ilen_d, self.llen_d, B, T, Cn, self.Lmax, skip, Cn - 1,
-                             float(sp.ctc["eps"]), 1.0, self.loss_b, 0, self.ws_ctc, self.ws_ctc.nbytes)
+                             float(sp.ctc["eps"]), 1.0, lring[o], 0, self.ws_ctc, self.ws_ctc.nbytes)
                     dev.record(self.EV_LAB[self._lab_slot])
                     self._lab_user[self._lab_slot] = 1 << 60
                 dev.record(self.EV_FUSED[f])
@@ -763,7 +806,8 @@ class Engine:
                     dev.d2h_async(pins[o][1], dlen)
                     dev.d2h_async(pins[o][2], dlogp)
                 else:
-                    dev.d2h_async(pins[o], self.loss_b)
+                    dev.d2h_async(pins[o], lring[o])
+                dev.d2h_async(spin[o], self.status)
                 dev.record(self.EV_OUT[o])
                 dev.stream(0)
                 n = i + 1
@@ -826,20 +870,41 @@ class Engine:
     LOSS_STREAM = 6   # (pipelined inference: decode / result copies)
     EV_LOSS = 52      # the loss and the scan status of the step enqueued last have reached their page-locked host words
 
-    def read_loss(self):
+    def read_loss(self, local=False):
         """Mean CTC loss of the step enqueued last: waits for the event behind the loss kernels and their read-back - not for
-        the gradient GEMMs / optimizer queued behind them - so the host can enqueue the next step early."""
+        the gradient GEMMs / optimizer queued behind them - so the host can enqueue the next step early.
+        Data parallel (world > 1): the mean over the GLOBAL batch, the same number on every rank - it arrives with the gradient
+        all-reduce, i.e. at the END of the step (read_global_loss); local=True returns this rank's own mean without that wait
+        (a training loop that wants to keep the host ahead of the device reads the global loss one step late)."""
         dev = self.dev
         dev.event_sync(self.EV_LOSS)
         v = float(self.loss_host[0])
-        self._synced_step = self._step_id - 1
-        self._check_scans(step=self._step_id - 1, snapshot=self.status_host)   # raises if a persistent scan gave up: results would be garbage
+        step = self._step_id - 1
+        self._synced_step = step
+        self._check_scans(step=step, snapshot=self.status_host)   # raises if a persistent scan gave up: results would be garbage
+        if not local and self.world > 1 and self._gloss_step[step & 1] == step:
+            return self.read_global_loss(step)
         if self.nonfinite_seen:
             # a hidden state went NaN / Inf: in the reference every later op propagates the NaN into the loss.  Here a NaN
             # feature that input dropout happens to drop is SKIPPED by the dropout-aware kernels (no 0 x NaN), so the number
             # the device computed may look finite - report what the reference would report
             return float("nan")
         return v
+
+    EV_GLOSS = (53, 54)   # the all-reduced (gate flag, loss sum) of step s has reached gloss_host[s & 1]
+
+    def read_global_loss(self, step=None):
+        """Mean CTC loss over the global batch of training step `step` (default: the one enqueued last), identical on every
+        rank: (sum over ranks of the local means) / world, carried by the gradient all-reduce of that step.  NaN on EVERY rank
+        when any rank's scans reported a non-finite state or gave up in that step (the all-reduced update-gate flag)."""
+        step = self._step_id - 1 if step is None else int(step)
+        slot = step & 1
+        if self._gloss_step[slot] != step:
+            raise ValueError("no all-reduced loss for step %d (not a data-parallel step, its update was not applied, or two "
+                             "later steps have been enqueued since)" % step)
+        self.dev.event_sync(self.EV_GLOSS[slot])
+        flag, total = float(self.gloss_host[slot][0]), float(self.gloss_host[slot][1])
+        return float("nan") if flag != 0.0 else total / self.world
 
     @property
     def can_pipeline(self):
@@ -901,6 +966,8 @@ class Engine:
                  int(sp.ctc["skip"]), Cn - 1, float(sp.ctc["eps"]), 1.0 / B, self.loss_b, self.dLogits,
                  self.ws_ctc, self.ws_ctc.nbytes)
         dev.call("mgr_mean", self.loss_b, B, self.loss_mean)
+        if self.comm is not None:
+            dev.call("mgr_mean", self.loss_b, B, self.loss_slot)   # travels with the gradient all-reduce (apply_gradients)
         dev.record(self.EV_LAB[self._lab_slot])
         # The loss and this engine's scan status go to page-locked host words from THIS stream, an event behind them: the host
         # polls that event (read_loss) while the backward pass queued behind it runs.  Round 2 read them on a stream of their own
@@ -987,6 +1054,10 @@ class Engine:
                 if ahead and k == 0:
                     dev.stream(ES)
                     dev.wait_event(ES, self.EV_FPROJ)
+                    if self.schedule.exclusive_narrow_scans:
+                        # the fusion layer's single-CU scan (enqueued above, on stream 0, right behind those projections) takes
+                        # its CUs before the 408 encoder workgroups arrive
+                        dev.call("mgr_stream_wait_last_resident", 300)
                 if k == depth - 1:
                     dev.wait(0, ES)
                     dev.stream(0)
@@ -1087,20 +1158,28 @@ class Engine:
         if self.comm is not None:   # (a 1-rank communicator is legal: the reduction is then the identity)
             self.comm.allreduce_sum(self.grads, max(self.n_train, 4) + 4)
             gscale = 1.0 / self.world
-        dev.call("mgr_update_gate_set", self.gate_flag)
+            step = self._step_id - 1
+            dev.d2h_async(self.gloss_host[step & 1], self.gate_flag)      # [flag sum, loss sum]: read_global_loss
+            dev.record(self.EV_GLOSS[step & 1])
+            self._gloss_step[step & 1] = step
+        # Keras' `iterations` counts APPLIED updates: what the gate skipped on the device (counted there; the host learns the
+        # number with each loss read-back, i.e. one or two steps late) does not advance the learning-rate decay / bias correction
         k = self.iterations
         lr_k = o["lr"] * (1.0 / (1.0 + o["decay"] * k))
         t = k + 1
         lr_t = lr_k * math.sqrt(1.0 - o["beta_2"] ** t) / (1.0 - o["beta_1"] ** t)
-        dev.call("mgr_adam_step", self.params, self.grads, self.m, self.v, self.n_train, lr_t, o["beta_1"],
-                 o["beta_2"], o["epsilon"], o["clipvalue"] or 0.0, gscale)
-        for name, (off, n, shape, kind) in self.seg.items():
-            if kind == "kernel":
-                mv = self.spec.kernel_maxnorm(name.rsplit("/", 2)[0])   # "<prefix>/<fwd|bwd>/W" -> "<prefix>"
-                if mv > 0:
-                    dev.call("mgr_maxnorm_cols", self.params.view(off, (n,)), shape[0], shape[1], mv, 1e-7)
-        dev.call("mgr_update_gate_set", 0)
-        self.iterations += 1
+        dev.call("mgr_update_gate_set", self.gate_flag)
+        try:
+            dev.call("mgr_adam_step", self.params, self.grads, self.m, self.v, self.n_train, lr_t, o["beta_1"],
+                     o["beta_2"], o["epsilon"], o["clipvalue"] or 0.0, gscale)
+            for name, (off, n, shape, kind) in self.seg.items():
+                if kind == "kernel":
+                    mv = self.spec.kernel_maxnorm(name.rsplit("/", 2)[0])   # "<prefix>/<fwd|bwd>/W" -> "<prefix>"
+                    if mv > 0:
+                        dev.call("mgr_maxnorm_cols", self.params.view(off, (n,)), shape[0], shape[1], mv, 1e-7)
+        finally:
+            dev.call("mgr_update_gate_set", 0)      # (never leave the gate pointer installed in the context)
+        self._adam_calls += 1
 
     def close(self):
         """Free this engine's device buffers; destroy the context only if the engine created it."""

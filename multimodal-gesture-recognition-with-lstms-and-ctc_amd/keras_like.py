@@ -50,7 +50,9 @@ class Adam:
 
 
 class RMSprop:
-    """Accepted by compile() for the decode scripts (sequence_decoding.py:112-115) which never train."""
+    """Accepted by compile() for the decode scripts (sequence_decoding.py:112-115), which never train: the device optimizer
+    is Adam (the only one on the reference's training path), so training after compile(optimizer=RMSprop(...)) is refused
+    (Model._require_trainable) instead of silently running Adam with default settings."""
 
     def __init__(self, lr=0.001, **kwargs):
         self.lr = lr
@@ -334,9 +336,17 @@ class Model:
         names = [n for n, _, _, _ in self.spec.weight_table()]
         self.set_weights_dict(dict(zip(names, lst)))
 
+    @property
+    def is_chief(self):
+        """Data parallel: rank 0 writes checkpoints / model files; every replica holds the same weights and - the validation loss
+        being all-reduced (evaluate_generator) - takes the same save_best_only / early-stopping decisions."""
+        return int(getattr(self.comm, "rank", 0) or 0) == 0
+
     def save_weights(self, filepath, overwrite=True):
         """``*.h5`` / ``*.hdf5``: an HDF5 file in the Keras 2.1.4 ``save_weights`` layout (keras_io / h5lite - no h5py);
-        any other name: a numpy ``.npz`` archive under exactly that name."""
+        any other name: a numpy ``.npz`` archive under exactly that name.  Data parallel: only rank 0 writes."""
+        if not self.is_chief:
+            return
         w = self.get_weights_dict()
         if str(filepath).lower().endswith((".h5", ".hdf5")):
             from .keras_io import save_keras_weights
@@ -410,16 +420,32 @@ class Model:
             return dict(zip(names, x))
         return {names[0]: x}
 
-    def train_on_batch(self, x, y=None, rand=None, next_x=None):
+    def _require_trainable(self):
+        if self.optimizer is not None and not isinstance(self.optimizer, Adam):
+            raise NotImplementedError("this model was compiled with %s: the device optimizer is Adam (the reference's training "
+                                      "path, multimodal.py:206-208) - compile(optimizer=Adam(...)) before training"
+                                      % type(self.optimizer).__name__)
+
+    def train_on_batch(self, x, y=None, rand=None, next_x=None, _lagged=False):
         """next_x: the batch of the FOLLOWING call (fit_generator passes it): with frozen encoders the engine overlaps
-        that batch's encoder pass with this step's trainable part."""
+        that batch's encoder pass with this step's trainable part.  Data parallel: returns the mean over the GLOBAL batch
+        (Engine.read_global_loss), the same number on every rank."""
+        self._require_trainable()
         ins = self._cached_split(x)
         first = next(iter(ins.values()))
         B, T = first.shape[0], first.shape[1]
         labels = np.asarray(x["the_labels"])
         e = self._ensure_engine(B, T, labels.shape[1])
         nxt = self._cached_split(next_x) if next_x is not None else None
-        return e.train_step(ins, labels, x["input_length"], x["label_length"], rand=rand, next_inputs=nxt)
+        if not _lagged:
+            return e.train_step(ins, labels, x["input_length"], x["label_length"], rand=rand, next_inputs=nxt)
+        # fit_generator, world > 1: the global loss arrives with the gradient all-reduce at the END of the step; waiting for it
+        # here would leave the device idle while the host assembles the next batch - pace on the local loss, collect the global
+        # one a step later (Engine.read_global_loss)
+        e.enqueue_train_step(ins, labels, x["input_length"], x["label_length"], rand, True, prefetch_next=nxt is not None,
+                             next_inputs=nxt)
+        e.read_loss(local=True)
+        return e._step_id - 1
 
     def _cached_split(self, x):
         """_split_inputs with identity preserved across calls (the engine matches a prefetched batch by identity).
@@ -452,6 +478,7 @@ class Model:
 
     def fit_generator(self, generator, steps_per_epoch, epochs=1, verbose=1, callbacks=None, validation_data=None,
                       validation_steps=None, initial_epoch=0, **kwargs):
+        self._require_trainable()
         callbacks = list(callbacks or [])
         hist = History()
         callbacks.append(hist)
@@ -471,13 +498,29 @@ class Model:
                 if hasattr(cb, "on_epoch_begin"):
                     cb.on_epoch_begin(epoch, {})
             losses = []
+            lagged = self.world > 1 and self.comm is not None
+            owed = None       # (data parallel) id of the step whose global loss has not been collected yet
+            skipped0 = self._engine.updates_skipped if self._engine is not None else 0
             pending = next(generator) if steps_per_epoch > 0 else None
             for step in range(steps_per_epoch):
                 x, y = pending
                 # fetch the next batch early (never across an epoch boundary: on_epoch_end reshuffles the file lists)
                 pending = next(generator) if step + 1 < steps_per_epoch else None
-                losses.append(self.train_on_batch(x, y, next_x=pending[0] if pending is not None else None))
+                r = self.train_on_batch(x, y, next_x=pending[0] if pending is not None else None, _lagged=lagged)
+                if lagged:
+                    if owed is not None:
+                        losses.append(self._engine.read_global_loss(owed))
+                    owed = r
+                else:
+                    losses.append(r)
+            if owed is not None:
+                losses.append(self._engine.read_global_loss(owed))
             logs = {"loss": float(np.mean(losses)) if losses else float("nan")}
+            if self._engine is not None and self._engine.updates_skipped > skipped0:
+                import warnings
+                warnings.warn("%d optimizer update(s) of this epoch were skipped on the device (a scan of the step reported a non-finite "
+                              "hidden state or gave up): the weights are those of the last good step - Model.clear_scan_status() "
+                              "after restoring a good state" % (self._engine.updates_skipped - skipped0))
             if validation_data is not None and validation_steps:
                 logs["val_loss"] = self.evaluate_generator(validation_data, validation_steps)
             if verbose:
@@ -565,7 +608,12 @@ class Model:
                 yield self._split_inputs(x), np.asarray(x["the_labels"]), x["input_length"], x["label_length"]
 
         means = [float(np.mean(l)) for l in e.predict_stream(feed(), output="loss", train_phase=bool(learning_phase()))]
-        return float(np.mean(means))
+        v = float(np.mean(means))
+        if self.comm is not None and self.world > 1:
+            # data parallel: every rank evaluated ITS shard of each batch; the validation loss every replica logs - and on which
+            # ModelCheckpoint(save_best_only) / EarlyStopping decide - is the mean over the global batches (one scalar all-reduce)
+            v = self.comm.allreduce_sum_scalar(v) / self.world
+        return v
 
 
 def model_from_json(text, device=0):

@@ -10,7 +10,7 @@ class DataGenerator(BaseDataGenerator):
     model_weights_name = "multimodal_ctc_blstm_weights.h5"
 
     def __init__(self, minibatch_size, numfeats_skeletal, numfeats_speech, maxlen, nb_classes, dataset, val_split=0.2,
-                 absolute_max_sequence_len=35, data_root='../data', synthetic_files=None, seed=20131900):
+                 absolute_max_sequence_len=35, data_root='../data', synthetic_files=None, seed=20131900, rank=0, world=1):
         self.numfeats_speech = numfeats_speech
         self.numfeats_skeletal = numfeats_skeletal
         names = {'train': ('train_audio', 'Training_set_skeletal.csv', 'training_oov.csv'),
@@ -25,4 +25,4 @@ class DataGenerator(BaseDataGenerator):
             n = synthetic_files if synthetic_files is not None else 470
             store = SyntheticStore(n, {'audio': (numfeats_speech, 3.0), 'skeletal': (numfeats_skeletal, 1.0)}, maxlen,
                                    nb_classes, seed=seed, lmax=min(20, absolute_max_sequence_len))
-        self._setup(minibatch_size, maxlen, nb_classes, dataset, val_split, absolute_max_sequence_len, store)
+        self._setup(minibatch_size, maxlen, nb_classes, dataset, val_split, absolute_max_sequence_len, store, rank=rank, world=world)

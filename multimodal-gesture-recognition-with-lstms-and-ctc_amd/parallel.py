@@ -71,6 +71,12 @@ class RcclComm:
         _capi.check(self.dev.lib.mgr_allreduce_max(self.comm, self._scratch.ptr, 1))
         return float(self._scratch.download()[0])
 
+    def allreduce_sum_scalar(self, value):
+        """Sum of one float over the ranks (validation loss, Model.evaluate_generator); the same bits on every rank."""
+        self._scratch.upload(np.array([value, 0, 0, 0], np.float32))
+        _capi.check(self.dev.lib.mgr_allreduce_sum(self.comm, self._scratch.ptr, 1))
+        return float(self._scratch.download()[0])
+
     def barrier(self):
         self.allreduce_max_scalar(0.0)
 
@@ -168,6 +174,9 @@ class HostComm:
 
     def allreduce_max_scalar(self, value):
         return float(self._reduce_host(np.array([value], np.float32), np.maximum)[0])
+
+    def allreduce_sum_scalar(self, value):
+        return float(self._reduce_host(np.array([value], np.float32), np.add)[0])
 
     def barrier(self):
         self.allreduce_max_scalar(0.0)

@@ -19,7 +19,7 @@ class DataGenerator(BaseDataGenerator):
 
     def __init__(self, minibatch_size, numfeats, maxlen, val_split, nb_classes, absolute_max_sequence_len=28,
                  in_file='Training_set_skeletal.csv', train_lab_file='../training.csv', synthetic_files=None,
-                 seed=20131902):
+                 seed=20131902, rank=0, world=1):
         self.numfeats = numfeats
         if synthetic_files is None and os.path.isfile(in_file) and os.path.isfile(train_lab_file):
             store = CsvStore(None, in_file, train_lab_file)
@@ -27,7 +27,7 @@ class DataGenerator(BaseDataGenerator):
             n = synthetic_files if synthetic_files is not None else 393
             store = SyntheticStore(n, {'skeletal': (numfeats, 1.0)}, maxlen, nb_classes, seed=seed,
                                    lmax=min(20, absolute_max_sequence_len))
-        self._setup(minibatch_size, maxlen, nb_classes, 'train', val_split, absolute_max_sequence_len, store)
+        self._setup(minibatch_size, maxlen, nb_classes, 'train', val_split, absolute_max_sequence_len, store, rank=rank, world=world)
 
 
 def build_model(maxlen, numfeats, nb_classes, lab_seq_len=28, load_previous='no', units=300, layers=2, device=0,

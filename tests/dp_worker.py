@@ -37,9 +37,10 @@ def dp_batches(spec, B, T, Lmax, nbatch):
     return out
 
 
-def run_steps(eng, spec, batches, steps, pipelined=True):
+def run_steps(eng, spec, batches, steps, pipelined=True, local=None):
     """`steps` training steps over the batches in turn through the host-batch path fit_generator uses (next batch announced so
-    that its encoder pass is prefetched).  Returns the per-step local mean losses."""
+    that its encoder pass is prefetched).  Returns the per-step losses train_step reports (world > 1: the mean over the GLOBAL
+    batch, Engine.read_global_loss); `local` (a list) receives this rank's own means."""
     names = [s["name"] for s in spec.streams]
     splits = [{n: b[n] for n in names} for b in batches]     # stable objects: the engine matches the announced batch by identity
     losses = []
@@ -47,6 +48,8 @@ def run_steps(eng, spec, batches, steps, pipelined=True):
         b, ins = batches[i % len(batches)], splits[i % len(batches)]
         nxt = splits[(i + 1) % len(batches)] if (pipelined and i + 1 < steps) else None
         losses.append(eng.train_step(ins, b["the_labels"], b["input_length"], b["label_length"], next_inputs=nxt))
+        if local is not None:
+            local.append(float(eng.loss_host[0]))      # (the page-locked word the step's own mean was copied to)
     return losses
 
 
@@ -71,7 +74,8 @@ def dp_rank(rank, world, port, out_path, exact, B, T, Lmax, steps, comm_kind="ho
         assert eng.can_pipeline
         eng.set_weights(synthetic_weights(spec, 3))
         mine = [shard_batch(b, rank, world) for b in dp_batches(spec, B, T, Lmax, 2)]
-        losses = run_steps(eng, spec, mine, steps)
+        local = []
+        losses = run_steps(eng, spec, mine, steps, local=local)
         dev.sync()
         import ctypes
         st = ctypes.c_uint(7)
@@ -80,11 +84,60 @@ def dp_rank(rank, world, port, out_path, exact, B, T, Lmax, steps, comm_kind="ho
         dev.call("mgr_persist_stats", ctypes.byref(nl), ctypes.byref(ns))
         w, g = eng.get_weights(), eng.get_grads()
         comm.barrier()
-        np.savez(out_path, losses=np.array(losses, np.float64), status=st.value, persist=np.array([nl.value, ns.value]),
+        np.savez(out_path, losses=np.array(losses, np.float64), local=np.array(local, np.float64), status=st.value, persist=np.array([nl.value, ns.value]),
                  **{"w__" + k.replace("/", "__"): v for k, v in w.items()},
                  **{"g__" + k.replace("/", "__"): v for k, v in g.items()})
         comm.close()
         eng.close()
+    except BaseException:
+        with open(out_path + ".err", "w") as f:
+            f.write(traceback.format_exc())
+        raise
+
+
+def fit_model(comm, world, rank, workdir, epochs=3):
+    """The reference's training script in small (multimodal.py:206-269): compile(Adam), ModelCheckpoint(val_loss, save_best_only),
+    fit_generator over a (rank-aware) DataGenerator with validation.  Returns (loss history, val_loss history, checkpoint
+    decisions per epoch, weights after training)."""
+    import mgr_amd  # noqa: F401
+    from mgr_amd.keras_like import Adam, Callback, Model, ModelCheckpoint
+    from mgr_amd.multimodal_fusion.data_generator import DataGenerator
+    spec = dp_spec(True)
+    m = Model(spec, device=comm.dev if comm is not None else 0)
+    if comm is not None:
+        m.distribute(comm, world)
+    m.compile(loss={'ctc': lambda y_true, y_pred: y_pred}, optimizer=Adam(lr=1e-3, clipvalue=0.5, decay=1e-5))
+    from mgr_amd.synthetic import synthetic_weights
+    m.set_weights_dict(synthetic_weights(spec, 3))
+    gen = DataGenerator(8, 20, 39, 64, 22, 'train', synthetic_files=45, rank=rank, world=world, absolute_max_sequence_len=8)
+    gen.model_json_name = os.path.join(workdir, "model_rank%d.json" % rank)
+    gen.model_weights_name = os.path.join(workdir, "weights_rank%d.h5" % rank)
+    ck = ModelCheckpoint(os.path.join(workdir, "best_rank%d.h5" % rank), monitor='val_loss', save_best_only=True, save_weights_only=True)
+    decisions = []
+
+    class Watch(Callback):
+        def on_epoch_end(self, epoch, logs=None):
+            decisions.append(float(ck.best))
+
+    h = m.fit_generator(gen.next_train(), steps_per_epoch=gen.get_size(True) // 8, epochs=epochs, verbose=0,
+                        validation_data=gen.next_val(), validation_steps=gen.get_size(False) // 8, callbacks=[ck, Watch(), gen])
+    return h.history["loss"], h.history["val_loss"], decisions, m.get_weights_dict()
+
+
+def dp_fit_rank(rank, world, port, out_path, workdir):
+    """Rank process of the Model-level data-parallel test: fit_generator with the rank-aware DataGenerator on GPU 0 (HostComm)."""
+    try:
+        sys.path.insert(0, ROOT)
+        import mgr_amd  # noqa: F401
+        from mgr_amd import _capi
+        from mgr_amd.parallel import HostComm
+        dev = _capi.Device(0)
+        comm = HostComm(dev, rank, world, addr="127.0.0.1", port=port, timeout=120.0)
+        loss, val, dec, w = fit_model(comm, world, rank, workdir)
+        comm.barrier()
+        np.savez(out_path, loss=np.array(loss, np.float64), val=np.array(val, np.float64), dec=np.array(dec, np.float64),
+                 **{"w__" + k.replace("/", "__"): v for k, v in w.items()})
+        comm.close()
     except BaseException:
         with open(out_path + ".err", "w") as f:
             f.write(traceback.format_exc())

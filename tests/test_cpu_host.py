@@ -347,3 +347,119 @@ def test_effective_cores_honours_the_cgroup_quota_and_import_caps_blas_pools(tmp
     env["LOCAL_WORLD_SIZE"] = "4"      # the ranks of a node share the quota
     out = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
     assert out == [str(max(1, n // 4))] * 2
+
+
+def test_rank_aware_generator_assembles_only_its_shard_of_every_global_batch():
+    """DataGenerator(..., rank=, world=): every rank walks the SAME file lists (seeded shuffle, split, whole-minibatch rule,
+    wrap-around, epoch-end reshuffle) and assembles only its contiguous slice of each global minibatch:
+    rank-aware batch == parallel.shard_batch(full batch) - for training batches, validation batches and a short last batch of
+    an un-truncated list (reference per-file loop: multimodal_fusion/data_generator.py:157-278)."""
+    import random
+    from mgr_amd.multimodal_fusion.data_generator import DataGenerator
+    from mgr_amd.parallel import shard_batch
+    world, mb = 2, 8
+    kw = dict(synthetic_files=45)
+    random.seed(123)
+    full = DataGenerator(mb, 20, 39, 40, 22, 'train', **kw)
+    parts = [DataGenerator(mb, 20, 39, 40, 22, 'train', rank=r, world=world, **kw) for r in range(world)]
+    for g in parts:
+        assert g.get_size(True) == full.get_size(True) and g.get_file_list(True) == full.get_file_list(True)
+        assert g.get_file_list(False) == full.get_file_list(False)
+
+    def same(a, b):
+        assert set(a[0]) == set(b[0])
+        for k in a[0]:
+            assert a[0][k].shape == b[0][k].shape and np.array_equal(a[0][k], b[0][k]), k
+        assert a[1]['ctc'].shape == b[1]['ctc'].shape
+
+    for train in (True, False):
+        gens = [(g.next_train() if train else g.next_val()) for g in [full] + parts]
+        for _ in range(full.get_size(train) // mb + 2):          # (+2: across the wrap-around)
+            fb = next(gens[0])
+            fb = ({k: v.copy() for k, v in fb[0].items()}, fb[1])
+            for r in range(world):
+                rb = next(gens[1 + r])
+                assert rb[0]['the_input_audio'].shape[0] == mb // world
+                same(rb, (shard_batch(fb[0], r, world), {'ctc': np.zeros(mb // world)}))
+    # epoch end: the same global `random` state gives every rank the same new order
+    lists = []
+    for g in [full] + parts:
+        random.seed(5)
+        g.on_epoch_end(0)
+        lists.append((list(g.train_list), list(g.val_list)))
+    assert lists[0] == lists[1] == lists[2]
+    # a short last batch of an un-truncated list ('final': 14 files, global batch 8 -> 8, then 6 -> 3 + 3)
+    vf = DataGenerator(mb, 20, 39, 40, 22, 'final', synthetic_files=14)
+    vp = [DataGenerator(mb, 20, 39, 40, 22, 'final', synthetic_files=14, rank=r, world=world) for r in range(world)]
+    for g in [vf] + vp:
+        g.val_index = 8
+    fb = vf.get_batch(False)
+    assert fb[0]['the_labels'].shape[0] == 6
+    for r in range(world):
+        same(vp[r].get_batch(False), (shard_batch(fb[0], r, world), {'ctc': np.zeros(3)}))
+    with pytest.raises(ValueError):
+        DataGenerator(9, 20, 39, 40, 22, 'train', rank=0, world=2, **kw)      # global batch not divisible
+    with pytest.raises(ValueError):
+        DataGenerator(8, 20, 39, 40, 22, 'train', rank=2, world=2, **kw)
+
+
+def test_training_after_compile_with_rmsprop_is_refused():
+    """The decode scripts compile with RMSprop and never train (sequence_decoding.py:112-115); fit_generator / train_on_batch on
+    such a model must refuse instead of silently running the device's Adam with default settings."""
+    from mgr_amd.keras_like import RMSprop
+    spec = configs.fusion_spec(h_audio=8, h_skeletal=4, h_fusion=4)
+    m = Model(spec)
+    m.compile(loss={'ctc': lambda a, b: b}, optimizer=RMSprop(lr=0.01))
+    with pytest.raises(NotImplementedError) as ei:
+        m.fit_generator(iter(()), steps_per_epoch=1, epochs=1)
+    assert "RMSprop" in str(ei.value) and "Adam" in str(ei.value)
+    with pytest.raises(NotImplementedError):
+        m.train_on_batch({"the_labels": np.zeros((1, 3))})
+    m.compile(loss={'ctc': lambda a, b: b}, optimizer=Adam(lr=1e-4))       # compiling with Adam afterwards is fine
+    m._require_trainable()
+
+
+def test_only_rank_zero_writes_checkpoints(tmp_path, monkeypatch):
+    """Data parallel: every replica takes the same save_best_only decision (the validation loss is all-reduced), rank 0 alone
+    writes - Model.save_weights and the generator's epoch-end model files (multimodal.py:252-258, data_generator.py:317-321)."""
+    from mgr_amd.multimodal_fusion.data_generator import DataGenerator
+
+    class Comm:
+        def __init__(self, rank):
+            self.rank, self.dev = rank, None
+
+    spec = configs.fusion_spec(h_audio=8, h_skeletal=4, h_fusion=4)
+    monkeypatch.chdir(tmp_path)
+    for rank in (1, 0):
+        m = Model(spec)
+        m.distribute(Comm(rank), 2)
+        assert m.is_chief == (rank == 0)
+        ck = ModelCheckpoint(str(tmp_path / "best.h5"), monitor='val_loss', save_best_only=True, save_weights_only=True)
+        ck.set_model(m)
+        ck.on_epoch_end(0, {"val_loss": 2.0})
+        assert ck.best == 2.0                                           # the decision is taken on every rank ...
+        assert os.path.exists(tmp_path / "best.h5") == (rank == 0)      # ... the file is written by rank 0
+        g = DataGenerator(4, 20, 39, 30, 22, 'train', synthetic_files=12, rank=rank, world=2)
+        g.model = m
+        g.on_epoch_end(0)
+        assert os.path.exists(tmp_path / g.model_json_name) == (rank == 0)
+
+
+def test_local_world_size_does_not_take_a_multi_node_world_for_the_node(monkeypatch):
+    from mgr_amd import _hostenv
+    for k in ("LOCAL_WORLD_SIZE", "WORLD_SIZE", "NNODES", "GROUP_WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    assert _hostenv.local_world_size() == 1
+    monkeypatch.setenv("WORLD_SIZE", "16")                 # 2 x 8 ranks, no LOCAL_WORLD_SIZE: not this node's rank count
+    assert _hostenv.local_world_size() == 1
+    monkeypatch.setenv("NNODES", "1")
+    assert _hostenv.local_world_size() == 16
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert _hostenv.local_world_size() == 8
+    # opt-out of the import side effect
+    import subprocess
+    import sys as _sys
+    code = "import os, sys; sys.path.insert(0, %r); import mgr_amd; print(os.environ.get('OPENBLAS_NUM_THREADS'))" % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+    env["MGR_NO_THREAD_CAP"] = "1"
+    assert subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split() == ["None"]

@@ -35,14 +35,17 @@ def _need(comm_kind, world):
             pytest.skip("comm=rccl needs %d GPUs (this box has %d): RCCL refuses two ranks on one device" % (world, device_count()))
 
 
-def _run_ranks(tmp_path, world, exact, B, T, Lmax, steps, comm_kind="host"):
+def _run_ranks(tmp_path, world, exact, B, T, Lmax, steps, comm_kind="host", target=None, args=None):
     from multiprocessing import forkserver
     if getattr(forkserver._forkserver, "_forkserver_pid", None) is None:
         pytest.skip("the fork server must be started before the GPU is initialised: run through `pytest -m gpu` (tests/conftest.py)")
     ctx = mp.get_context("forkserver")
     port = _free_port()
     outs = [str(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
-    procs = [ctx.Process(target=dp_worker.dp_rank, args=(r, world, port, outs[r], exact, B, T, Lmax, steps, comm_kind)) for r in range(world)]
+    if target is None:
+        procs = [ctx.Process(target=dp_worker.dp_rank, args=(r, world, port, outs[r], exact, B, T, Lmax, steps, comm_kind)) for r in range(world)]
+    else:
+        procs = [ctx.Process(target=target, args=(r, world, port, outs[r]) + tuple(args or ())) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -77,8 +80,12 @@ def test_two_ranks_equal_one_process_on_the_full_batch(device, tmp_path, comm_ki
     eng.close()
     r0, r1 = ranks
     assert int(r0["status"]) == 0 and int(r1["status"]) == 0            # no persistent scan gave up, nothing went non-finite
-    # losses: the global mean is the mean of the ranks' local means
-    glob = (r0["losses"] + r1["losses"]) / world
+    # losses: every rank reports the GLOBAL mean (it rides on the gradient all-reduce) = the mean of the ranks' local
+    # means = the one-process loss on the full batch
+    assert np.array_equal(r0["losses"], r1["losses"])
+    glob = (r0["local"] + r1["local"]) / world
+    assert np.allclose(r0["losses"], glob, rtol=1e-6), (r0["losses"], glob)
+    assert not np.array_equal(r0["local"], r1["local"])
     assert np.allclose(glob, ref_losses, rtol=2e-6), (glob, ref_losses)
     assert np.all(np.isfinite(glob)) and len(set(np.round(glob, 3))) > 1
     for k, v in w_ref.items():
@@ -104,10 +111,37 @@ def test_two_ranks_with_device_rng_stay_in_lockstep(device, tmp_path, comm_kind)
     r0, r1 = ranks
     assert int(r0["status"]) == 0 and int(r1["status"]) == 0
     assert np.all(np.isfinite(r0["losses"])) and np.all(np.isfinite(r1["losses"]))
-    assert not np.array_equal(r0["losses"], r1["losses"])
+    assert np.array_equal(r0["losses"], r1["losses"])            # the reported loss is the global one on every rank ...
+    assert not np.array_equal(r0["local"], r1["local"])          # ... the local means differ (different shards, different masks)
     for k in r0.files:
         if k.startswith(("w__", "g__")):
             assert np.array_equal(r0[k], r1[k]), k
+
+
+def test_fit_generator_on_two_ranks_logs_global_losses_and_takes_one_checkpoint_decision(device, tmp_path):
+    """The reference's training loop (compile / ModelCheckpoint(val_loss, save_best_only) / fit_generator with validation,
+    multimodal.py:206-269) on two ranks with the rank-aware DataGenerator: both ranks log the same loss and val_loss per epoch
+    = what one process logs on the global batches (2e-6), both take the same save_best_only decision in each of 3 epochs, and
+    rank 0 alone writes the files."""
+    world = 2
+    ranks = _run_ranks(tmp_path, world, True, 0, 0, 0, 0, target=dp_worker.dp_fit_rank, args=(str(tmp_path),))
+    one = tmp_path / "one"
+    one.mkdir()
+    loss, val, dec, w = dp_worker.fit_model(None, 1, 0, str(one))
+    r0, r1 = ranks
+    assert len(loss) == 3 and np.all(np.isfinite(loss)) and np.all(np.isfinite(val))
+    for key in ("loss", "val", "dec"):
+        assert np.array_equal(r0[key], r1[key]), key                 # same numbers on every rank: same decisions
+    assert np.allclose(r0["loss"], loss, rtol=2e-6), (r0["loss"], loss)
+    assert np.allclose(r0["val"], val, rtol=2e-6), (r0["val"], val)
+    assert np.allclose(r0["dec"], dec, rtol=2e-6)
+    for k, v in w.items():
+        kk = "w__" + k.replace("/", "__")
+        assert np.array_equal(r0[kk], r1[kk]), k
+        assert np.allclose(r0[kk], v, rtol=0, atol=2e-3), (k, np.abs(r0[kk] - v).max())     # (6 Adam steps at lr 1e-3)
+    files = sorted(os.listdir(tmp_path))
+    assert "best_rank0.h5" in files and "model_rank0.json" in files and "weights_rank0.h5" in files
+    assert not any("rank1." in f and not f.startswith("rank1.npz") for f in files), files
 
 
 def _bench_in_clean_process(tmp_path, argv, timeout):
