@@ -11,6 +11,8 @@
 int mgr_scan_fwd_simple(mgr_ctx*, const float*, const float*, float*, int, const float*, int, float*, float*, int, int, int, int);
 int mgr_scan_bwd_simple(mgr_ctx*, const float*, int, const float*, const float*, const float*, float*, int, int, int, int);
 int mgr_scan_bwd_mfma_multi(mgr_ctx*, int, const mgr_scan_bwd_job*, int);
+bool mgr_scan_cu_supported(int H);
+int mgr_scan_cu_fwd_launch(mgr_ctx*, int, const mgr_scan_job*, unsigned*, unsigned);
 
 namespace {
 
@@ -229,6 +231,27 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
   }
   int r = mgr_prof_begin(c, MGR_K_SCAN_FWD);
   if (r) return r;
+  // tune key 12: narrow layers (H <= 128 with an instantiation) run the CU-owning single-CU kernel (lstm_cu.hip): one workgroup
+  // per (direction, batch group) that wants a whole CU - the caller orders the launch so that free CUs exist
+  if (c->tune[12] && ws && ws_bytes >= kScanHdrBytes) {
+    bool ok = mgr_scan_cu_supported(jobs[0].H);
+    int wgs = 0;
+    for (int i = 0; i < njobs && ok; ++i) {
+      const mgr_scan_job& j = jobs[i];
+      ok = j.H == jobs[0].H && !j.R && !j.YT && (!j.gates == !j.cs) && (size_t)j.B * j.T * 4 * j.H * sizeof(float) < ((size_t)1 << 31) &&
+           (size_t)j.B * j.T * j.ldy * sizeof(float) < ((size_t)1 << 31);
+      wgs += (j.B + 15) / 16;
+    }
+    if (ok && wgs <= c->cu_count) {
+      MGR_HIP(hipMemsetAsync(ws, 0, kScanHdrBytes, mgr_stream(c)));
+      r = mgr_scan_cu_fwd_launch(c, njobs, jobs, reinterpret_cast<unsigned*>(ws), ++c->persist_seq);
+      if (r) return r;
+      r = mgr_prof_end(c, MGR_K_SCAN_FWD);
+      if (r) return r;
+      if (c->tune[1]) return check_launch_status(c, reinterpret_cast<unsigned*>(ws), "single-CU scan");
+      return 0;
+    }
+  }
   Plan P;
   make_plan(c, njobs, jobs, P);
   if (P.any && (!ws || ws_bytes < mgr_lstm_scan_multi_ws_bytes(njobs, jobs))) {
@@ -328,11 +351,6 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     if (P.exchange) {
       r = mgr_persist_admit(c, P.total, waves, per_cu, &L.cm.seq);
       if (r) return r;
-    } else if (c->tune[12]) {
-      // tune key 12: workgroups of a launch without an exchange take a CU of their own (LDS request) and the launch gets a sequence
-      // number, so that another stream can wait until it is resident (mgr_stream_wait_last_resident)
-      L.own_cu = 1;
-      L.cm.seq = ++c->persist_seq;
     }
     // exchange slots + status must be zero at every launch (epochs count from 1 within the call)
     MGR_HIP(hipMemsetAsync(base, 0, (size_t)(w - base), mgr_stream(c)));

@@ -52,7 +52,6 @@ struct ClusterLaunch {
   ClusterCommon cm;
   int njobs;
   int ksplit;        // one-tile-per-wave clusters use the K-split step (cluster_run_ks: register-direct gather); 0 = LDS-image step
-  int own_cu;        // launches without an exchange: request enough LDS that a workgroup shares its CU with no other LDS user
   int xcd_local;     // K-split launches: clusters are laid out on workgroup ids congruent mod 8 (one XCD under the dispatcher's
                      // round-robin); a cluster that FINDS all its members on one XCD publishes with plain stores into that L2
   ClusterJob job[MGR_MAX_SCAN_JOBS];

@@ -694,7 +694,6 @@ int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool a
   int waves, per_cu;
   mgr_cluster_geometry(L, any_exchange, &waves, &per_cu);
   size_t lds = image_lds(L);
-  if (L.own_cu && lds < 120 * 1024) lds = 120 * 1024;
   if (any_exchange) {
     // co-residency of every spinning workgroup is what makes the in-launch hand-off deadlock-free; a workgroup that must sit
     // alone on its CU says so through its LDS request
