@@ -116,7 +116,6 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the next step's frozen-encoder pass")
     ap.add_argument("--scan-path", type=int, default=0, help="0 auto, 3/4 clusters of 4/8 tiles per workgroup")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--exclusive-narrow", action="store_true", help="narrow trainable layer: single-CU scans on CUs of their own")
     ap.add_argument("--no-transposed", action="store_true", help="dropout-aware projections gather columns of the row-major input")
     ap.add_argument("--cpu-T", type=int, default=0, help="T of the CPU leg's sample; 0 (default) = the configuration's own T: the full step")
     ap.add_argument("--cpu-B", type=int, default=0, help="batch of the CPU leg's sample; 0 (default) = the configuration's own")
@@ -167,9 +166,6 @@ def main():
         dev.call("mgr_tune", 2, 1)
     if args.scan_path:
         dev.call("mgr_tune", 0, args.scan_path)
-    if args.exclusive_narrow:
-        dev.call("mgr_tune", 0, 6)
-        dev.call("mgr_tune", 12, 1)
 
     comm = None
     if world > 1:
@@ -184,7 +180,7 @@ def main():
 
     from mgr_amd.engine import Schedule
     eng = Engine(spec, B, T, Lmax, device=dev, seed=1000 + rank, comm=comm, world=world,
-                 schedule=Schedule(transposed_inputs=not args.no_transposed, exclusive_narrow_scans=args.exclusive_narrow))
+                 schedule=Schedule(transposed_inputs=not args.no_transposed))
     eng.set_weights(synthetic_weights(spec, 20131900 + 3))
     xs, labels, il, ll = synthetic_arrays(spec, B, T, Lmax, 20131900 + 3 + 17 * rank)
     eng._upload_inputs(xs, None, True)

@@ -156,9 +156,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
  *        XCD-local exchange).
  * key 7: one-tile-per-wave clusters: 0 = K-split step (register-direct gather), 1 = LDS-image step.
  * key 8: 1 = the multi-CU BPTT keeps its 4-wave kernel instead of the split-role (4 compute + 4 gather waves) one, 2 = always split.
- * key 9: 1 = mgr_lstm_input_proj_dropout always takes the dense kernel.
- * key 0 value 6: layers with H <= 128 run one workgroup per batch group (no inter-CU exchange), wider ones as planned.
- * key 12: 1 = workgroups of a scan launch without an exchange request a CU of their own (LDS) and the launch reports residency. */
+ * key 9: 1 = mgr_lstm_input_proj_dropout always takes the dense kernel. */
 enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 16 };
 int mgr_tune(mgr_ctx* ctx, int key, int value);
 /* Health of the persistent multi-CU scans launched on this context since the last mgr_scan_status_clear: *out receives the OR
@@ -195,9 +193,6 @@ int mgr_update_gate_set(mgr_ctx* ctx, const float* flag);
  * persistent scan launched on this context (on any stream) has started, or timeout_us (<= 100000) has passed.  Chip-filling
  * GEMMs enqueued behind it therefore arrive when the scan is resident instead of racing its workgroups for the CUs. */
 int mgr_stream_wait_next_resident(mgr_ctx* ctx, int timeout_us);
-/* The same for the persistent / CU-owning scan launched LAST on this context (already enqueued, on any stream): the encoder
- * scans of the next step wait with it until the narrow trainable layer's single-CU scan (tune key 12) holds its CUs. */
-int mgr_stream_wait_last_resident(mgr_ctx* ctx, int timeout_us);
 /* Persistent launches on different streams are admitted against the chip's workgroup slots; one that would not fit beside the
  * launches still in flight is ordered behind them (co-residency by construction).  Counters: launches so far, and how many of
  * them had to be serialised that way. */

@@ -10,9 +10,7 @@
 
 int mgr_scan_fwd_simple(mgr_ctx*, const float*, const float*, float*, int, const float*, int, float*, float*, int, int, int, int);
 int mgr_scan_bwd_simple(mgr_ctx*, const float*, int, const float*, const float*, const float*, float*, int, int, int, int);
-int mgr_scan_bwd_mfma_multi(mgr_ctx*, int, const mgr_scan_bwd_job*, int);
-bool mgr_scan_cu_supported(int H);
-int mgr_scan_cu_fwd_launch(mgr_ctx*, int, const mgr_scan_job*, unsigned*, unsigned);
+int mgr_scan_bwd_mfma_multi(mgr_ctx*, int, const mgr_scan_bwd_job*);
 
 namespace {
 
@@ -78,7 +76,6 @@ void make_plan(const mgr_ctx* c, int njobs, const mgr_scan_job* jobs, Plan& P) {
       if (path == 3 && cur[k] != 0) feas = false;
       if (path == 4 && cur[k] != 1) feas = false;
       if (path == 2 && (f.nw * f.tpw < ks)) feas = false;  // force single-CU (no exchange)
-      if (path == 6 && j.H <= 128 && (f.nw * f.tpw < ks)) feas = false;  // narrow layers only: single-CU, wide ones as planned
       int tiles = f.nw * f.tpw;
       int G = (ks + tiles - 1) / tiles;
       if (G > 64) feas = false;
@@ -231,27 +228,6 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
   }
   int r = mgr_prof_begin(c, MGR_K_SCAN_FWD);
   if (r) return r;
-  // tune key 12: narrow layers (H <= 128 with an instantiation) run the CU-owning single-CU kernel (lstm_cu.hip): one workgroup
-  // per (direction, batch group) that wants a whole CU - the caller orders the launch so that free CUs exist
-  if (c->tune[12] && ws && ws_bytes >= kScanHdrBytes) {
-    bool ok = mgr_scan_cu_supported(jobs[0].H);
-    int wgs = 0;
-    for (int i = 0; i < njobs && ok; ++i) {
-      const mgr_scan_job& j = jobs[i];
-      ok = j.H == jobs[0].H && !j.R && !j.YT && (!j.gates == !j.cs) && (size_t)j.B * j.T * 4 * j.H * sizeof(float) < ((size_t)1 << 31) &&
-           (size_t)j.B * j.T * j.ldy * sizeof(float) < ((size_t)1 << 31);
-      wgs += (j.B + 15) / 16;
-    }
-    if (ok && wgs <= c->cu_count) {
-      MGR_HIP(hipMemsetAsync(ws, 0, kScanHdrBytes, mgr_stream(c)));
-      r = mgr_scan_cu_fwd_launch(c, njobs, jobs, reinterpret_cast<unsigned*>(ws), ++c->persist_seq);
-      if (r) return r;
-      r = mgr_prof_end(c, MGR_K_SCAN_FWD);
-      if (r) return r;
-      if (c->tune[1]) return check_launch_status(c, reinterpret_cast<unsigned*>(ws), "single-CU scan");
-      return 0;
-    }
-  }
   Plan P;
   make_plan(c, njobs, jobs, P);
   if (P.any && (!ws || ws_bytes < mgr_lstm_scan_multi_ws_bytes(njobs, jobs))) {
@@ -414,7 +390,7 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
     nbg[i] = (j.B + 15) / 16;
     // (the cluster kernel addresses the saved state with 32-bit byte offsets per lane: LDS-DMA prefetch)
     const bool small = (size_t)j.B * j.T * j.H * 16 < ((size_t)1 << 32) && (size_t)j.B * j.T * j.lddy * 4 < ((size_t)1 << 32);
-    use_cluster[i] = (path == 0 || path == 3 || (path == 6 && j.H > 128)) && mgr_cluster_bwd_supported(j.H) && small;
+    use_cluster[i] = (path == 0 || path == 3) && mgr_cluster_bwd_supported(j.H) && small;
     if (use_cluster[i]) total += ((j.H + 15) / 16) * nbg[i];
   }
   if (total + 8 * njobs > 2 * c->cu_count)
@@ -473,7 +449,7 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
       ++rest;
     }
     if (rest > 0 && same && path != 1) {
-      r = mgr_scan_bwd_mfma_multi(c, rest, left, c->tune[12]);
+      r = mgr_scan_bwd_mfma_multi(c, rest, left);
       if (r < 0) return r;
       mfma_done = r == 1;
     }
@@ -482,7 +458,7 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
     if (use_cluster[i] || mfma_done) continue;
     const mgr_scan_bwd_job& j = jobs[i];
     r = 0;
-    if (path != 1) r = mgr_scan_bwd_mfma_multi(c, 1, &j, 0);
+    if (path != 1) r = mgr_scan_bwd_mfma_multi(c, 1, &j);
     if (r == 0) {
       float* UpT = reinterpret_cast<float*>(wj[i]);
       r = mgr_transpose(c, j.Up, UpT, j.H, 4 * j.H);
@@ -590,13 +566,6 @@ extern "C" {
 int mgr_stream_wait_next_resident(mgr_ctx* c, int timeout_us) {
   MGR_REQUIRE(c && timeout_us >= 0 && timeout_us <= 100000, "timeout_us must be in [0, 100000]");
   hipLaunchKernelGGL(k_wait_resident, dim3(1), dim3(1), 0, mgr_stream(c), c->sticky_status + 1, c->persist_seq + 1, (unsigned)timeout_us);
-  MGR_LAUNCH_CHECK();
-  return 0;
-}
-
-int mgr_stream_wait_last_resident(mgr_ctx* c, int timeout_us) {
-  MGR_REQUIRE(c && timeout_us >= 0 && timeout_us <= 100000, "timeout_us must be in [0, 100000]");
-  hipLaunchKernelGGL(k_wait_resident, dim3(1), dim3(1), 0, mgr_stream(c), c->sticky_status + 1, c->persist_seq, (unsigned)timeout_us);
   MGR_LAUNCH_CHECK();
   return 0;
 }

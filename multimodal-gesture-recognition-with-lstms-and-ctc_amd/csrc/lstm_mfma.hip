@@ -148,8 +148,8 @@ __global__ __launch_bounds__(NW * 64) void k_scan_bwd_mfma(BwdMfmaJobs J, int ld
 }  // namespace
 
 // returns 1 if launched, 0 if the shape has no instantiation, <0 on error.  All jobs (same H, B, T, lddy) go out as ONE launch
-// (blockIdx.y = job); own_cu: request so much LDS that nothing else with an LDS footprint shares the workgroup's CU
-int mgr_scan_bwd_mfma_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs, int own_cu) {
+// (blockIdx.y = job): the two directions of a layer run side by side instead of one after the other
+int mgr_scan_bwd_mfma_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs) {
   BwdMfmaJobs J;
   memset(&J, 0, sizeof(J));
   const int B = jobs[0].B, T = jobs[0].T, H = jobs[0].H, lddy = jobs[0].lddy;
@@ -159,11 +159,9 @@ int mgr_scan_bwd_mfma_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
   }
   dim3 grid((B + 15) / 16, njobs);
   hipStream_t s = mgr_stream(c);
-  const size_t dyn = own_cu ? 64 * 1024 : 0;
 #define BWD_CASE(HH)                                                                                              \
   case HH:                                                                                                        \
-    if (own_cu) MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_bwd_mfma<HH>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024)); \
-    hipLaunchKernelGGL((k_scan_bwd_mfma<HH>), grid, dim3(NW * 64), dyn, s, J, lddy, B, T); \
+    hipLaunchKernelGGL((k_scan_bwd_mfma<HH>), grid, dim3(NW * 64), 0, s, J, lddy, B, T); \
     break;
   switch (H) {
     BWD_CASE(4)

@@ -84,9 +84,8 @@ class Schedule:
     """
 
     def __init__(self, pipeline=True, defer_param_grads=True, encoders_run_ahead=True, resident_wait_us=2000,
-                 transposed_inputs=True, exclusive_narrow_scans=False):
+                 transposed_inputs=True):
         self.transposed_inputs = bool(transposed_inputs)
-        self.exclusive_narrow_scans = bool(exclusive_narrow_scans)
         self.pipeline = bool(pipeline)
         self.defer_param_grads = bool(defer_param_grads)
         self.encoders_run_ahead = bool(encoders_run_ahead)
@@ -1054,10 +1053,6 @@ class Engine:
                 if ahead and k == 0:
                     dev.stream(ES)
                     dev.wait_event(ES, self.EV_FPROJ)
-                    if self.schedule.exclusive_narrow_scans:
-                        # the fusion layer's single-CU scan (enqueued above, on stream 0, right behind those projections) takes
-                        # its CUs before the 408 encoder workgroups arrive
-                        dev.call("mgr_stream_wait_last_resident", 300)
                 if k == depth - 1:
                     dev.wait(0, ES)
                     dev.stream(0)
