@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the next step's frozen-encoder pass")
     ap.add_argument("--scan-path", type=int, default=0, help="0 auto, 3/4 clusters of 4/8 tiles per workgroup")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], help="KEY=VALUE for mgr_tune (A/B of kernel variants; may be repeated)")
     ap.add_argument("--no-transposed", action="store_true", help="dropout-aware projections gather columns of the row-major input")
     ap.add_argument("--cpu-T", type=int, default=0, help="T of the CPU leg's sample; 0 (default) = the configuration's own T: the full step")
     ap.add_argument("--cpu-B", type=int, default=0, help="batch of the CPU leg's sample; 0 (default) = the configuration's own")
@@ -166,6 +167,9 @@ def main():
         dev.call("mgr_tune", 2, 1)
     if args.scan_path:
         dev.call("mgr_tune", 0, args.scan_path)
+    for kv in args.tune:
+        k, v = kv.split("=")
+        dev.call("mgr_tune", int(k), int(v))
 
     comm = None
     if world > 1:

@@ -156,7 +156,8 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
  *        XCD-local exchange).
  * key 7: one-tile-per-wave clusters: 0 = K-split step (register-direct gather), 1 = LDS-image step.
  * key 8: 1 = the multi-CU BPTT keeps its 4-wave kernel instead of the split-role (4 compute + 4 gather waves) one, 2 = always split.
- * key 9: 1 = mgr_lstm_input_proj_dropout always takes the dense kernel. */
+ * key 9: 1 = mgr_lstm_input_proj_dropout always takes the dense kernel.
+ * key 13: 1 = mgr_dense_softmax_fwd / mgr_dense_bwd keep their LDS-tiled vector-ALU kernels where the matrix-core forms would run. */
 enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 16 };
 int mgr_tune(mgr_ctx* ctx, int key, int value);
 /* Health of the persistent multi-CU scans launched on this context since the last mgr_scan_status_clear: *out receives the OR
@@ -262,6 +263,16 @@ size_t mgr_dense_bwd_ws_bytes(int B, int T, int D, int C);
 int mgr_dense_bwd(mgr_ctx* ctx, const float* A, int lda, const float* dmask, float p, uint64_t seed,
                   const float* dLogits, const float* Wd, float* dWd, float* dbd, float* dA, int ldda, int B,
                   int T, int D, int C, void* ws, size_t ws_bytes);
+/* The whole head of a training step in ONE call: Dropout -> Dense -> softmax (P written), CTC loss + gradient, Dense backward, and the
+ * mean loss if loss_mean != NULL (written between the CTC kernel and the Dense backward, so a read-back of it does not wait for the
+ * backward).  Reference: multimodal_fusion/multimodal.py:171-179 (Dropout / Dense / Activation('softmax')), losses.py:4-15
+ * (ctc_lambda_func) and Keras' backward pass through them.  Bit for bit the results of mgr_dense_softmax_fwd + mgr_ctc_loss_grad
+ * (+ mgr_mean) + mgr_dense_bwd with the same arguments; dLogits [B,T,C] is a required scratch / output; ws >= mgr_head_ws_bytes. */
+size_t mgr_head_ws_bytes(int B, int T, int D, int C, int Lmax);
+int mgr_head_fwd_bwd(mgr_ctx* ctx, const float* A, int lda, const float* dmask, float p, uint64_t seed, const float* Wd, const float* bd,
+                     const int32_t* labels, const int32_t* input_len, const int32_t* label_len, int B, int T, int D, int C, int Lmax,
+                     int skip, int blank, float eps, float gscale, float* P, float* loss, float* loss_mean, float* dLogits, float* dWd,
+                     float* dbd, float* dA, int ldda, void* ws, size_t ws_bytes);
 
 /* ---- K6: ctc_lambda_func (multimodal_fusion/losses.py:4-15 -> K.ctc_batch_cost -> tf.nn.ctc_loss) ---- */
 /* CTC on P[:, skip:, :] with y = softmax(log(P+eps)); labels int32 [B,Lmax] padded -1; blank = C-1 in the

@@ -85,6 +85,9 @@ SIGNATURES = {
     "mgr_dense_softmax_fwd": (i32, [vp, vp, i32, vp, C.c_float, u64, vp, vp, vp, i32, i32, i32, i32]),
     "mgr_dense_bwd_ws_bytes": (sz, [i32, i32, i32, i32]),
     "mgr_dense_bwd": (i32, [vp, vp, i32, vp, C.c_float, u64, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz]),
+    "mgr_head_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "mgr_head_fwd_bwd": (i32, [vp, vp, i32, vp, C.c_float, u64, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.c_float, C.c_float,
+                               vp, vp, vp, vp, vp, vp, vp, i32, vp, sz]),
     "mgr_ctc_ws_bytes": (sz, [i32, i32, i32, i32]),
     "mgr_ctc_loss_grad": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_float, C.c_float, vp, vp, vp, sz]),
     "mgr_adam_step": (i32, [vp, vp, vp, vp, vp, sz, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),

@@ -34,6 +34,25 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
   return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
 }
 
+// Cross-lane traffic of the recursions through DPP (one v_mov_b32_dpp, a few cycles) instead of __shfl_* (a ds_bpermute round trip
+// through the LDS crossbar, ~100 cycles, on the serial chain of every time step): wave_shr:1 / wave_shl:1 move a value to the
+// next / previous lane of the whole wave; lanes without a source receive `fill`.
+constexpr int DPP_WAVE_SHR1 = 0x138, DPP_WAVE_SHL1 = 0x130;
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v, float fill) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// wave-wide maximum: DPP within the rows of 16 lanes, then the four row results through v_readlane (uniform)
+__device__ __forceinline__ float wave_max_f32(float m) {
+  m = fmaxf(m, dpp_f32<0x111>(m, m));   // row_shr:1 (lanes without a source keep their own value)
+  m = fmaxf(m, dpp_f32<0x112>(m, m));
+  m = fmaxf(m, dpp_f32<0x114>(m, m));
+  m = fmaxf(m, dpp_f32<0x118>(m, m));   // lane 15 of a row holds the row's maximum
+  const int i = __float_as_int(m);
+  return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 15)), __int_as_float(__builtin_amdgcn_readlane(i, 31))),
+               fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 47)), __int_as_float(__builtin_amdgcn_readlane(i, 63))));
+}
+
 template <int PPL>
 struct Chunk {
   static constexpr int CH = (8 / PPL) >= 2 ? (8 / PPL) : 2;
@@ -134,8 +153,7 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
         for (int k = 0; k < CH; ++k) {
           int t = t0 + k;
           if (t < Tp) {
-            float carry = __shfl_up(al[PPL - 1], 1);
-            if (lane == 0) carry = kNegInf;
+            const float carry = dpp_f32<DPP_WAVE_SHR1>(al[PPL - 1], kNegInf);   // (lane 0: log 0)
             float nb[PPL], nl[PPL];
 #pragma unroll
             for (int j = 0; j < PPL; ++j) {
@@ -159,7 +177,7 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
           float m = kNegInf;
 #pragma unroll
           for (int j = 0; j < PPL; ++j) m = fmaxf(m, fmaxf(ab[j], al[j]));
-          for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+          m = wave_max_f32(m);
           if (m != kNegInf) {
 #pragma unroll
             for (int j = 0; j < PPL; ++j) {
@@ -232,12 +250,8 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
               xb[j] = vb[j] ? bb[j] + cur.eb[k] : kNegInf;
               xl[j] = vl[j] ? bl[j] + cur.el[k][j] : kNegInf;
             }
-            float nxb = __shfl_down(xb[0], 1);
-            float nxl = __shfl_down(xl[0], 1);
-            if (lane == 63) {
-              nxb = kNegInf;
-              nxl = kNegInf;
-            }
+            const float nxb = dpp_f32<DPP_WAVE_SHL1>(xb[0], kNegInf);   // (lane 63: log 0)
+            const float nxl = dpp_f32<DPP_WAVE_SHL1>(xl[0], kNegInf);
 #pragma unroll
             for (int j = 0; j < PPL; ++j) {
               float b1 = (j < PPL - 1) ? xb[j + 1] : nxb;  // blank of pair p+1 (state u+1 for the label state)
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
           float m = kNegInf;
 #pragma unroll
           for (int j = 0; j < PPL; ++j) m = fmaxf(m, fmaxf(bb[j], bl[j]));
-          for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+          m = wave_max_f32(m);
           if (m != kNegInf) {
 #pragma unroll
             for (int j = 0; j < PPL; ++j) {

@@ -426,12 +426,11 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
 
   for (int step = 0; step < T; ++step) {
     const int t = reverse ? T - 1 - step : step;
+    // (no per-step zeroing of the 32 gather registers and the 16 accumulators: vector instructions do not overlap with this
+    // SIMD's MFMAs - profiles/r04_single_cu_probes.txt - so every v_mov of a step is step time; the first MFMA of each
+    // accumulator takes a literal zero instead)
     f32x4 acc[4];
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     u32x4 v[NBW];
-#pragma unroll
-    for (int i = 0; i < NBW; ++i) v[i] = (u32x4){0u, 0u, 0u, 0u};
     const bool gather = step > 0 && nb > 0 && !failed;
     if (gather) {
       const int slot = (step - 1) & 1;
@@ -457,7 +456,6 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
     // Z / R of the NEXT step leave BEHIND the gather (an HBM miss in front of it would hold the gathered blocks - L2 hits - back
     // for the length of the miss: memory operations complete in issue order), from inside the MFMA chain: the matrix pipe is
     // busy anyway, the eight scalar / vector-memory instructions of the two DMAs cost nothing there
-    if (!(gather && !failed)) prefetch(step + 1);
     if (gather && !failed) {
 #pragma unroll
       for (int i = 0; i < NBW; ++i) {
@@ -466,10 +464,16 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
-          for (int tt = 0; tt < 4; ++tt)   // k-steps / blocks that do not exist carry zero weights
-            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[tt][i * 4 + r], hv[r], acc[tt], 0, 0, 0);
+          for (int tt = 0; tt < 4; ++tt) {   // k-steps / blocks that do not exist carry zero weights
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[tt][i * 4 + r], hv[r], (i == 0 && r == 0) ? zero : acc[tt], 0, 0, 0);
+          }
         }
       }
+    } else {   // the first step (h_{-1} = 0), a wave without K range, a launch that gave up
+      prefetch(step + 1);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     // the four partial sums of every tile meet in LDS (double-buffered on the step parity: one barrier per step)
     float* rbuf = red + (step & 1) * (16 * 64 * 4);

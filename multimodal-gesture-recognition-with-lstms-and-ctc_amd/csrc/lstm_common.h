@@ -6,10 +6,11 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float mgr_hsig(float z) { return fminf(fmaxf(0.2f * z + 0.5f, 0.f), 1.f); }
-// tanh via one v_exp_f32 + one v_rcp_f32: |abs err| ~1e-7, saturates cleanly to +-1
+// tanh via one v_exp_f32 + one v_rcp_f32 (1 ulp; __frcp_rn would be the ten-instruction IEEE division sequence, and vector
+// instructions are step time in the scans: they do not overlap with the SIMD's MFMAs): |abs err| ~1e-7, saturates cleanly to +-1
 __device__ __forceinline__ float mgr_tanh(float x) {
   float e = __expf(2.f * x);
-  return 1.f - 2.f * __frcp_rn(e + 1.f);
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 __device__ __forceinline__ float mgr_hsig_grad(float a) { return (a > 0.f && a < 1.f) ? 0.2f : 0.f; }
 

@@ -262,6 +262,7 @@ class Engine:
                              for _ in range(2)]
             self.ws_ctc = dev.bytes(self.lib.mgr_ctc_ws_bytes(B, T, Cn, self.Lmax))
             self.ws_dense = dev.bytes(self.lib.mgr_dense_bwd_ws_bytes(B, T, D, Cn))
+            self.ws_head = dev.bytes(self.lib.mgr_head_ws_bytes(B, T, D, Cn, self.Lmax))
         self.dev.sync()
 
     def _wview(self, name):
@@ -534,8 +535,9 @@ class Engine:
                          B * T, 2 * H)
         self.rng_step = saved_step
 
-    def _enqueue_fusion_head(self, train, rand, feat_buf, rng_step):
-        """Fusion BiLSTM (projection GEMMs + recurrences) and Dropout/Dense/softmax on stream 0."""
+    def _enqueue_fusion_head(self, train, rand, feat_buf, rng_step, dense=True):
+        """Fusion BiLSTM (projection GEMMs + recurrences) and Dropout/Dense/softmax on stream 0 (dense=False: the caller runs
+        the Dense layer itself - the training step's mgr_head_fwd_bwd)."""
         sp, dev, B, T = self.spec, self.dev, self.B, self.T
         W = sp.concat_width
         save = train and not self.inference_only
@@ -578,8 +580,9 @@ class Engine:
         elif train and p_head > 0:
             self._head_seed = self._seed(999)
         self._head_args = (hm, p_head, self._head_seed)
-        dev.call("mgr_dense_softmax_fwd", feat, ldf, hm, p_head, C.c_uint64(self._head_seed),
-                 self._wview("dense/W"), self._wview("dense/b"), self.P, B, T, D, Cn)
+        if dense:
+            dev.call("mgr_dense_softmax_fwd", feat, ldf, hm, p_head, C.c_uint64(self._head_seed),
+                     self._wview("dense/W"), self._wview("dense/b"), self.P, B, T, D, Cn)
         self._feat = (feat, ldf)
         self.rng_step = saved_step
 
@@ -957,44 +960,42 @@ class Engine:
             else:
                 dev.wait(ES, 0)
         # ---- 2. fusion layer, head, CTC, loss read-back point
-        self._enqueue_fusion_head(True, rand, cur, self.rng_step)
+        self._enqueue_fusion_head(True, rand, cur, self.rng_step, dense=False)
         self.rng_step += 1
         Cn, D = sp.num_classes, sp.head_width
         dev.stream(0)
-        dev.call("mgr_ctc_loss_grad", self.P, self.labels_d, self.ilen_d, self.llen_d, B, T, Cn, self.Lmax,
-                 int(sp.ctc["skip"]), Cn - 1, float(sp.ctc["eps"]), 1.0 / B, self.loss_b, self.dLogits,
-                 self.ws_ctc, self.ws_ctc.nbytes)
-        dev.call("mgr_mean", self.loss_b, B, self.loss_mean)
-        if self.comm is not None:
-            dev.call("mgr_mean", self.loss_b, B, self.loss_slot)   # travels with the gradient all-reduce (apply_gradients)
-        dev.record(self.EV_LAB[self._lab_slot])
-        # The loss and this engine's scan status go to page-locked host words from THIS stream, an event behind them: the host
-        # polls that event (read_loss) while the backward pass queued behind it runs.  Round 2 read them on a stream of their own
-        # that waited for stream 0 - a copy on an otherwise idle hardware queue now and then started 20-45 ms after the event
-        # it waited for (one step in ten of a 5 ms step; profiles/r03_loss_readback_stall.txt).
-        dev.d2h_async(self.loss_host, self.loss_mean)
-        dev.d2h_async(self.status_host, self.status)
-        dev.record(self.EV_LOSS)
-        this_step = self._step_id
-        self._step_id += 1
-        self._lab_user[self._lab_slot] = this_step
-        any_tr_stream = any(s["trainable"] for s in sp.streams)
-        if have is None:   # this step's own inputs (a prefetched set was tagged when it was uploaded)
-            # trainable first layers read them again in their dW GEMMs, which only the NEXT step's loss read-back covers
-            self._xin_user[self._xin_slot] = this_step + (1 if any_tr_stream else 0)
-        # ---- 3. backward
         feat, ldf = self._feat
         hm, p_head, hseed = self._head_args
         W = sp.concat_width
+        any_tr_stream = any(s["trainable"] for s in sp.streams)
         if sp.fusion:
             dA, ldda = self.dYF, 2 * sp.fusion["H"]
         elif any_tr_stream:
             dA, ldda = self.dFEAT, W
         else:
             dA, ldda = 0, D
-        dev.call("mgr_dense_bwd", feat, ldf, hm, p_head, C.c_uint64(hseed), self.dLogits, self._wview("dense/W"),
-                 self._gview("dense/W"), self._gview("dense/b"), dA, ldda, B, T, D, Cn, self.ws_dense,
-                 self.ws_dense.nbytes)
+        # the whole head in one call (mgr.h): Dropout / Dense / softmax, CTC loss + gradient, the mean loss, Dense backward
+        dev.call("mgr_head_fwd_bwd", feat, ldf, hm, p_head, C.c_uint64(hseed), self._wview("dense/W"), self._wview("dense/b"),
+                 self.labels_d, self.ilen_d, self.llen_d, B, T, D, Cn, self.Lmax, int(sp.ctc["skip"]), Cn - 1, float(sp.ctc["eps"]),
+                 1.0 / B, self.P, self.loss_b, self.loss_mean, self.dLogits, self._gview("dense/W"), self._gview("dense/b"),
+                 dA, ldda, self.ws_head, self.ws_head.nbytes)
+        if self.comm is not None:
+            dev.call("mgr_mean", self.loss_b, B, self.loss_slot)   # travels with the gradient all-reduce (apply_gradients)
+        dev.record(self.EV_LAB[self._lab_slot])
+        # The loss and this engine's scan status go to page-locked host words from THIS stream, an event behind them: the host
+        # polls that event (read_loss) while the rest of the backward pass queued behind it runs.  Round 2 read them on a stream
+        # of their own that waited for stream 0 - a copy on an otherwise idle hardware queue now and then started 20-45 ms after
+        # the event it waited for (one step in ten of a 5 ms step; profiles/r03_loss_readback_stall.txt).
+        dev.d2h_async(self.loss_host, self.loss_mean)
+        dev.d2h_async(self.status_host, self.status)
+        dev.record(self.EV_LOSS)
+        this_step = self._step_id
+        self._step_id += 1
+        self._lab_user[self._lab_slot] = this_step
+        if have is None:   # this step's own inputs (a prefetched set was tagged when it was uploaded)
+            # trainable first layers read them again in their dW GEMMs, which only the NEXT step's loss read-back covers
+            self._xin_user[self._xin_slot] = this_step + (1 if any_tr_stream else 0)
+        # ---- 3. backward
         deferred = None
         if sp.fusion:
             Hf = sp.fusion["H"]
