@@ -194,6 +194,9 @@ int mgr_update_gate_set(mgr_ctx* ctx, const float* flag);
  * persistent scan launched on this context (on any stream) has started, or timeout_us (<= 100000) has passed.  Chip-filling
  * GEMMs enqueued behind it therefore arrive when the scan is resident instead of racing its workgroups for the CUs. */
 int mgr_stream_wait_next_resident(mgr_ctx* ctx, int timeout_us);
+/* The same for ONE given launch: `seq` is the context's count of persistent launches (mgr_persist_stats: `launches`) read right
+ * before that launch was enqueued, plus one.  Lets a stream wait for a launch that is already enqueued on another stream. */
+int mgr_stream_wait_resident(mgr_ctx* ctx, unsigned seq, int timeout_us);
 /* Persistent launches on different streams are admitted against the chip's workgroup slots; one that would not fit beside the
  * launches still in flight is ordered behind them (co-residency by construction).  Counters: launches so far, and how many of
  * them had to be serialised that way. */

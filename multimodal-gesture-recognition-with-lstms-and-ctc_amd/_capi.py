@@ -69,6 +69,7 @@ SIGNATURES = {
     "mgr_update_gate_eval": (i32, [vp, C.c_uint, vp]),
     "mgr_update_gate_set": (i32, [vp, vp]),
     "mgr_stream_wait_next_resident": (i32, [vp, i32]),
+    "mgr_stream_wait_resident": (i32, [vp, C.c_uint, i32]),
     "mgr_persist_stats": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
     "mgr_skeletal_features": (i32, [vp, vp, sz, vp]),
     "mgr_lstm_scan_bwd_multi_ws_bytes": (sz, [i32, vp]),

@@ -20,7 +20,7 @@ namespace {
 
 constexpr int MAXW = 32;   // beam width limit
 constexpr int MAXC = 64;   // classes limit
-constexpr int KMAX = 34;   // candidates per lane: ceil(MAXW*(MAXC+1)/64)
+constexpr int KMAX = 34;   // candidates per lane at the limits: ceil(MAXW*(MAXC+1)/64); the kernel is instantiated for 4 / 12 / 34
 constexpr double kNegInfD = -__builtin_huge_val();
 
 __device__ __forceinline__ double lse64(double a, double b) {
@@ -37,6 +37,9 @@ __device__ __forceinline__ double shfl_xor_d(double v, int o) {
   return __hiloint2double(hi, lo);
 }
 
+// KM = candidate scores a lane keeps in registers (64 * KM >= W * (C + 1)).  One size for every shape (34) used 256 VGPRs and
+// spilled 92 bytes of them to scratch memory - also for the reference's own shape (beam 10, 22 classes: 230 candidates, 4 per lane).
+template <int KM>
 __global__ __launch_bounds__(64) void k_beam(const float* __restrict__ P, const int32_t* __restrict__ input_len, int B, int T,
                                              int C, int skip, int blank, int W, float eps, int merge_repeated,
                                              int32_t* __restrict__ out, int32_t* __restrict__ out_len,
@@ -109,10 +112,10 @@ __global__ __launch_bounds__(64) void k_beam(const float* __restrict__ P, const 
     }
     __syncthreads();
     // ---- 3. candidate scores (this lane's slice) and W rounds of arg-max
-    double cs[KMAX];
+    double cs[KM];
     const int ncand = nb * CP1;
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
+    for (int k = 0; k < KM; ++k) {
       int idx = lane + 64 * k;
       double sc = kNegInfD;
       if (idx < ncand) {
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(64) void k_beam(const float* __restrict__ P, const 
       double best = kNegInfD;
       int bidx = 0x7fffffff;
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k) {
+      for (int k = 0; k < KM; ++k) {
         if (k < kused) {
           int idx = lane + 64 * k;
           if (cs[k] > best || (cs[k] == best && cs[k] != kNegInfD && idx < bidx)) {
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(64) void k_beam(const float* __restrict__ P, const 
       if (best == kNegInfD) break;  // wave-uniform
       // the owning lane retires the candidate
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k)
+      for (int k = 0; k < KM; ++k)
         if (lane + 64 * k == bidx) cs[k] = kNegInfD;
       if (lane == 0) {
         int r = bidx / CP1, slot = bidx - r * CP1;
@@ -275,8 +278,17 @@ int mgr_ctc_beam_search(mgr_ctx* c, const float* P, const int32_t* input_len, in
   unsigned long long* table =
       reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + 2 * mgr_align_up((size_t)B * nodes * sizeof(int32_t), 256));
   mgr_prof_begin(c, MGR_K_MISC);
-  hipLaunchKernelGGL(k_beam, dim3(B), dim3(64), 0, mgr_stream(c), P, input_len, B, T, C, skip, blank, beam, eps,
-                     merge_repeated, out, out_len, logp, parent, label, nodes, table, beam_table_bits(nodes));
+  const int per_lane = (beam * (C + 1) + 63) / 64;
+#define MGR_BEAM_LAUNCH(KM)                                                                                        \
+  hipLaunchKernelGGL(k_beam<KM>, dim3(B), dim3(64), 0, mgr_stream(c), P, input_len, B, T, C, skip, blank, beam, eps, \
+                     merge_repeated, out, out_len, logp, parent, label, nodes, table, beam_table_bits(nodes))
+  if (per_lane <= 4)
+    MGR_BEAM_LAUNCH(4);
+  else if (per_lane <= 12)
+    MGR_BEAM_LAUNCH(12);
+  else
+    MGR_BEAM_LAUNCH(KMAX);
+#undef MGR_BEAM_LAUNCH
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_MISC);
   return 0;

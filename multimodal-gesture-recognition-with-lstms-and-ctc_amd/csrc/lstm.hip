@@ -570,6 +570,13 @@ int mgr_stream_wait_next_resident(mgr_ctx* c, int timeout_us) {
   return 0;
 }
 
+int mgr_stream_wait_resident(mgr_ctx* c, unsigned seq, int timeout_us) {
+  MGR_REQUIRE(c && timeout_us >= 0 && timeout_us <= 100000, "timeout_us must be in [0, 100000]");
+  hipLaunchKernelGGL(k_wait_resident, dim3(1), dim3(1), 0, mgr_stream(c), c->sticky_status + 16 + (seq & 15u), seq, (unsigned)timeout_us);
+  MGR_LAUNCH_CHECK();
+  return 0;
+}
+
 int mgr_persist_stats(mgr_ctx* c, int* launches, int* serialised) {
   MGR_REQUIRE(c, "null ctx");
   if (launches) *launches = (int)c->persist_seq;

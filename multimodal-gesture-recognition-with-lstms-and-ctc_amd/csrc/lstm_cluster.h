@@ -12,6 +12,7 @@ constexpr size_t kScanHdrBytes = 4096;   //   [64, 1024) XCC (XCD) id + 1 of eve
 // Status block (mgr_ctx::sticky_status, or the block bound with mgr_scan_status_bind; never cleared by a launch):
 //   [0] OR of every launch's status bits since the last mgr_scan_status_clear
 //   [1] (context's own block only) highest launch sequence number whose workgroups have ALL started (mgr_stream_wait_next_resident)
+//   [16, 32) (context's own block only) the same per launch: word 16 + seq % 16 holds seq once launch `seq` is resident
 //   [2] optimizer updates skipped by the update gate since the last clear
 enum : unsigned {
   MGR_ST_GAVE_UP = MGR_SCAN_GAVE_UP,       // a bounded spin expired: a peer workgroup never showed up / never published
@@ -97,7 +98,11 @@ int mgr_persist_commit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu);
 __device__ __forceinline__ void mgr_cluster_enter(const ClusterCommon& cm) {
   if (threadIdx.x == 0) {
     const unsigned n = __hip_atomic_fetch_add(cm.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    if (n == (unsigned)cm.total_wgs) __hip_atomic_fetch_max(cm.resident, cm.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n == (unsigned)cm.total_wgs) {
+      __hip_atomic_fetch_max(cm.resident, cm.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // per-launch residency (mgr_stream_wait_resident): a ring of 16 words behind the context-wide one, slot seq % 16
+      __hip_atomic_fetch_max(cm.resident + 15 + (cm.seq & 15u), cm.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 // XCD-local exchange (forward K-split and BPTT cluster kernels).  Workgroup ids are dealt round-robin over the 8 XCDs (observed,

@@ -439,11 +439,14 @@ class Engine:
                 self.dev.stream(es)
                 self.dev.wait(es, hold_scans_for)
 
-    def _encoder_phases(self, train, rand, feat_buf, es, rng_step):
+    def _encoder_phases(self, train, rand, feat_buf, es, rng_step, first_stream=None, z_first=None):
         """Generator form of the encoder pass: yields ("projected", k) after the projection GEMMs of depth k are enqueued
         (before its scan) and ("scanned", k) after its multi-scan launch, so that a caller can interleave work of another
         stream at those points.  Re-selects stream `es` after every resume; self.rng_step is only switched to `rng_step`
-        while the generator body runs."""
+        while the generator body runs.
+        first_stream / z_first (pipelined inference): the noise kernels and the depth-1 projections are enqueued on stream
+        `first_stream` instead, into the gate pre-activation buffers z_first[name] = (fwd, bwd) instead of the stream's shared
+        Zbuf - the caller orders `es` behind them before it resumes the generator."""
         sp, dev, B, T = self.spec, self.dev, self.B, self.T
         W = sp.concat_width
         save = train and not self.inference_only
@@ -454,7 +457,7 @@ class Engine:
         for s in sp.streams:
             cols[s["name"]] = col
             col += sp.stream_width(s)
-        dev.stream(es)
+        dev.stream(es if first_stream is None else first_stream)
         # GaussianNoise (K1) per stream
         for si, s in enumerate(sp.streams):
             name = s["name"]
@@ -489,12 +492,13 @@ class Engine:
                     slot += 1   # (every projection GEMM fills the chip: one stream keeps their timings honest)
                     mptr = self._prep_mask(L, train, rand, slot)
                     self._masks[(L.prefix, L.d)] = mptr
-                    pair += [mptr, L.Wp, L.bp, self.Zbuf[name][di]]
+                    zb = z_first[name] if (k == 0 and z_first is not None) else self.Zbuf[name]
+                    pair += [mptr, L.Wp, L.bp, zb[di]]
                 self._project_pair(cur, ldcur, pair, Ls_pair, B, T, fin, H, XT=self.Y1T.get(name) if k == 1 else None,
                                    xt_ready=True)
                 for di, dname in enumerate(("fwd", "bwd")):
                     L = self.dirs["%s/l%d/%s" % (name, k, dname)]
-                    Z = self.Zbuf[name][di]
+                    Z = (z_first[name] if (k == 0 and z_first is not None) else self.Zbuf[name])[di]
                     R, ldr = 0, 0
                     YT, ytb = 0, 0      # transposed copy written by the scan itself (what the next dropout layer's GEMMs read)
                     if not last:
@@ -681,6 +685,8 @@ class Engine:
     EV_ENC = (46, 47)     # the encoder pass into FEAT buffer 0 / 1 is complete
     EV_FUSED = (48, 49)   # the fusion / head pass that read FEAT buffer 0 / 1 (and whatever decodes its output) is complete
     EV_OUT = (50, 51)     # the result of the batch in output slot 0 / 1 has reached its pinned host buffer
+    EV_D1P = (55, 56)     # the depth-1 projections into depth-1 Z set 0 / 1 are done (stream 0)
+    EV_D1S = (57, 58)     # the depth-1 scans that read depth-1 Z set 0 / 1 are done (stream ES)
 
     def predict_stream(self, batches, output="posteriors", train_phase=False, beam_width=10, merge_repeated=True):
         """Batches of an inference / validation run are independent of each other: this generator keeps two of them in flight.
@@ -762,29 +768,97 @@ class Engine:
                 r = pins[o].copy()
             return self._nan_if_nonfinite(r)
 
+        # Depth-1 projections of the NEXT batch on stream 0 (round 4).  The cycle of the pipeline is the encoder stream's chain
+        # (depth-1 projections 4.4 | depth-1 scans 8.2 | depth-2 projections 11.0 | depth-2 scans 8.3 ms at config F) while stream 0
+        # idles two thirds of it; with two sets of depth-1 gate pre-activation buffers the projections of batch i + 1 are enqueued
+        # on stream 0 in front of batch i's fusion pass - they run beside batch i's encoder scans - and the encoder stream's chain
+        # loses them.  Same kernels, same inputs per batch: results stay bit-identical to the one-batch-at-a-time calls.
+        two_stage = len(ring) > 1 and max(len(s_["layers"]) for s_ in sp.streams) >= 2
+        z1 = None
+        if two_stage:
+            z1 = bufs("z1", lambda: [{s_["name"]: (self.mem.empty((B, T, 4 * s_["layers"][0]["H"])), self.mem.empty((B, T, 4 * s_["layers"][0]["H"])))
+                                      for s_ in sp.streams} for _ in range(2)])
+
+        started = [0]
+        d1_seq = [0, 0]     # launch sequence number of the depth-1 scans of the batch in Z set 0 / 1 (its depth-2 scans: + 1)
+
+        def start_encoders(i, item):
+            """Upload batch i and enqueue its noise / depth-1 projections on stream 0 (two_stage), or nothing yet; returns the
+            generator that enqueues the rest of its encoder pass on ES."""
+            inputs = item[0] if output == "loss" else item
+            f = i % len(ring)
+            first = 0 if two_stage else ES
+            self._upload_inputs(inputs, None, train_phase, stream=first)
+            self._xin_user[self._xin_slot] = 1 << 60       # (its readers are known by event, not by a loss read-back)
+            gen = self._encoder_phases(train_phase, None, ring[f], ES, self.rng_step + (i - started[0]),
+                                       first_stream=0 if two_stage else None, z_first=z1[i & 1] if two_stage else None)
+            if two_stage:
+                dev.stream(0)
+                dev.wait_event(0, self.EV_D1S[i & 1])       # the depth-1 scans that read this Z set two batches ago
+                if i >= 1 and self.schedule.resident_wait_us > 0:
+                    # ... and not beside the previous batch's depth-2 projection GEMMs on ES (GEMM beside GEMM: the sum of both), but
+                    # beside its depth-2 SCANS, whose launch follows its depth-1 scan launch (bounded wait: placement only)
+                    dev.call("mgr_stream_wait_resident", C.c_uint(d1_seq[(i - 1) & 1] + 1), 5 * self.schedule.resident_wait_us)
+                tag = next(gen)                             # noise + depth-1 projections -> stream 0
+                assert tag == ("projected", 0)
+                dev.stream(0)
+                dev.record(self.EV_D1P[i & 1])
+            return gen
+
+        def finish_encoders(i, gen):
+            f = i % len(ring)
+            dev.stream(ES)
+            dev.wait_event(ES, self.EV_FUSED[f])            # the fusion pass that read this FEAT buffer two batches ago
+            if two_stage:
+                dev.wait_event(ES, self.EV_D1P[i & 1])
+                nl, ns = C.c_int(), C.c_int()
+                dev.call("mgr_persist_stats", C.byref(nl), C.byref(ns))
+                d1_seq[i & 1] = nl.value + 1                # the sequence number the depth-1 scan launch of this batch will get
+            for tag in gen:
+                if two_stage and tag == ("scanned", 0):
+                    dev.stream(ES)
+                    dev.record(self.EV_D1S[i & 1])
+            dev.stream(ES)
+            dev.record(self.EV_ENC[f])
+
         n = 0
         try:
-            for i, item in enumerate(batches):
+            it = iter(batches)
+            nxt_item = next(it, None)
+            if nxt_item is not None:
+                gen = start_encoders(0, nxt_item)
+                if two_stage:
+                    finish_encoders(0, gen)
+            i = -1
+            while nxt_item is not None:
+                i += 1
+                item = nxt_item
                 o, f = i & 1, i % len(ring)
-                inputs = item[0] if output == "loss" else item
-                # ---- upload + encoder pass of batch i (stream ES), beside what stream 0 still does for batch i - 1
-                self._upload_inputs(inputs, None, train_phase, stream=ES)
-                self._xin_user[self._xin_slot] = 1 << 60       # (its readers are known by event, not by a loss read-back)
-                dev.stream(ES)
-                dev.wait_event(ES, self.EV_FUSED[f])            # the fusion pass that read this FEAT buffer two batches ago
-                self._enqueue_encoders(train_phase, None, ring[f], ES, self.rng_step)
-                dev.stream(ES)
-                dev.record(self.EV_ENC[f])
+                if not two_stage:
+                    # ---- batch i's encoder pass (stream ES), beside what stream 0 still does for batch i - 1
+                    finish_encoders(i, gen)
+                nxt_item = next(it, None)
+                if two_stage:
+                    # ---- batch i + 1: upload, depth-1 projections on stream 0 (in front of batch i's fusion pass), and the REST of its
+                    # encoder pass on ES right away - so that the fusion pass below can be ordered behind the residency of that pass's
+                    # first scan launch
+                    if nxt_item is not None:
+                        finish_encoders(i + 1, start_encoders(i + 1, nxt_item))
+                elif nxt_item is not None:
+                    gen = start_encoders(i + 1, nxt_item)
                 # ---- fusion layer, head, decode / loss kernels of batch i (stream 0)
                 dev.stream(0)
                 dev.wait_event(0, self.EV_ENC[f])
+                if two_stage and nxt_item is not None and self.schedule.resident_wait_us > 0:
+                    # Batch i's encoder pass ends and batch i + 1's depth-1 scans start at the same instant on ES: fusion projection
+                    # GEMMs released at that instant race the scan's workgroups for the CUs and the scan runs at half speed for its
+                    # whole life (13.1 instead of 8.3 ms: profiles/r04_predict_timeline.txt) - they wait until it is resident
+                    dev.call("mgr_stream_wait_resident", C.c_uint(d1_seq[(i + 1) & 1]), self.schedule.resident_wait_us)
                 dev.wait_event(0, self.EV_OUT[o])               # batch i - 2's decode / download read the P buffer this pass overwrites
                 if output == "loss":
                     self._upload_labels(item[1], item[2], item[3])
                 self.P = pring[o]
-                self._enqueue_fusion_head(train_phase, None, ring[f], self.rng_step)
-                if train_phase:
-                    self.rng_step += 1
+                self._enqueue_fusion_head(train_phase, None, ring[f], self.rng_step + (i - started[0]))
                 dev.stream(0)
                 if output == "loss":
                     dev.call("mgr_ctc_loss_grad", self.P, self.labels_d, self.ilen_d, self.llen_d, B, T, Cn, self.Lmax, skip, Cn - 1,
@@ -819,6 +893,8 @@ class Engine:
                 yield collect(n - 1)
         finally:
             self.P = pring[0]
+            if train_phase:
+                self.rng_step += n          # (one draw of randomness per batch, as the one-batch-at-a-time calls)
             dev.stream(0)
             dev.sync()
             self._check_scans()
