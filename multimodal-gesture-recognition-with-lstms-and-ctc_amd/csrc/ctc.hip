@@ -17,6 +17,10 @@
 // are normalised by their own sum.
 // Phase 2 (all 4 waves) combines alpha+beta into per-class occupancies through an LDS row per thread and
 // chains through softmax(log(P+eps)) and the network's own softmax to dLogits.
+// Vector-memory instructions of the serial chain (round 4; a wave that is alone with its chain pays 60-130 cycles of issue for
+// each): the emissions are stored CLASS-MAJOR, forward in time for alpha and reversed for beta, so that a lane fetches eight
+// steps of its label's (and the blank's) emissions with two 16-byte loads instead of 16 four-byte ones, and alpha / beta rows
+// are stored two time steps at a time (one 16-byte store per lane and pair of steps): ~1 instead of ~3 per step.
 #include "common.h"
 
 namespace {
@@ -55,10 +59,15 @@ __device__ __forceinline__ float wave_max_f32(float m) {
 
 template <int PPL>
 struct Chunk {
-  static constexpr int CH = (8 / PPL) >= 2 ? (8 / PPL) : 2;
+  static constexpr int CH = PPL <= 2 ? 8 : 4;   // time steps per prefetched chunk (a multiple of 4: float4 loads along time)
   float eb[CH];
   float el[CH][PPL];
 };
+// row length of the class-major emission copies: T' + the over-read of two chunks + the 3-float offset that puts t = 1 on a
+// 16-byte boundary (alpha's chunks start at t = 1, 9, 17, ...)
+__host__ __device__ inline size_t ctc_ts(int To) { return ((size_t)To + 24 + 3) / 4 * 4; }
+// alpha / beta rows, two time steps per block: element (t, state 2p + e) at  (t >> 1) * 2 S2 + 4 p + 2 (t & 1) + e
+__device__ __forceinline__ size_t ab_off(int t, int S2) { return (size_t)(t >> 1) * (2 * S2) + 2 * (t & 1); }
 
 template <int PPL>
 __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const int32_t* __restrict__ labels,
@@ -79,9 +88,11 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
   int L = label_len[b];
   L = L < 0 ? 0 : (L > Lmax ? Lmax : L);
   const int S2 = 2 * (Lmax + 1);
-  float* LYb = LY + (size_t)b * To * C;
-  float* ALb = AL + (size_t)b * To * S2;
-  float* BEb = BE + (size_t)b * To * S2;
+  const size_t TS = ctc_ts(To);
+  float* LYTb = LY + (size_t)b * 2 * C * TS;       // [C][TS]: y(t, c) at c * TS + t + 3
+  float* LYRb = LYTb + (size_t)C * TS;             // [C][TS]: y(Tp - 1 - r, c) at c * TS + r
+  float* ALb = AL + (size_t)b * (To + 1) * S2;
+  float* BEb = BE + (size_t)b * (To + 1) * S2;
   int* s_lab = reinterpret_cast<int*>(smem + 256 * (C + 1));
   float* s_logp = reinterpret_cast<float*>(s_lab + Lmax + 1);
 
@@ -90,14 +101,17 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
     v = v < 0 ? 0 : (v >= C ? C - 1 : v);
     s_lab[i] = v;
   }
-  // ---- phase 0: emissions log y(t,c) = log(P+eps) - log(sum_c (P+eps)) --------------------------------
+  // ---- phase 0: emissions log y(t,c) = log(P+eps) - log(sum_c (P+eps)), class-major, forward and reversed in time ------
   for (int t = tid; t < Tp; t += 256) {
     const float* row = P + ((size_t)b * T + skip + t) * C;
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += row[c] + eps;
     float ls = logf(s);
-    float* o = LYb + (size_t)t * C;
-    for (int c = 0; c < C; ++c) o[c] = logf(row[c] + eps) - ls;
+    for (int c = 0; c < C; ++c) {
+      const float v = logf(row[c] + eps) - ls;
+      LYTb[(size_t)c * TS + t + 3] = v;
+      LYRb[(size_t)c * TS + (Tp - 1 - t)] = v;
+    }
   }
   __syncthreads();
 
@@ -125,23 +139,32 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
     }
     if (wave == 0) {
       float ab[PPL], al[PPL];
+      float hb[PPL], hl[PPL];   // the even step of the pair in flight (rows are stored two steps at a time)
 #pragma unroll
       for (int j = 0; j < PPL; ++j) {
         int p = lane * PPL + j;
-        ab[j] = (p == 0) ? LYb[blank] : kNegInf;
-        al[j] = (p == 0 && vl[j]) ? LYb[lab[j]] : kNegInf;
-        if (p <= Lmax) *reinterpret_cast<float2*>(ALb + 2 * p) = make_float2(ab[j], al[j]);
+        ab[j] = (p == 0) ? LYTb[(size_t)blank * TS + 3] : kNegInf;
+        al[j] = (p == 0 && vl[j]) ? LYTb[(size_t)lab[j] * TS + 3] : kNegInf;
+        hb[j] = ab[j];
+        hl[j] = al[j];
+        if (Tp == 1 && p <= Lmax) *reinterpret_cast<float2*>(ALb + 4 * p) = make_float2(ab[j], al[j]);
       }
       Chunk<PPL> cur, nxt;
-      auto load = [&](Chunk<PPL>& ch, int t0) {
+      auto load = [&](Chunk<PPL>& ch, int t0) {   // steps t0 .. t0 + CH - 1 (t0 = 1 mod CH: 16-byte aligned; over-read stays in the row)
+        const float* rb = LYTb + (size_t)blank * TS + t0 + 3;
 #pragma unroll
-        for (int k = 0; k < CH; ++k) {
-          int t = t0 + k;
-          t = t < Tp ? t : Tp - 1;
-          const float* r = LYb + (size_t)t * C;
-          ch.eb[k] = r[blank];
+        for (int q = 0; q < CH / 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(rb + 4 * q);
+          ch.eb[4 * q] = v.x; ch.eb[4 * q + 1] = v.y; ch.eb[4 * q + 2] = v.z; ch.eb[4 * q + 3] = v.w;
+        }
 #pragma unroll
-          for (int j = 0; j < PPL; ++j) ch.el[k][j] = r[lab[j]];
+        for (int j = 0; j < PPL; ++j) {
+          const float* rl = LYTb + (size_t)lab[j] * TS + t0 + 3;
+#pragma unroll
+          for (int q = 0; q < CH / 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(rl + 4 * q);
+            ch.el[4 * q][j] = v.x; ch.el[4 * q + 1][j] = v.y; ch.el[4 * q + 2][j] = v.z; ch.el[4 * q + 3][j] = v.w;
+          }
         }
       };
       load(cur, 1);
@@ -166,7 +189,13 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
               ab[j] = nb[j];
               al[j] = nl[j];
               int p = lane * PPL + j;
-              if (p <= Lmax) *reinterpret_cast<float2*>(ALb + (size_t)t * S2 + 2 * p) = make_float2(ab[j], al[j]);
+              if (t & 1) {          // the pair (t - 1, t) is complete: one 16-byte store
+                if (p <= Lmax) *reinterpret_cast<float4*>(ALb + ab_off(t - 1, S2) + 4 * p) = make_float4(hb[j], hl[j], ab[j], al[j]);
+              } else {
+                hb[j] = ab[j];
+                hl[j] = al[j];
+                if (t == Tp - 1 && p <= Lmax) *reinterpret_cast<float2*>(ALb + ab_off(t, S2) + 4 * p) = make_float2(ab[j], al[j]);
+              }
             }
           }
         }
@@ -214,24 +243,34 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
 #pragma unroll
         for (int j = 0; j < PPL; ++j) csn[j] = (j < PPL - 1) ? cs[j + 1] : (lane < 63 && nfirst != 0);
       }
+      float hb[PPL], hl[PPL];   // the odd step of the pair in flight (beta walks down: t + 1 comes before t)
 #pragma unroll
       for (int j = 0; j < PPL; ++j) {
         int p = lane * PPL + j;
         bb[j] = (p == L) ? 0.f : kNegInf;
         bl[j] = (p == L - 1) ? 0.f : kNegInf;
-        if (p <= Lmax) *reinterpret_cast<float2*>(BEb + (size_t)(Tp - 1) * S2 + 2 * p) = make_float2(bb[j], bl[j]);
+        hb[j] = bb[j];
+        hl[j] = bl[j];
+        // t = Tp - 1: an even t is a pair's first half and nothing pairs with it from above - stored on its own
+        if (((Tp - 1) & 1) == 0 && p <= Lmax) *reinterpret_cast<float2*>(BEb + ab_off(Tp - 1, S2) + 4 * p) = make_float2(bb[j], bl[j]);
       }
       Chunk<PPL> cur, nxt;
-      // step index n = 0.. walks t = Tp-2-n; uses emissions at t+1 = Tp-1-n
-      auto load = [&](Chunk<PPL>& ch, int n0) {
+      // step index n = 0.. walks t = Tp-2-n; uses emissions at t+1 = Tp-1-n = reversed index n
+      auto load = [&](Chunk<PPL>& ch, int n0) {   // reversed steps n0 .. n0 + CH - 1 (n0 = 0 mod CH: aligned)
+        const float* rb = LYRb + (size_t)blank * TS + n0;
 #pragma unroll
-        for (int k = 0; k < CH; ++k) {
-          int te = Tp - 1 - (n0 + k);
-          te = te > 0 ? te : 0;
-          const float* r = LYb + (size_t)te * C;
-          ch.eb[k] = r[blank];
+        for (int q = 0; q < CH / 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(rb + 4 * q);
+          ch.eb[4 * q] = v.x; ch.eb[4 * q + 1] = v.y; ch.eb[4 * q + 2] = v.z; ch.eb[4 * q + 3] = v.w;
+        }
 #pragma unroll
-          for (int j = 0; j < PPL; ++j) ch.el[k][j] = r[lab[j]];
+        for (int j = 0; j < PPL; ++j) {
+          const float* rl = LYRb + (size_t)lab[j] * TS + n0;
+#pragma unroll
+          for (int q = 0; q < CH / 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(rl + 4 * q);
+            ch.el[4 * q][j] = v.x; ch.el[4 * q + 1][j] = v.y; ch.el[4 * q + 2][j] = v.z; ch.el[4 * q + 3][j] = v.w;
+          }
         }
       };
       load(cur, 0);
@@ -259,7 +298,12 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
               bb[j] = vb[j] ? lse2(xb[j], xl[j]) : kNegInf;
               bl[j] = vl[j] ? lse3(xl[j], b1, csn[j] ? l1 : kNegInf) : kNegInf;
               int p = lane * PPL + j;
-              if (p <= Lmax) *reinterpret_cast<float2*>(BEb + (size_t)t * S2 + 2 * p) = make_float2(bb[j], bl[j]);
+              if (t & 1) {          // first half of the pair (t - 1, t) to arrive: keep it (or store it alone at t = ... never: t >= 0 even ends)
+                hb[j] = bb[j];
+                hl[j] = bl[j];
+              } else {              // the pair (t, t + 1) is complete (t + 1 was held, or is the initial row when Tp - 1 is odd)
+                if (p <= Lmax) *reinterpret_cast<float4*>(BEb + ab_off(t, S2) + 4 * p) = make_float4(bb[j], bl[j], hb[j], hl[j]);
+              }
             }
           }
         }
@@ -300,19 +344,19 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
       continue;
     }
     for (int c = 0; c < C; ++c) occ[c] = 0.f;
-    const float* ar = ALb + (size_t)tt * S2;
-    const float* br = BEb + (size_t)tt * S2;
+    const float* ar = ALb + ab_off(tt, S2);
+    const float* br = BEb + ab_off(tt, S2);
     float vmax = kNegInf;
     for (int p = 0; p <= L; ++p) {
-      float2 a = *reinterpret_cast<const float2*>(ar + 2 * p);
-      float2 be = *reinterpret_cast<const float2*>(br + 2 * p);
+      float2 a = *reinterpret_cast<const float2*>(ar + 4 * p);
+      float2 be = *reinterpret_cast<const float2*>(br + 4 * p);
       vmax = fmaxf(vmax, a.x + be.x);
       if (p < L) vmax = fmaxf(vmax, a.y + be.y);
     }
     float den = 0.f;
     for (int p = 0; p <= L; ++p) {
-      float2 a = *reinterpret_cast<const float2*>(ar + 2 * p);
-      float2 be = *reinterpret_cast<const float2*>(br + 2 * p);
+      float2 a = *reinterpret_cast<const float2*>(ar + 4 * p);
+      float2 be = *reinterpret_cast<const float2*>(br + 4 * p);
       float wb = __expf(a.x + be.x - vmax);
       occ[blank] += wb;
       den += wb;
@@ -344,8 +388,8 @@ extern "C" {
 
 size_t mgr_ctc_ws_bytes(int B, int T, int C, int Lmax) {
   size_t To = (size_t)(T > 0 ? T : 1);
-  size_t ly = mgr_align_up((size_t)B * To * C * sizeof(float), 256);
-  size_t ab = mgr_align_up((size_t)B * To * 2 * (Lmax + 1) * sizeof(float), 256);
+  size_t ly = mgr_align_up((size_t)B * 2 * C * ctc_ts((int)To) * sizeof(float), 256);   // class-major emissions, forward + reversed
+  size_t ab = mgr_align_up((size_t)B * (To + 1) * 2 * (Lmax + 1) * sizeof(float), 256);
   return ly + 2 * ab;
 }
 
@@ -358,8 +402,8 @@ int mgr_ctc_loss_grad(mgr_ctx* c, const float* P, const int32_t* labels, const i
   MGR_REQUIRE(Lmax + 1 <= 256, "Lmax %d too large (max 255)", Lmax);
   MGR_REQUIRE(ws && ws_bytes >= mgr_ctc_ws_bytes(B, T, C, Lmax), "workspace too small");
   size_t To = (size_t)T;  // sized with T (>= T-skip) to keep the query simple
-  size_t ly = mgr_align_up((size_t)B * To * C * sizeof(float), 256);
-  size_t ab = mgr_align_up((size_t)B * To * 2 * (Lmax + 1) * sizeof(float), 256);
+  size_t ly = mgr_align_up((size_t)B * 2 * C * ctc_ts((int)To) * sizeof(float), 256);
+  size_t ab = mgr_align_up((size_t)B * (To + 1) * 2 * (Lmax + 1) * sizeof(float), 256);
   float* LY = reinterpret_cast<float*>(ws);
   float* AL = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ly);
   float* BE = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ly + ab);
