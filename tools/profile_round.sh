@@ -11,7 +11,7 @@ TAG=${1:-r01}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd $R && python -c "import mgr_amd; from mgr_amd._build import source_hash; print(source_hash())" > gpurun_out/${TAG}_src_sha.txt   # the tree that is measured
-cd $R && timeout 600 python bench.py > gpurun_out/${TAG}_bench.log 2>&1
+cd $R && timeout 900 python bench.py > gpurun_out/${TAG}_bench.log 2>&1
 tail -1 gpurun_out/${TAG}_bench.log > gpurun_out/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/${TAG}_prof

@@ -17,7 +17,8 @@ def parse(s):
     return [tuple(int(x) for x in kv.split("=")) for kv in s.split(",") if kv]
 
 
-for hs in ((500,), (300,), (500, 300)):
+HS = [tuple(int(h) for h in a.split("+")) for a in os.environ.get("SCAN_PROBE_H", "500,300,500+300").split(",")]
+for hs in HS:
     jobs, keep = [], []
     for H in hs:
         for rev in (0, 1):
