@@ -157,8 +157,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
  * key 7: one-tile-per-wave clusters: 0 = K-split step (register-direct gather), 1 = LDS-image step.
  * key 8: 1 = the multi-CU BPTT keeps its 4-wave kernel instead of the split-role (4 compute + 4 gather waves) one, 2 = always split.
  * key 9: 1 = mgr_lstm_input_proj_dropout always takes the dense kernel.
- * key 13: 1 = mgr_dense_softmax_fwd / mgr_dense_bwd keep their LDS-tiled vector-ALU kernels where the matrix-core forms would run.
- * key 14: 1 = K-split scan launches keep four tiles per workgroup for every layer (no three-tile skeletal workgroups). */
+ * key 13: 1 = mgr_dense_softmax_fwd / mgr_dense_bwd keep their LDS-tiled vector-ALU kernels where the matrix-core forms would run. */
 enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 16 };
 int mgr_tune(mgr_ctx* ctx, int key, int value);
 /* Health of the persistent multi-CU scans launched on this context since the last mgr_scan_status_clear: *out receives the OR

@@ -31,13 +31,9 @@ struct Plan {
   bool any, exchange;
 };
 
-// floats of one exchange slot of a batch group: one 1 KiB block per workgroup of the cluster; sized for the three-tile form of the
-// K-split step (the most workgroups per cluster), whichever form the launch takes
-size_t job_img_floats(int ks) { return (size_t)((ks + 2) / 3) * 256; }
-
 size_t job_ws(const mgr_scan_job& j) {
   int ks = j.H / 4;
-  size_t img = job_img_floats(ks);
+  size_t img = (size_t)((ks + 3) / 4) * 256;
   int nbg = (j.B + 15) / 16;
   return mgr_align_up((size_t)nbg * 2 * img * sizeof(float), 256);
 }
@@ -259,41 +255,6 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
       const size_t zb = (size_t)j.B * j.T * 4 * j.H * sizeof(float), rb = j.R ? (size_t)j.B * j.T * j.ldr * sizeof(float) : 0;
       ks_ok = zb < ((size_t)1 << 32) && rb < ((size_t)1 << 32);
     }
-    // K-split launches (every cluster job: 4 waves, one tile per wave, an exchange, an instantiation): layers with a three-tile
-    // instantiation (the skeletal encoder, H = 300) take 3 instead of 4 tiles per workgroup where the larger grid still fits -
-    // lighter partner waves for the audio workgroups they share CUs with (lstm_cluster.hip).  tune key 14 = 1: off
-    int nt[MGR_MAX_SCAN_JOBS];
-    for (int i = 0; i < njobs; ++i) nt[i] = 4;
-    {
-      bool ks_all = ks_ok && P.exchange;
-      for (int i = 0; i < njobs && ks_all; ++i)
-        if (P.cluster[i]) ks_all = P.cfg[i].nw == 4 && P.cfg[i].tpw == 1 && P.G[i] > 1 && mgr_cluster_ks_supported(jobs[i].H / 4);
-      bool mixed = false;   // (pays only beside a heavier layer; a layer alone in its launch keeps four tiles)
-      for (int i = 0; i < njobs; ++i) mixed = mixed || (P.cluster[i] && jobs[i].H != jobs[0].H);
-      if (ks_all && mixed && c->tune[14] == 0) {
-        int tot = 0;    // grid of the octet layout: per layer width, its clusters (all jobs of that width) rounded up to 8
-        for (int i = 0; i < njobs; ++i) {
-          if (!P.cluster[i]) continue;
-          bool first = true;
-          for (int k = 0; k < i; ++k) first = first && !(P.cluster[k] && jobs[k].H == jobs[i].H);
-          if (!first) continue;
-          int clusters = 0;
-          for (int k = i; k < njobs; ++k)
-            if (P.cluster[k] && jobs[k].H == jobs[i].H) clusters += P.nbg[k];
-          const int ks = jobs[i].H / 4;
-          const int g = mgr_cluster_ks3_supported(ks) ? (ks + 2) / 3 : P.G[i];
-          tot += g * ((clusters + 7) / 8 * 8);
-        }
-        if (tot <= 2 * c->cu_count) {
-          for (int i = 0; i < njobs; ++i) {
-            if (!P.cluster[i] || !mgr_cluster_ks3_supported(jobs[i].H / 4)) continue;
-            nt[i] = 3;
-            P.G[i] = (jobs[i].H / 4 + 2) / 3;
-            P.wgs[i] = P.G[i] * P.nbg[i];
-          }
-        }
-      }
-    }
     bool xcd = c->tune[3] == 0 && ks_ok && P.exchange;
     {
       int tot = 0;
@@ -329,10 +290,10 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
       const mgr_scan_job& j = jobs[i];
       ClusterJob& cj = L.job[L.njobs++];
       int ks = j.H / 4;
-      size_t img = job_img_floats(ks);
+      size_t img = (size_t)((ks + 3) / 4) * 256;
       cj.Z = j.Z; cj.Up = j.Up; cj.Y = j.Y; cj.R = j.R; cj.G = j.gates; cj.Cs = j.cs;
       cj.ldy = j.ldy; cj.ldr = j.ldr; cj.B = j.B; cj.T = j.T; cj.H = j.H; cj.reverse = j.reverse;
-      cj.ks = ks; cj.tpw = P.cfg[i].tpw; cj.nw = P.cfg[i].nw; cj.nt = nt[i];
+      cj.ks = ks; cj.tpw = P.cfg[i].tpw; cj.nw = P.cfg[i].nw;
       cj.G_ = P.G[i]; cj.nbg = P.nbg[i];
       cj.cls_begin = cb[i]; cj.cls_nclusters = cn[i]; cj.cls_cluster0 = c0[i]; cj.cls_rot = cr[i];
       cj.xbuf = reinterpret_cast<float*>(w);

@@ -41,7 +41,6 @@ struct ClusterJob {
   int ldt;          // ... its row length (T padded; entries t in [T, ldt) are written as zero)
   int ldy, ldr, B, T, H, reverse;
   int ks, tpw, nw;  // k-steps (H/4), tiles per wave, active waves per workgroup
-  int nt;           // K-split step: tiles per workgroup (4, or 3 for the lighter skeletal workgroups: lstm_cluster.hip); G_ = ceil(ks / nt)
   int G_;           // workgroups per cluster (one cluster = one 16-sample batch group)
   int nbg;          // batch groups
   // jobs with identical geometry form a CLASS that shares one contiguous workgroup range: cluster `cl` of the class
@@ -62,7 +61,6 @@ struct ClusterLaunch {
 // true if (ks, tpw) has an instantiation / if ks has a K-split instantiation
 bool mgr_cluster_supported(int ks, int tpw);
 bool mgr_cluster_ks_supported(int ks);
-bool mgr_cluster_ks3_supported(int ks);   // ... with three tiles per workgroup
 // geometry of the launch that mgr_cluster_launch would issue: waves per workgroup, workgroups per CU
 void mgr_cluster_geometry(const ClusterLaunch& L, bool any_exchange, int* waves, int* per_cu);
 bool mgr_cluster_uses_ks(const ClusterLaunch& L, bool any_exchange);   // the launch will run the K-split kernel (which honours ClusterJob::YT)

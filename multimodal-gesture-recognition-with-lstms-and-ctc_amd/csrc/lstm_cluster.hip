@@ -326,17 +326,9 @@ __device__ __forceinline__ void mgr_dma_b32(const void* gbase, unsigned voff, un
 // [2][64] f32x4 | 4 residual rings [2][64]
 constexpr int KS_LDS_FLOATS = 2 * 16 * 64 * 4 + 4 * KS_STG * 64 + 4 * 2 * 256 + 4 * 2 * 64;
 
-// NT = tiles (16 packed gate columns = 4 units each) per workgroup: 4, or 3.  Round 4: with two workgroups per CU a time step of
-// the audio + skeletal pair costs the audio wave's own step plus the ISSUE TIME of its skeletal partner on the same SIMD - f32
-// MFMAs and vector instructions of two waves do not overlap (tools/scan_variant_probe.py: audio alone 2.84 us, beside an
-// H = 128 layer 3.43, beside H = 300 4.41).  Three tiles per skeletal workgroup = 25 instead of 19 workgroups per cluster (456
-// instead of 408 in the launch, still one audio + at most one skeletal per CU) and 63 instead of 80 MFMAs per skeletal wave and
-// step.  An image block keeps its four k-step slots (1 KiB per publishing workgroup); slot NT.. of a block is padding that carries
-// the parity and meets no MFMA.
-template <int KS, int NT>
+template <int KS>
 __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const ClusterCommon& cm, int bg, int ug, float* smem, bool fast) {
-  constexpr int H = 4 * KS, N = 4 * H, QN = (KS + NT - 1) / NT, IMG = QN * 256, NBW = (QN + 3) / 4;
-  static_assert(NT == 3 || NT == 4, "three or four tiles per workgroup");
+  constexpr int H = 4 * KS, N = 4 * H, QN = (KS + 3) / 4, IMG = QN * 256, NBW = (QN + 3) / 4;
   static_assert(NBW >= 1 && NBW <= 8, "1..8 image blocks per wave (H <= 512)");
   unsigned* status = cm.status;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -356,26 +348,26 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
   asm volatile("" : "+s"(Rp), "+s"(Yp), "+s"(Gp), "+s"(Csp), "+s"(ldr), "+s"(ldy));
 
   auto unit_of = [](int tile, int u) {   // hidden unit of MFMA slot (tile, unit-in-tile): see cluster_run_ks
-    const int q = tile / NT, nv = (KS - NT * q) < NT ? (KS - NT * q) : NT;
-    return 4 * NT * q + nv * u + (tile % NT);
+    const int q = tile >> 2, nv = (KS - 4 * q) < 4 ? (KS - 4 * q) : 4;
+    return 16 * q + nv * u + (tile & 3);
   };
   const int qb = wave * NBW;     // K range of this wave: image blocks [qb, qb + nb) = what unit groups qb .. qb + nb - 1 publish
   int nb = QN - qb;
   nb = nb < 0 ? 0 : (nb > NBW ? NBW : nb);
   nb = __builtin_amdgcn_readfirstlane(nb);
 
-  float uf[NT][NBW * NT];
+  float uf[4][NBW * 4];
 #pragma unroll
-  for (int tt = 0; tt < NT; ++tt) {
-    const int gt = ug * NT + tt;
+  for (int tt = 0; tt < 4; ++tt) {
+    const int gt = ug * 4 + tt;
 #pragma unroll
-    for (int sl = 0; sl < NBW * NT; ++sl) {
-      const int s = qb * NT + sl;      // k-step = tile index: slot sl % NT of image block qb + sl / NT
+    for (int sl = 0; sl < NBW * 4; ++sl) {
+      const int s = qb * 4 + sl;
       uf[tt][sl] = (gt < KS && s < KS) ? Up[(size_t)unit_of(s, uq) * N + unit_of(gt, j >> 2) * 4 + (j & 3)] : 0.f;
     }
   }
-  const int ftile = ug * NT + uq;    // the cell this lane finishes: slot (tile NT*ug + uq, unit-in-tile wave); lanes uq >= NT: padding
-  const bool cvalid = uq < NT && ftile < KS;
+  const int ftile = ug * 4 + uq;     // the cell this lane finishes: slot (tile 4*ug + uq, unit-in-tile wave)
+  const bool cvalid = ftile < KS;
   const int unit = cvalid ? unit_of(ftile, wave) : 0;
   const int red_off = ((uq * 4) * 64 + wave * 16 + j) * 4;
 
@@ -437,7 +429,7 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
     // (no per-step zeroing of the 32 gather registers and the 16 accumulators: vector instructions do not overlap with this
     // SIMD's MFMAs - profiles/r04_single_cu_probes.txt - so every v_mov of a step is step time; the first MFMA of each
     // accumulator takes a literal zero instead)
-    f32x4 acc[NT];
+    f32x4 acc[4];
     u32x4 v[NBW];
     const bool gather = step > 0 && nb > 0 && !failed;
     if (gather) {
@@ -470,23 +462,23 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
         if (i == (NBW > 1 ? 1 : 0)) prefetch(step + 1);
         const float hv[4] = {__uint_as_float(v[i].x), __uint_as_float(v[i].y), __uint_as_float(v[i].z), __uint_as_float(v[i].w)};
 #pragma unroll
-        for (int r = 0; r < NT; ++r) {
+        for (int r = 0; r < 4; ++r) {
 #pragma unroll
-          for (int tt = 0; tt < NT; ++tt) {   // k-steps / blocks that do not exist carry zero weights
+          for (int tt = 0; tt < 4; ++tt) {   // k-steps / blocks that do not exist carry zero weights
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[tt][i * NT + r], hv[r], (i == 0 && r == 0) ? zero : acc[tt], 0, 0, 0);
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[tt][i * 4 + r], hv[r], (i == 0 && r == 0) ? zero : acc[tt], 0, 0, 0);
           }
         }
       }
     } else {   // the first step (h_{-1} = 0), a wave without K range, a launch that gave up
       prefetch(step + 1);
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int tt = 0; tt < 4; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     // the four partial sums of every tile meet in LDS (double-buffered on the step parity: one barrier per step)
     float* rbuf = red + (step & 1) * (16 * 64 * 4);
 #pragma unroll
-    for (int tt = 0; tt < NT; ++tt) *reinterpret_cast<f32x4*>(rbuf + ((tt * 4 + wave) * 64 + lane) * 4) = acc[tt];
+    for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(rbuf + ((tt * 4 + wave) * 64 + lane) * 4) = acc[tt];
     // Z_t / R_t were fetched one step ago; the only vector-memory operations this wave has issued since that may still be in
     // flight are the one or two DMAs of step t + 1: a counted wait makes their landing explicit (in practice it never waits)
     if (Rp)
@@ -598,15 +590,12 @@ __global__ __launch_bounds__(CL_WAVES * 64) void k_scan_cluster(ClusterLaunch L)
 // a narrow layer's scan (the fusion layer, H = 100: 56 workgroups that run BESIDE the 408 of the encoder scans) should not
 // ask a CU for registers it never touches - with ~100 it fits on any CU that has a wave slot left.
 #define CLKS_LARGE(X) X(125) X(75)
-#define CLKS_THREE(X) X(75)          // instantiations with three tiles per workgroup
 #define CLKS_SMALL(X) X(32) X(25)
 template <bool SMALL>
 __device__ __forceinline__ void scan_cluster_ks_body(const ClusterLaunch& L, float* smem) {
   mgr_cluster_enter(L.cm);
 #define CLKS_CASE(KS) \
-  if (jb.ks == KS && jb.nt == 4) { cluster_run_ks<KS, 4>(jb, L.cm, bg, ug, smem, same); return mgr_cluster_exit(L.cm); }
-#define CLKS3_CASE(KS) \
-  if (jb.ks == KS && jb.nt == 3) { cluster_run_ks<KS, 3>(jb, L.cm, bg, ug, smem, same); return mgr_cluster_exit(L.cm); }
+  if (jb.ks == KS) { cluster_run_ks<KS>(jb, L.cm, bg, ug, smem, same); return mgr_cluster_exit(L.cm); }
   if (L.xcd_local) {
     for (int k_ = 0; k_ < L.njobs; ++k_) {
       const ClusterJob& jb = L.job[k_];
@@ -620,7 +609,6 @@ __device__ __forceinline__ void scan_cluster_ks_body(const ClusterLaunch& L, flo
         CLKS_SMALL(CLKS_CASE)
       } else {
         CLKS_LARGE(CLKS_CASE)
-        CLKS_THREE(CLKS3_CASE)
         CLKS_SMALL(CLKS_CASE)
       }
       return;
@@ -633,13 +621,11 @@ __device__ __forceinline__ void scan_cluster_ks_body(const ClusterLaunch& L, flo
       CLKS_SMALL(CLKS_CASE)
     } else {
       CLKS_LARGE(CLKS_CASE)
-      CLKS_THREE(CLKS3_CASE)
       CLKS_SMALL(CLKS_CASE)
     }
     return;
   }
 #undef CLKS_CASE
-#undef CLKS3_CASE
 }
 
 __global__ __launch_bounds__(256, 2) void k_scan_cluster_ks(ClusterLaunch L) {
@@ -660,14 +646,6 @@ bool mgr_cluster_supported(int ks, int tpw) {
   if (ks == KS && tpw == TPW) return true;
   CL_FOREACH(CL_CASE)
 #undef CL_CASE
-  return false;
-}
-
-bool mgr_cluster_ks3_supported(int ks) {
-#define CLKS_CASE(KS) \
-  if (ks == KS) return true;
-  CLKS_THREE(CLKS_CASE)
-#undef CLKS_CASE
   return false;
 }
 

@@ -665,64 +665,3 @@ def test_head_fwd_bwd_equals_the_three_kernels_and_the_oracle(device, B, T, D, C
     assert rel_err(got["dL"], ref_dz / B) < 5e-4
     for name, a, b in (("dA", got["gA"], dAref), ("dWd", got["gW"], dWref), ("dbd", got["gb"], dbref)):
         assert rel_err(a, b) < 5e-4, (name, rel_err(a, b))     # (the bound of the CTC gradient they are products of)
-
-
-@pytest.mark.parametrize("B,T", [(64, 9), (19, 6), (33, 3)])
-def test_mixed_encoder_launch_three_tile_skeletal_workgroups(device, B, T):
-    """The encoder depth of config F in ONE launch (audio H = 500 + skeletal H = 300, both directions, residual inputs,
-    transposed output copies): in such a mixed K-split launch the skeletal clusters take THREE tiles per workgroup (25 instead
-    of 19 workgroups per cluster: lighter partner waves for the audio workgroups they share CUs with; mgr_tune key 14 = 1 keeps
-    four).  Both forms against the oracle (reference call sites multimodal_fusion/multimodal.py:109-118) and against each other
-    (same sums per cell up to the K-quarter boundaries: 1e-6), over enough steps to cycle the epoch parity, launched twice."""
-    from mgr_amd import _capi
-    dev = device
-    rng = np.random.default_rng(B * 10 + T)
-    f32 = np.float32
-    F = 6
-    jobs, refs, outs, keep = [], [], [], []
-    ldt = (T + 127) // 128 * 128
-    for H in (500, 300):
-        Ycat = dev.zeros((B, T, 2 * H))
-        R = (rng.standard_normal((B, T, 2 * H)) * 0.3).astype(f32)
-        dR = dev.array(R)
-        YT = dev.array(np.full((B, 2 * H, ldt), 7.0, f32))
-        for reverse in (0, 1):
-            x, W, U, b, _ = _lstm_case(rng, B, T, F, H, 0.0)
-            U = U * 0.1
-            y_ref, cache = kr.lstm_forward(x, W, U, b, None, bool(reverse))
-            Wp, Up, bp = dev.empty((F, 4 * H)), dev.empty((H, 4 * H)), dev.empty((4 * H,))
-            dev.call("mgr_lstm_pack", dev.array(W.astype(f32)), Wp, F, H, 0)
-            dev.call("mgr_lstm_pack", dev.array(U.astype(f32)), Up, H, H, 0)
-            dev.call("mgr_lstm_pack", dev.array(b.astype(f32)), bp, 1, H, 0)
-            Z = dev.empty((B, T, 4 * H))
-            dev.call("mgr_lstm_input_proj", dev.array(x.astype(f32)), F, 0, Wp, bp, Z, B, T, F, H)
-            G, Cs = dev.empty((B, T, H, 4)), dev.empty((B, T, H))
-            jobs.append(dict(Z=Z, Up=Up, Y=Ycat.view(reverse * H, (1,)), ldy=2 * H, R=dR.view(reverse * H, (1,)), ldr=2 * H, gates=G, cs=Cs,
-                             B=B, T=T, H=H, reverse=reverse, YT=YT.ptr + reverse * H * ldt * 4, ytb=2 * H * ldt, ldt=ldt))
-            refs.append((y_ref + R[:, :, reverse * H:(reverse + 1) * H], cache))
-            outs.append((Ycat, reverse * H, H, G, Cs, YT))
-            keep += [Wp, Up, bp, Z, dR]
-    arr = _capi.make_scan_jobs(jobs)
-    ws = dev.bytes(dev.lib.mgr_lstm_scan_multi_ws_bytes(len(jobs), arr))
-    got = {}
-    dev.call("mgr_tune", 1, 1)  # synchronous give-up check
-    try:
-        for four in (0, 1):
-            dev.call("mgr_tune", 14, four)
-            for rep in range(2):
-                _capi.check(dev.lib.mgr_lstm_scan_fwd_multi(dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes))
-            res = []
-            for (Ycat, c0, H, G, Cs, YT), (y_ref, cache) in zip(outs, refs):
-                y = Ycat.download()[:, :, c0:c0 + H]
-                assert rel_err(y, y_ref) < 3e-5
-                assert rel_err(Cs.download(), cache["c"]) < 3e-5
-                assert rel_err(G.download()[..., 3], cache["o"]) < 3e-5
-                yt = YT.download()[:, c0:c0 + H]
-                assert np.array_equal(yt[:, :, :T], y.transpose(0, 2, 1)) and not yt[:, :, T:].any()
-                res.append(y)
-            got[four] = res
-    finally:
-        dev.call("mgr_tune", 14, 0)
-        dev.call("mgr_tune", 1, 0)
-    for a, b in zip(got[0], got[1]):
-        assert np.abs(a - b).max() < 1e-6
