@@ -345,6 +345,7 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nn2(const float* __restrict__ X
 __global__ __launch_bounds__(64) void k_mask_compact(const float* __restrict__ mask4, int F, int Fp, int* __restrict__ kidx,
                                                      float* __restrict__ kval, int* __restrict__ kcnt,
                                                      int* __restrict__ kpos /* [4B][F] list position of a kept feature, -1 if dropped; may be null */) {
+  MGR_OFF_PAIRED_CUS(2);
   const int gb = blockIdx.x, lane = threadIdx.x;
   const float* m = mask4 + (size_t)gb * F;
   int* out = kidx + (size_t)gb * Fp;
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(64) void k_mask_compact(const float* __restrict__ m
 // Wg[g][f][u] = Wp[f][4u + g]: gate-major copy of the packed kernel, so that the row gather of one gate pass reads
 // contiguous units instead of every fourth float (a quarter of the L2 traffic of the B operand); F x 4H floats per call.
 __global__ __launch_bounds__(256) void k_gate_major(const float* __restrict__ Wp, float* __restrict__ Wg, int F, int H) {
+  MGR_OFF_PAIRED_CUS(2);
   const size_t n = (size_t)F * H;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float4 w = *reinterpret_cast<const float4*>(Wp + i * 4);   // (f, u): gates 0..3
@@ -738,6 +740,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_sparse(const float* __restri
 // dWp[f][4u+g] = sum over the samples that kept feature f for gate g, in sample order
 __global__ __launch_bounds__(256) void k_dw_gather(const float* __restrict__ P, const int* __restrict__ kpos, float* __restrict__ dWp,
                                                    int B, int F, int Fp, int H) {
+  MGR_OFF_PAIRED_CUS(2);
   const size_t n = (size_t)4 * F * H;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const int u = (int)(i % H);
@@ -831,6 +834,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const float* __restrict__ dZ
 
 // slab reduce: out[i] = sum_k slab[k][i]
 __global__ void k_reduce(const float* __restrict__ slab, float* __restrict__ out, size_t n, int nslab) {
+  MGR_OFF_PAIRED_CUS(2);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < nslab; ++k) s += slab[(size_t)k * n + i];
@@ -842,6 +846,7 @@ __global__ void k_reduce(const float* __restrict__ slab, float* __restrict__ out
 // float4 loads, two row lanes summed through LDS (N = 4H is a multiple of 4)
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dZ, float* __restrict__ slab, size_t rows, int N,
                                                 int rows_per_wg) {
+  MGR_OFF_PAIRED_CUS(2);
   __shared__ float4 part[128];
   const size_t rbeg = (size_t)blockIdx.x * rows_per_wg;
   const size_t rend = rbeg + rows_per_wg < rows ? rbeg + rows_per_wg : rows;
@@ -870,6 +875,7 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dZ, fl
 // out[i] = sum_k slab[k][i] for MANY slabs of a SHORT vector (the bias gradient: hundreds of row-block partial sums of 4H
 // numbers): 8 slab lanes per element, summed through LDS in a fixed order
 __global__ __launch_bounds__(256) void k_reduce_tall(const float* __restrict__ slab, float* __restrict__ out, int n, int nslab) {
+  MGR_OFF_PAIRED_CUS(2);
   __shared__ float part[8][32];
   const int e = blockIdx.x * 32 + (threadIdx.x & 31), kl = threadIdx.x >> 5;
   float s = 0.f;
@@ -1020,6 +1026,7 @@ int mgr_lstm_input_proj_dropout_t(mgr_ctx* c, const float* XT, int ldt, const fl
 namespace {
 __global__ __launch_bounds__(256) void k_transpose_bt(const float* __restrict__ X, int ldx, float* __restrict__ XT, int ldt, int T, int F,
                                                       long long xtb /* batch stride of XT; 0: F * ldt */, int fill /* columns written: ldt or less */) {
+  MGR_OFF_PAIRED_CUS(2);
   __shared__ float tile[64][65];
   const int b = blockIdx.z, t0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
