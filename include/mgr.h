@@ -112,11 +112,16 @@ int mgr_lstm_input_proj_dropout(mgr_ctx* ctx, const float* X, int ldx, const flo
 /* The same projection from a TRANSPOSED copy of the layer input, XT[b][f][t] with row stride ldt (T padded to a multiple of
  * 128, zeros behind T; mgr_transpose_bt writes it): a kept feature is then a contiguous row, and the kernel's A operand is
  * staged with coalesced 16-byte loads instead of one scattered 4-byte load per element.  Only for shapes the dropout-aware
- * kernel handles - mgr_lstm_input_proj_dropout_wants_transposed says whether a copy is worth making for (drop_rate, F). */
+ * kernel handles - mgr_lstm_input_proj_dropout_wants_transposed says whether a copy is worth making for (drop_rate, F).
+ * x_absmax: an upper bound on |XT| the caller can vouch for (the output of an LSTM layer: 1; with a residual sum: 2), or 0 if it
+ * has none.  With a bound the products run on the f16 matrix pipe with every f32 operand split into an f16 (hi, lo) pair of its
+ * scaled value and f32 accumulation (22+ significant bits per operand: gemm.hip, k_gemm_nn_sparse16; the representation error is
+ * below the rounding an f32 accumulation of the same length commits); an input beyond the bound overflows f16 and shows as
+ * Inf / NaN in Z.  0, or tune key 15 = 1: v_mfma_f32_32x32x2_f32. */
 int mgr_lstm_input_proj_dropout_wants_transposed(mgr_ctx* ctx, float drop_rate, int F);
 int mgr_lstm_input_proj_dropout_t(mgr_ctx* ctx, const float* XT, int ldt, const float* mask4, float drop_rate,
                                   const float* Wp, const float* bp, float* Z, int B, int T, int F, int H, void* ws,
-                                  size_t ws_bytes);
+                                  size_t ws_bytes, float x_absmax);
 int mgr_transpose_bt(mgr_ctx* ctx, const float* X, int ldx, float* XT, int ldt, int B, int T, int F);
 /* Recurrence. reverse=1 walks t = T-1..0 and writes outputs at their original t (Bidirectional backward
  * sub-layer).  Y[b,t,0:H] with row stride ldy gets h_t (+ R[b,t,0:H] with stride ldr when R != NULL: the
@@ -157,7 +162,10 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
  * key 7: one-tile-per-wave clusters: 0 = K-split step (register-direct gather), 1 = LDS-image step.
  * key 8: 1 = the multi-CU BPTT keeps its 4-wave kernel instead of the split-role (4 compute + 4 gather waves) one, 2 = always split.
  * key 9: 1 = mgr_lstm_input_proj_dropout always takes the dense kernel.
- * key 13: 1 = mgr_dense_softmax_fwd / mgr_dense_bwd keep their LDS-tiled vector-ALU kernels where the matrix-core forms would run. */
+ * key 13: 1 = mgr_dense_softmax_fwd / mgr_dense_bwd keep their LDS-tiled vector-ALU kernels where the matrix-core forms would run.
+ * key 14: K-split scan step: 0 = recurrent product on the f16 matrix pipe with every f32 operand split into an f16 (hi, lo) pair and
+ *        f32 accumulation (22+ significant bits per operand; lstm_cluster.hip cluster_run_k16), 1 = v_mfma_f32_16x16x4_f32.
+ * key 15: 1 = the transposed-input projection / parameter-gradient GEMMs keep their f32 MFMA kernels whatever bound the caller states. */
 enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 16 };
 int mgr_tune(mgr_ctx* ctx, int key, int value);
 /* Health of the persistent multi-CU scans launched on this context since the last mgr_scan_status_clear: *out receives the OR
@@ -245,12 +253,16 @@ int mgr_lstm_param_grads_dropout(mgr_ctx* ctx, const float* X, int ldx, const fl
  * projection mgr_lstm_input_proj_dropout_t was fed): the K dimension of dW is time, so both operands (XT rows of the kept
  * features; dZ transposed into the workspace by this call) are read as contiguous float4 along t.  Results bit-identical
  * to mgr_lstm_param_grads_dropout.  Only for shapes where ..._wants_transposed() says 1; ldt % 4 == 0, ldt >= T rounded
- * up to 16, the pad zero. */
+ * up to 16, the pad zero.
+ * x_absmax: as for mgr_lstm_input_proj_dropout_t - with a bound on |XT| (and ldt >= T rounded up to 32) the dW product runs on the
+ * f16 matrix pipe with split-f16 (hi, lo) operands and f32 accumulation (k_gemm_tn_sparse16; dZ is scaled per (sample, gate
+ * column) by its own largest magnitude, so its dynamic range costs nothing); then equal to mgr_lstm_param_grads_dropout to the
+ * f32 tolerance instead of bit for bit.  0, or tune key 15 = 1: the f32 MFMA kernel. */
 int mgr_lstm_param_grads_dropout_wants_transposed(mgr_ctx* ctx, float drop_rate, int F);
 size_t mgr_lstm_param_grads_dropout_t_ws_bytes(int B, int T, int F, int H, int ldt);
 int mgr_lstm_param_grads_dropout_t(mgr_ctx* ctx, const float* XT, int ldt, const float* mask4, float drop_rate,
                                    const float* Hs, int ldh, const float* dZ, float* dWp, float* dUp, float* dbp, int B,
-                                   int T, int F, int H, int reverse, void* ws, size_t ws_bytes);
+                                   int T, int F, int H, int reverse, void* ws, size_t ws_bytes, float x_absmax);
 /* dX[b,t,0:F] (stride lddx) (+)= sum_g mask4[g] (.) (dZ_g . W_g^T); accumulate=1 adds into dX. */
 int mgr_lstm_input_grad(mgr_ctx* ctx, const float* dZ, const float* Wp, const float* mask4, float* dX,
                         int lddx, int accumulate, int B, int T, int F, int H);

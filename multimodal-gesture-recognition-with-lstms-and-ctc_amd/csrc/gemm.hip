@@ -344,9 +344,11 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nn2(const float* __restrict__ X
 // in the packed order the scans read.  At p = 0.5 that is half the MFMA work of the dense kernel for the same result.
 __global__ __launch_bounds__(64) void k_mask_compact(const float* __restrict__ mask4, int F, int Fp, int* __restrict__ kidx,
                                                      float* __restrict__ kval, int* __restrict__ kcnt,
-                                                     int* __restrict__ kpos /* [4B][F] list position of a kept feature, -1 if dropped; may be null */) {
+                                                     int* __restrict__ kpos /* [4B][F] list position of a kept feature, -1 if dropped; may be null */,
+                                                     unsigned* __restrict__ zero_word /* set to 0 (the max |W| word k_gate_major fills next); may be null */) {
   MGR_OFF_PAIRED_CUS(2);
   const int gb = blockIdx.x, lane = threadIdx.x;
+  if (zero_word && gb == 0 && lane == 0) *zero_word = 0u;
   const float* m = mask4 + (size_t)gb * F;
   int* out = kidx + (size_t)gb * Fp;
   float* val = kval + (size_t)gb * Fp;
@@ -375,15 +377,25 @@ __global__ __launch_bounds__(64) void k_mask_compact(const float* __restrict__ m
 
 // Wg[g][f][u] = Wp[f][4u + g]: gate-major copy of the packed kernel, so that the row gather of one gate pass reads
 // contiguous units instead of every fourth float (a quarter of the L2 traffic of the B operand); F x 4H floats per call.
-__global__ __launch_bounds__(256) void k_gate_major(const float* __restrict__ Wp, float* __restrict__ Wg, int F, int H) {
+// wmax (may be null): the largest |W| of the call as float bits, by atomic max (zeroed by k_mask_compact in front) - the scale of
+// the split-f16 projection.
+__global__ __launch_bounds__(256) void k_gate_major(const float* __restrict__ Wp, float* __restrict__ Wg, int F, int H, unsigned* __restrict__ wmax) {
   MGR_OFF_PAIRED_CUS(2);
   const size_t n = (size_t)F * H;
+  float m = 0.f;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float4 w = *reinterpret_cast<const float4*>(Wp + i * 4);   // (f, u): gates 0..3
     Wg[i] = w.x;
     Wg[n + i] = w.y;
     Wg[2 * n + i] = w.z;
     Wg[3 * n + i] = w.w;
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(w.x), fabsf(w.y))), fmaxf(fabsf(w.z), fabsf(w.w)));
+  }
+  if (wmax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    // (a NaN weight does not survive fmaxf; Inf does: the projection then scales by 0 and its output is NaN - visible)
+    if ((threadIdx.x & 63) == 0) atomicMax(wmax, __float_as_uint(m));
   }
 }
 
@@ -553,6 +565,154 @@ __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_gemm_nn_sparse(co
                 make_float4(acc[0][mt][reg] + bias.x, acc[1][mt][reg] + bias.y, acc[2][mt][reg] + bias.z, acc[3][mt][reg] + bias.w);
         }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ nn, dropout-aware, split-f16
+// The same tile walk as k_gemm_nn_sparse<2, true> (transposed activations, 128 rows x 64 units x 4 gates, one K loop per gate over the
+// kept features, 16 list positions per stage) on the f16 matrix pipe (round 4): every f32 operand goes to LDS as an f16 (hi, lo)
+// pair of its scaled value - x sx = hi + lo to 22+ bits - and a stage is THREE v_mfma_f32_32x32x16_f16 per 32 x 32 block
+// (hi hi + lo hi + hi lo, f32 accumulation; the dropped lo lo term is 2^-22 of the product) instead of sixteen
+// v_mfma_f32_32x32x2_f32: 96 instead of 1024 matrix-pipe cycles per stage and block.  See lstm_cluster.hip (cluster_run_k16) for the
+// error argument; the parity tests hold both kernels to the same bounds against the f64 oracle.
+// Scales (powers of two, so scaling is exact): sx from the caller's bound on |X| (activations of LSTM layers: 1, with a residual
+// sum 2), sw from the largest |W| of the call (k_gate_major) times the largest mask factor 1 / (1 - p); the largest scaled magnitude
+// lies in [2^14, 2^15).  An input beyond the stated bound overflows f16 and shows as Inf / NaN in Z - never silently.
+// List position p = q + 4c of a stage (quad q, slot c: the staging threads' order) is MFMA k-slot (half q >> 1, element 4 (q & 1) + c).
+typedef _Float16 f16x8_ __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256, 2) void k_gemm_nn_sparse16(const float* __restrict__ X, int ldx, const int* __restrict__ kidx,
+                                                             const float* __restrict__ kval, const int* __restrict__ kcnt,
+                                                             const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                             float* __restrict__ Z, int B, int T, int Fp, int F, int H,
+                                                             const unsigned* __restrict__ wmax, float vmax, float sx) {
+  constexpr int TM = SP_TM, TU = 64, SK = SP_SK, NT = 256, QT = 64, RPT = 2;
+  __shared__ __attribute__((aligned(16))) _Float16 Ah[2][2][TM][8], Al[2][2][TM][8];   // [buffer][k half][row][8 k-slots]
+  __shared__ __attribute__((aligned(16))) _Float16 Bh[2][2][TU][8], Bl[2][2][TU][8];
+  __shared__ unsigned short Ls[SP_MAXF];
+  __shared__ float Vs[SP_MAXF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int N = 4 * H;
+  const int q = tid / QT, r = tid % QT;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int ncol = (H + TU - 1) / TU, nrow = (T + TM - 1) / TM;
+  float sw = 1.f;
+  {
+    const float m = __uint_as_float(*wmax) * vmax;
+    int ex = 0;
+    if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &ex);
+    ex = ex < -60 ? -60 : ex;
+    sw = m < 3.0e38f ? ldexpf(1.f, 15 - ex) : 0.f;
+  }
+  const float inv = sw > 0.f ? 1.f / (sw * sx) : __uint_as_float(0x7FC00000u);
+  struct Regs {
+    float a[RPT * 4], w[4], v[4];
+  };
+  const int x = blockIdx.x & 7, jj = blockIdx.x >> 3;   // XCD-aware tile order: see k_gemm_nn_sparse
+  const int rt = (jj / ncol) * 8 + x;
+  if (rt >= nrow * B) return;
+  const int u0 = (jj % ncol) * TU, r0 = (rt % nrow) * TM, b = rt / nrow;
+  const float* Xb = X + (size_t)b * F * ldx + r0 + r;
+  const int ucl = (u0 + r < H) ? u0 + r : H - 1;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[g][mt][e] = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int nst = (kcnt[g * B + b] + SK - 1) / SK;
+    {
+      const int* list = kidx + ((size_t)g * B + b) * Fp;
+      const float* lval = kval + ((size_t)g * B + b) * Fp;
+      for (int i = tid; i < nst * SK; i += NT) {
+        Ls[i] = (unsigned short)list[i];
+        Vs[i] = lval[i];
+      }
+    }
+    __syncthreads();
+    const float* Wg = Wp + (size_t)g * F * H + ucl;
+    auto fetch = [&](Regs& R, int st) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int p = st * SK + q + 4 * c;
+        const int f = Ls[p];
+        R.v[c] = Vs[p];
+        R.w[c] = Wg[(size_t)f * H];
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) R.a[i * 4 + c] = Xb[(size_t)f * ldx + QT * i];
+      }
+    };
+    auto split4 = [](const float (&xs)[4], f16x4_& hi, f16x4_& lo) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const _Float16 h = (_Float16)xs[c];
+        hi[c] = h;
+        lo[c] = (_Float16)(xs[c] - (float)h);
+      }
+    };
+    auto stash = [&](const Regs& R, int buf) {
+      f16x4_ hi, lo;
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const float xs[4] = {R.a[i * 4] * sx, R.a[i * 4 + 1] * sx, R.a[i * 4 + 2] * sx, R.a[i * 4 + 3] * sx};
+        split4(xs, hi, lo);
+        *reinterpret_cast<f16x4_*>(&Ah[buf][q >> 1][r + QT * i][(q & 1) * 4]) = hi;
+        *reinterpret_cast<f16x4_*>(&Al[buf][q >> 1][r + QT * i][(q & 1) * 4]) = lo;
+      }
+      const float ws[4] = {R.w[0] * R.v[0] * sw, R.w[1] * R.v[1] * sw, R.w[2] * R.v[2] * sw, R.w[3] * R.v[3] * sw};
+      split4(ws, hi, lo);
+      *reinterpret_cast<f16x4_*>(&Bh[buf][q >> 1][r][(q & 1) * 4]) = hi;
+      *reinterpret_cast<f16x4_*>(&Bl[buf][q >> 1][r][(q & 1) * 4]) = lo;
+    };
+    auto mma = [&](int buf) {
+      const int ra = wr * 64 + l31, ub = wc * 32 + l31;
+      const f16x8_ bh = *reinterpret_cast<const f16x8_*>(&Bh[buf][lh][ub][0]);
+      const f16x8_ bl = *reinterpret_cast<const f16x8_*>(&Bl[buf][lh][ub][0]);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const f16x8_ ah = *reinterpret_cast<const f16x8_*>(&Ah[buf][lh][ra + 32 * mt][0]);
+        const f16x8_ al = *reinterpret_cast<const f16x8_*>(&Al[buf][lh][ra + 32 * mt][0]);
+        acc[g][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[g][mt], 0, 0, 0);
+        acc[g][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[g][mt], 0, 0, 0);
+        acc[g][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[g][mt], 0, 0, 0);
+      }
+    };
+    if (nst > 0) {
+      Regs R0, R1;
+      fetch(R0, 0);
+      if (nst > 1) fetch(R1, 1);
+      stash(R0, 0);
+      __syncthreads();
+      for (int st = 0; st < nst; st += 2) {
+        if (st + 2 < nst) fetch(R0, st + 2);
+        mma(0);
+        if (st + 1 < nst) stash(R1, 1);
+        __syncthreads();
+        if (st + 1 < nst) {
+          if (st + 3 < nst) fetch(R1, st + 3);
+          mma(1);
+          if (st + 2 < nst) stash(R0, 0);
+          __syncthreads();
+        }
+      }
+    }
+  }
+  const int unit = u0 + wc * 32 + l31;
+  if (unit < H) {
+    const float4 bias = *reinterpret_cast<const float4*>(bp + unit * 4);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = r0 + wr * 64 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        if (row < T)
+          *reinterpret_cast<float4*>(Z + ((size_t)b * T + row) * N + unit * 4) =
+              make_float4(fmaf(acc[0][mt][reg], inv, bias.x), fmaf(acc[1][mt][reg], inv, bias.y), fmaf(acc[2][mt][reg], inv, bias.z),
+                          fmaf(acc[3][mt][reg], inv, bias.w));
+      }
   }
 }
 
@@ -733,6 +893,128 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_sparse(const float* __restri
       for (int reg = 0; reg < 16; ++reg) {
         const int r = ACC_ROW(wr, mt, reg, lane);
         if (q0 + r < cnt && u < H) out[(size_t)(q0 + r) * H + u] = acc[mt][nt][reg] * rowf[r];
+      }
+    }
+}
+
+// The transposed-operand form of k_gemm_tn_sparse on the f16 matrix pipe (round 4): both operands as split-f16 (hi, lo) pairs of
+// their scaled values, three v_mfma_f32_32x32x16_f16 per 32 x 32 block and 16 time steps (hi hi + lo hi + hi lo, f32 accumulation)
+// instead of eight v_mfma_f32_32x32x2_f32 - see k_gemm_nn_sparse16 / lstm_cluster.hip for the error argument.  The K dimension is
+// time: a thread's 8 consecutive time steps of its row ARE one lane's operand of one MFMA, so a stage of 32 steps goes to LDS as two
+// 16-byte writes per operand part.  Scales (powers of two): X by the caller's bound on |X|; dZT PER ROW (sample, gate column) by
+// the row's largest magnitude (k_transpose_bt): a row's scale factors out of the sum over time exactly and is divided out of its
+// output column, so the gradient's dynamic range across units, samples and gates costs nothing.
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_sparse16(const float* __restrict__ X, int ldx, const int* __restrict__ kidx,
+                                                             const float* __restrict__ kval, const int* __restrict__ kcnt,
+                                                             const float* __restrict__ dZ, int ldz, const unsigned* __restrict__ zmax,
+                                                             float* __restrict__ P, int B, int T, int Fp, int F, int H, float sx) {
+  constexpr int TK = 32;   // time steps per stage
+  __shared__ __attribute__((aligned(16))) _Float16 Ah[2][2][2][BM][8], Al[2][2][2][BM][8];   // [buffer][k-step][k half][row][8]
+  __shared__ __attribute__((aligned(16))) _Float16 Bh[2][2][2][BN][8], Bl[2][2][2][BN][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int nft = (Fp + BM - 1) / BM, nut = (H + BN - 1) / BN, wps = 4 * nft * nut;   // (decode: see k_gemm_tn_sparse)
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int b = (jj / wps) * 8 + xcd;
+  if (b >= B) return;
+  const int w = jj % wps, g = w / (nft * nut), gb = g * B + b;
+  const int q0 = ((w / nut) % nft) * BM, u0 = (w % nut) * BN;
+  const int cnt = kcnt[gb];
+  if (q0 >= cnt) return;
+  const int N = 4 * H;
+  const int m = tid & 127, kb = tid >> 7;   // staging: this thread's row (feature / unit) and k-step of the stage (16 time steps)
+  const int q = q0 + m < Fp ? q0 + m : Fp - 1;
+  const int un = u0 + m < H ? u0 + m : H - 1;
+  const float* xrow = X + ((size_t)b * F + kidx[(size_t)gb * Fp + q]) * ldx + 16 * kb;
+  const float* zrow = dZ + ((size_t)b * N + 4 * un + g) * ldz + 16 * kb;
+  auto zscale = [&](int unit) -> float {   // the power of two that puts the row's largest |dZ| in [2^14, 2^15)
+    const float zm = __uint_as_float(zmax[(size_t)b * N + 4 * unit + g]);
+    int ex = 0;
+    if (zm > 0.f && zm < 3.0e38f) (void)frexpf(zm, &ex);
+    ex = ex < -100 ? -100 : ex;
+    return zm < 3.0e38f ? ldexpf(1.f, 15 - ex) : __uint_as_float(0x7FC00000u);   // (an Inf / NaN gradient stays visible)
+  };
+  const float sz = zscale(un);
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  float4 ra[4], rb[4];
+  auto fetch = [&](int t0) {   // (t0 + 32 <= the padded row length; the pad is zero)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const float4*>(xrow + t0 + 4 * i);
+      rb[i] = *reinterpret_cast<const float4*>(zrow + t0 + 4 * i);
+    }
+  };
+  auto split8 = [](const float4& v0, const float4& v1, float s, f16x8_& hi, f16x8_& lo) {
+    const float xs[8] = {v0.x * s, v0.y * s, v0.z * s, v0.w * s, v1.x * s, v1.y * s, v1.z * s, v1.w * s};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const _Float16 h = (_Float16)xs[e];
+      hi[e] = h;
+      lo[e] = (_Float16)(xs[e] - (float)h);
+    }
+  };
+  auto stash = [&](int buf) {
+    f16x8_ hi, lo;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      split8(ra[2 * hf], ra[2 * hf + 1], sx, hi, lo);
+      *reinterpret_cast<f16x8_*>(&Ah[buf][kb][hf][m][0]) = hi;
+      *reinterpret_cast<f16x8_*>(&Al[buf][kb][hf][m][0]) = lo;
+      split8(rb[2 * hf], rb[2 * hf + 1], sz, hi, lo);
+      *reinterpret_cast<f16x8_*>(&Bh[buf][kb][hf][m][0]) = hi;
+      *reinterpret_cast<f16x8_*>(&Bl[buf][kb][hf][m][0]) = lo;
+    }
+  };
+  auto mma = [&](int buf) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8_ ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8_*>(&Ah[buf][ks][lh][wr * 64 + i * 32 + l31][0]);
+        al[i] = *reinterpret_cast<const f16x8_*>(&Al[buf][ks][lh][wr * 64 + i * 32 + l31][0]);
+        bh[i] = *reinterpret_cast<const f16x8_*>(&Bh[buf][ks][lh][wc * 64 + i * 32 + l31][0]);
+        bl[i] = *reinterpret_cast<const f16x8_*>(&Bl[buf][ks][lh][wc * 64 + i * 32 + l31][0]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+    }
+  };
+  const int nst = (T + TK - 1) / TK;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (int st = 0; st < nst; ++st) {
+    const bool more = st + 1 < nst;
+    if (more) fetch((st + 1) * TK);
+    mma(buf);
+    if (more) stash(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  float* out = P + (size_t)gb * Fp * H;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int u = u0 + ACC_COL(wc, nt, lane);
+      const float cf = 1.f / (zscale(u < H ? u : H - 1) * sx);
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = ACC_ROW(wr, mt, reg, lane);
+        if (q0 + r < cnt && u < H) out[(size_t)(q0 + r) * H + u] = acc[mt][nt][reg] * cf * kval[(size_t)gb * Fp + q0 + r];
       }
     }
 }
@@ -950,8 +1232,8 @@ int mgr_lstm_input_proj_pair(mgr_ctx* c, const float* X, int ldx, const float* m
 
 size_t mgr_lstm_input_proj_dropout_ws_bytes(int B, int F, int H) {
   const size_t Fp = (size_t)(F + SP_SK - 1) / SP_SK * SP_SK;
-  return 2 * mgr_align_up((size_t)4 * B * Fp * sizeof(int), 256) + mgr_align_up((size_t)4 * B * sizeof(int), 256) +
-         mgr_align_up((size_t)F * 4 * H * sizeof(float), 256);
+  return 2 * mgr_align_up((size_t)4 * B * Fp * sizeof(int), 256) + mgr_align_up((size_t)4 * B * sizeof(int), 256) + 256 +
+         mgr_align_up((size_t)F * 4 * H * sizeof(float), 256);   // (+256: the max |W| word of the split-f16 kernel)
 }
 
 static bool sparse_proj_shape(const mgr_ctx* c, float drop_rate, int F) {
@@ -966,21 +1248,25 @@ int mgr_lstm_input_proj_dropout_wants_transposed(mgr_ctx* c, float drop_rate, in
 }
 
 static int input_proj_dropout_impl(mgr_ctx* c, const float* X, int ldx, bool transposed, const float* mask4, float drop_rate,
-                                   const float* Wp, const float* bp, float* Z, int B, int T, int F, int H, void* ws, size_t ws_bytes) {
+                                   const float* Wp, const float* bp, float* Z, int B, int T, int F, int H, void* ws, size_t ws_bytes,
+                                   float x_absmax = 0.f) {
   const int Fp = (F + SP_SK - 1) / SP_SK * SP_SK;
   const size_t lbytes = mgr_align_up((size_t)4 * B * Fp * sizeof(int), 256);
   char* w = reinterpret_cast<char*>(ws);
   int* kidx = reinterpret_cast<int*>(w);
   float* kval = reinterpret_cast<float*>(w + lbytes);
   int* kcnt = reinterpret_cast<int*>(w + 2 * lbytes);
-  float* Wg = reinterpret_cast<float*>(w + 2 * lbytes + mgr_align_up((size_t)4 * B * sizeof(int), 256));
+  unsigned* wmax = reinterpret_cast<unsigned*>(w + 2 * lbytes + mgr_align_up((size_t)4 * B * sizeof(int), 256));
+  float* Wg = reinterpret_cast<float*>(w + 2 * lbytes + mgr_align_up((size_t)4 * B * sizeof(int), 256) + 256);
   hipStream_t s = mgr_stream(c);
+  // split-f16 kernel (tune key 15 = 1: never): transposed input with a stated bound on |X|, a drop rate that bounds the mask factor
+  const bool f16 = transposed && x_absmax > 0.f && x_absmax < 1.0e30f && drop_rate < 0.99f && c->tune[15] == 0;
   mgr_prof_begin(c, MGR_K_GEMM_NN);
-  hipLaunchKernelGGL(k_mask_compact, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp, kidx, kval, kcnt, (int*)nullptr);
+  hipLaunchKernelGGL(k_mask_compact, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp, kidx, kval, kcnt, (int*)nullptr, wmax);
   {
     const size_t n = (size_t)F * H;
     const int wgs = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(k_gate_major, dim3(wgs), dim3(256), 0, s, Wp, Wg, F, H);
+    hipLaunchKernelGGL(k_gate_major, dim3(wgs), dim3(256), 0, s, Wp, Wg, F, H, wmax);
   }
   // 128-unit tiles (tune key 11 = 2) are faster alone (audio L2 2.77 against 3.03 ms) but slower in the training step
   // (39.7 against 38.5 ms/step): a 512-thread workgroup needs two free wave slots on all four SIMDs of a CU at once and
@@ -988,7 +1274,13 @@ static int input_proj_dropout_impl(mgr_ctx* c, const float* X, int ldx, bool tra
   const bool wide = c->tune[11] == 2 && !transposed;
   const int tu = wide ? 128 : 64;
   const int ntiles = ((H + tu - 1) / tu) * ((((T + SP_TM - 1) / SP_TM) * B + 7) / 8) * 8;   // (row tiles padded to the 8 XCDs)
-  if (transposed)
+  if (f16) {
+    int ex;
+    (void)frexpf(x_absmax, &ex);                       // x_absmax = m 2^ex, m in [0.5, 1): |X| sx < 2^15
+    const float sx = ldexpf(1.f, 15 - ex);
+    hipLaunchKernelGGL(k_gemm_nn_sparse16, dim3(ntiles), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H, wmax,
+                       1.f / (1.f - drop_rate), sx);
+  } else if (transposed)
     hipLaunchKernelGGL((k_gemm_nn_sparse<2, true>), dim3(ntiles), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H);
   else if (wide)
     hipLaunchKernelGGL((k_gemm_nn_sparse<4, false>), dim3(ntiles), dim3(512), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H);
@@ -1011,7 +1303,7 @@ int mgr_lstm_input_proj_dropout(mgr_ctx* c, const float* X, int ldx, const float
 }
 
 int mgr_lstm_input_proj_dropout_t(mgr_ctx* c, const float* XT, int ldt, const float* mask4, float drop_rate, const float* Wp,
-                                  const float* bp, float* Z, int B, int T, int F, int H, void* ws, size_t ws_bytes) {
+                                  const float* bp, float* Z, int B, int T, int F, int H, void* ws, size_t ws_bytes, float x_absmax) {
   MGR_REQUIRE(c && XT && mask4 && Wp && bp && Z, "null argument");
   MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0, "bad shape");
   MGR_REQUIRE(ldt % 4 == 0 && ldt >= (T + SP_TM - 1) / SP_TM * SP_TM, "the transposed copy must be padded to whole row tiles of %d (ldt %d, T %d)", SP_TM, ldt, T);
@@ -1019,13 +1311,14 @@ int mgr_lstm_input_proj_dropout_t(mgr_ctx* c, const float* XT, int ldt, const fl
   MGR_REQUIRE(aligned16(XT) && aligned16(bp) && aligned16(Z) && aligned16(Wp), "XT / bp / Z / Wp must be 16-byte aligned");
   MGR_REQUIRE((size_t)F * ldt < (1u << 31), "sample block too large");
   MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_input_proj_dropout_ws_bytes(B, F, H), "workspace too small");
-  return input_proj_dropout_impl(c, XT, ldt, true, mask4, drop_rate, Wp, bp, Z, B, T, F, H, ws, ws_bytes);
+  return input_proj_dropout_impl(c, XT, ldt, true, mask4, drop_rate, Wp, bp, Z, B, T, F, H, ws, ws_bytes, x_absmax);
 }
 
 // XT[b][f][0..ldt) = X[b][0..T)[f], zero for t >= T (ldt: T padded to whole row tiles of the dropout-aware projection)
 namespace {
 __global__ __launch_bounds__(256) void k_transpose_bt(const float* __restrict__ X, int ldx, float* __restrict__ XT, int ldt, int T, int F,
-                                                      long long xtb /* batch stride of XT; 0: F * ldt */, int fill /* columns written: ldt or less */) {
+                                                      long long xtb /* batch stride of XT; 0: F * ldt */, int fill /* columns written: ldt or less */,
+                                                      unsigned* __restrict__ rowmax /* [B][F] largest |x| of a row of XT as float bits, by atomic max (zeroed by the caller); may be null */) {
   MGR_OFF_PAIRED_CUS(2);
   __shared__ float tile[64][65];
   const int b = blockIdx.z, t0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
@@ -1041,7 +1334,14 @@ __global__ __launch_bounds__(256) void k_transpose_bt(const float* __restrict__ 
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int f = f0 + ty + 4 * i, t = t0 + tx;
-    if (f < F && t < fill) XTb[(size_t)f * ldt + t] = tile[tx][ty + 4 * i];
+    const float v = tile[tx][ty + 4 * i];
+    if (f < F && t < fill) XTb[(size_t)f * ldt + t] = v;
+    if (rowmax) {   // (a wave holds 64 time steps of ONE row)
+      float m = fabsf(v);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      if (tx == 0 && f < F) atomicMax(rowmax + (size_t)b * F + f, __float_as_uint(m));
+    }
   }
 }
 }  // namespace
@@ -1050,7 +1350,7 @@ int mgr_transpose_bt(mgr_ctx* c, const float* X, int ldx, float* XT, int ldt, in
   MGR_REQUIRE(c && X && XT, "null argument");
   MGR_REQUIRE(B > 0 && T > 0 && F > 0 && ldx >= F && ldt >= T, "bad shape");
   mgr_prof_begin(c, MGR_K_MISC);
-  hipLaunchKernelGGL(k_transpose_bt, dim3((ldt + 63) / 64, (F + 63) / 64, B), dim3(256), 0, mgr_stream(c), X, ldx, XT, ldt, T, F, 0LL, ldt);
+  hipLaunchKernelGGL(k_transpose_bt, dim3((ldt + 63) / 64, (F + 63) / 64, B), dim3(256), 0, mgr_stream(c), X, ldx, XT, ldt, T, F, 0LL, ldt, (unsigned*)nullptr);
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_MISC);
   return 0;
@@ -1129,7 +1429,7 @@ size_t mgr_lstm_param_grads_dropout_ws_bytes(int B, int T, int F, int H) {
 // from transposed copies (XT given by the caller, dZT made here)
 static int param_grads_dropout_impl(mgr_ctx* c, const float* X, int ldx, const float* XT, int ldt, const float* mask4, float drop_rate,
                                     const float* Hs, int ldh, const float* dZ, float* dWp, float* dUp, float* dbp, int B, int T, int F,
-                                    int H, int reverse, void* ws, bool sparse) {
+                                    int H, int reverse, void* ws, bool sparse, float x_absmax = 0.f) {
   mgr_prof_begin(c, MGR_K_GEMM_TN);
   // dU / db first: they are short, and in the training step the long dW kernel then ends this direction's work (the step
   // runs these under an encoder scan; what is left over after the scan is exposed)
@@ -1147,12 +1447,25 @@ static int param_grads_dropout_impl(mgr_ctx* c, const float* X, int ldx, const f
     float* P = reinterpret_cast<float*>(w);
     w += mgr_align_up((size_t)4 * B * Fp * H * sizeof(float), 256);
     hipStream_t s = mgr_stream(c);
-    hipLaunchKernelGGL(k_mask_compact, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp, kidx, kval, kcnt, kpos);
+    hipLaunchKernelGGL(k_mask_compact, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp, kidx, kval, kcnt, kpos, (unsigned*)nullptr);
     const int grid = 8 * ((B + 7) / 8) * 4 * ((Fp + BM - 1) / BM) * ((H + BN - 1) / BN);
     if (XT) {
       float* dZT = reinterpret_cast<float*>(w);   // [B][4H][ldt]
-      hipLaunchKernelGGL(k_transpose_bt, dim3((ldt + 63) / 64, (4 * H + 63) / 64, B), dim3(256), 0, s, dZ, 4 * H, dZT, ldt, T, 4 * H, 0LL, ldt);
-      hipLaunchKernelGGL((k_gemm_tn_sparse<true>), dim3(grid), dim3(256), 0, s, XT, ldt, kidx, kval, kcnt, dZT, ldt, P, B, T, Fp, F, H);
+      w += mgr_align_up((size_t)B * 4 * H * ldt * sizeof(float), 256);
+      // split-f16 kernel (tune key 15 = 1: never): a stated bound on |X|, whole stages of 32 time steps in the padded rows
+      const bool f16 = x_absmax > 0.f && x_absmax < 1.0e30f && c->tune[15] == 0 && ldt >= (T + 31) / 32 * 32;
+      unsigned* zmax = reinterpret_cast<unsigned*>(w);   // [B][4H] largest |dZ| of a (sample, gate column)
+      if (f16) MGR_HIP(hipMemsetAsync(zmax, 0, (size_t)B * 4 * H * sizeof(unsigned), s));
+      hipLaunchKernelGGL(k_transpose_bt, dim3((ldt + 63) / 64, (4 * H + 63) / 64, B), dim3(256), 0, s, dZ, 4 * H, dZT, ldt, T, 4 * H, 0LL, ldt,
+                         f16 ? zmax : (unsigned*)nullptr);
+      if (f16) {
+        int ex;
+        (void)frexpf(x_absmax, &ex);
+        hipLaunchKernelGGL(k_gemm_tn_sparse16, dim3(grid), dim3(256), 0, s, XT, ldt, kidx, kval, kcnt, dZT, ldt, zmax, P, B, T, Fp, F, H,
+                           ldexpf(1.f, 15 - ex));
+      } else {
+        hipLaunchKernelGGL((k_gemm_tn_sparse<true>), dim3(grid), dim3(256), 0, s, XT, ldt, kidx, kval, kcnt, dZT, ldt, P, B, T, Fp, F, H);
+      }
     } else {
       hipLaunchKernelGGL((k_gemm_tn_sparse<false>), dim3(grid), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, dZ, 0, P, B, T, Fp, F, H);
     }
@@ -1185,19 +1498,20 @@ int mgr_lstm_param_grads_dropout_wants_transposed(mgr_ctx* c, float drop_rate, i
 }
 
 size_t mgr_lstm_param_grads_dropout_t_ws_bytes(int B, int T, int F, int H, int ldt) {
-  return mgr_lstm_param_grads_dropout_ws_bytes(B, T, F, H) + mgr_align_up((size_t)B * 4 * H * ldt * sizeof(float), 256);
+  return mgr_lstm_param_grads_dropout_ws_bytes(B, T, F, H) + mgr_align_up((size_t)B * 4 * H * ldt * sizeof(float), 256) +
+         mgr_align_up((size_t)B * 4 * H * sizeof(unsigned), 256);   // (dZT, the row maxima of dZT)
 }
 
 int mgr_lstm_param_grads_dropout_t(mgr_ctx* c, const float* XT, int ldt, const float* mask4, float drop_rate, const float* Hs, int ldh,
                                    const float* dZ, float* dWp, float* dUp, float* dbp, int B, int T, int F, int H, int reverse,
-                                   void* ws, size_t ws_bytes) {
+                                   void* ws, size_t ws_bytes, float x_absmax) {
   MGR_REQUIRE(c && XT && mask4 && Hs && dZ && dWp && dUp && dbp, "null argument");
   MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0 && ldh >= H, "bad shape");
   MGR_REQUIRE(ldt % 4 == 0 && ldt >= (T + BK - 1) / BK * BK, "the transposed copy must be padded to whole stages of %d time steps (ldt %d, T %d)", BK, ldt, T);
   MGR_REQUIRE(aligned16(dZ) && aligned16(XT), "dZ / XT must be 16-byte aligned");
   MGR_REQUIRE(sparse_dw_shape(c, mask4, drop_rate, F), "shape / drop rate not handled by the dropout-aware kernel (ask mgr_lstm_param_grads_dropout_wants_transposed)");
   MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_param_grads_dropout_t_ws_bytes(B, T, F, H, ldt), "workspace too small");
-  return param_grads_dropout_impl(c, nullptr, 0, XT, ldt, mask4, drop_rate, Hs, ldh, dZ, dWp, dUp, dbp, B, T, F, H, reverse, ws, true);
+  return param_grads_dropout_impl(c, nullptr, 0, XT, ldt, mask4, drop_rate, Hs, ldh, dZ, dWp, dUp, dbp, B, T, F, H, reverse, ws, true, x_absmax);
 }
 
 int mgr_lstm_input_grad(mgr_ctx* c, const float* dZ, const float* Wp, const float* mask4, float* dX, int lddx,
@@ -1217,7 +1531,7 @@ int mgr_lstm_input_grad(mgr_ctx* c, const float* dZ, const float* Wp, const floa
 }  // extern "C"
 
 int mgr_transpose_bt_strided(mgr_ctx* c, const float* X, int ldx, float* XT, int ldt, long long xtb, int ldt_fill, int B, int T, int F) {
-  hipLaunchKernelGGL(k_transpose_bt, dim3((ldt_fill + 63) / 64, (F + 63) / 64, B), dim3(256), 0, mgr_stream(c), X, ldx, XT, ldt, T, F, xtb, ldt_fill);
+  hipLaunchKernelGGL(k_transpose_bt, dim3((ldt_fill + 63) / 64, (F + 63) / 64, B), dim3(256), 0, mgr_stream(c), X, ldx, XT, ldt, T, F, xtb, ldt_fill, (unsigned*)nullptr);
   MGR_LAUNCH_CHECK();
   return 0;
 }

@@ -33,7 +33,7 @@ struct Plan {
 
 size_t job_ws(const mgr_scan_job& j) {
   int ks = j.H / 4;
-  size_t img = (size_t)((ks + 3) / 4) * 256;
+  size_t img = (size_t)((ks + 7) / 8) * 512;   // 1 KiB per 16 units, in whole K-blocks of 32 (the split-f16 step's image)
   int nbg = (j.B + 15) / 16;
   return mgr_align_up((size_t)nbg * 2 * img * sizeof(float), 256);
 }
@@ -290,7 +290,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
       const mgr_scan_job& j = jobs[i];
       ClusterJob& cj = L.job[L.njobs++];
       int ks = j.H / 4;
-      size_t img = (size_t)((ks + 3) / 4) * 256;
+      size_t img = (size_t)((ks + 7) / 8) * 512;   // (job_ws)
       cj.Z = j.Z; cj.Up = j.Up; cj.Y = j.Y; cj.R = j.R; cj.G = j.gates; cj.Cs = j.cs;
       cj.ldy = j.ldy; cj.ldr = j.ldr; cj.B = j.B; cj.T = j.T; cj.H = j.H; cj.reverse = j.reverse;
       cj.ks = ks; cj.tpw = P.cfg[i].tpw; cj.nw = P.cfg[i].nw;
@@ -301,6 +301,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     }
     // tune key 7: 0 = K-split step for one-tile-per-wave clusters, 1 = LDS-image step for every cluster
     L.ksplit = ks_ok ? 1 : 0;
+    L.split16 = c->tune[14] == 0;   // tune key 14: 1 = f32 MFMA in the K-split step
     // transposed outputs: the K-split kernel writes them itself; everything else gets a transpose behind the scans (below)
     if (mgr_cluster_uses_ks(L, P.exchange)) {
       int k = 0;

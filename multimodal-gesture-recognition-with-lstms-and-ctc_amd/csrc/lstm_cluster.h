@@ -53,6 +53,7 @@ struct ClusterLaunch {
   ClusterCommon cm;
   int njobs;
   int ksplit;        // one-tile-per-wave clusters use the K-split step (cluster_run_ks: register-direct gather); 0 = LDS-image step
+  int split16;       // K-split launches: f16 (hi, lo) operands on the f16 matrix pipe (cluster_run_k16; tune key 14 = 1: f32 MFMA step)
   int xcd_local;     // K-split launches: clusters are laid out on workgroup ids congruent mod 8 (one XCD under the dispatcher's
                      // round-robin); a cluster that FINDS all its members on one XCD publishes with plain stores into that L2
   ClusterJob job[MGR_MAX_SCAN_JOBS];

@@ -556,6 +556,294 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split-f16 variant of the K-split step (round 4; the default - tune key 14 = 1 keeps the f32 MFMA step above).
+//
+// The recurrence h_{t-1} U is an f32 product; v_mfma_f32_16x16x4_f32 delivers it at 64 FLOP per cycle and SIMD, the f16 form
+// v_mfma_f32_16x16x32_f16 at 1024.  Here every f32 operand x travels as TWO f16 values, x*s = hi + lo (s a power of two, hi =
+// rn_f16(x*s), lo = rn_f16(x*s - hi): |x*s - hi - lo| <= 2^-23 |x*s|, 22+ significant bits), and the product is taken as
+//     U h  ~  (Uhi hhi + Ulo hhi + Uhi hlo) / (sU sh)                      [three f16 MFMAs, ONE f32 accumulator]
+// The dropped Ulo hlo term is 2^-22 of the product; f16 x f16 products are exact in the f32 accumulator.  The representation
+// error (~2^-21.5 per product) is BELOW what an f32 dot product of this length loses to rounding in its accumulation
+// (measured, K = 500: 2.0e-7 absolute against 1.5e-6 for an f32 sgemm, both against f64; tests/test_gpu_kernels.py holds the same
+// bounds against the f64 oracle for both steps).  Scales: h in [-1, 1] -> sh = 2^15 (hi <= 32768 < 65504; a lo below the f16
+// normal range is an absolute error <= 2^-14 / 2^15 = 2^-29); U -> sU = the power of two that puts the workgroup's largest
+// |U| in [2^14, 2^15) (computed in the prologue from the slice the workgroup holds).  12 MFMAs of 16 cycles replace 128 of 32 per
+// wave and step at H = 500: 0.3 instead of 1.8 us of matrix pipe per step.
+//
+// Same cluster geometry as cluster_run_ks (a workgroup = 16 hidden units = 4 tiles, wave w = a quarter of K for all four tiles,
+// partial sums meet in LDS, ONE barrier per step, parity words as the flag), with these differences:
+//   * K is walked in blocks of 32 units.  The exchange image of a slot is [K-block][hi | lo][1 KiB]; the 1 KiB of a part holds, for
+//     B-operand lane (kg, n), the 16 bytes = 8 f16 = units 32 kb + 8 kg + 0..7 of sample n.  A block is produced by two workgroups
+//     (16 units each, half `kg >> 1`), inside a half the 16-byte chunks are ordered [n >> 2][n & 3][kg & 1]:
+//   * the FINISHING lanes are dealt so that wave u owns samples 4u .. 4u+3 and lane l the unit (l & 15) of the workgroup: the two
+//     lanes of a unit pair swap their packed (hi, lo) word by DPP, the even lane keeps (hi_even, hi_odd), the odd lane (lo_even,
+//     lo_odd), and ONE store instruction of the wave writes two whole 128-byte lines: the hi line and the lo line of its four samples.
+//     No ds_bpermute.  (Z / Y / gate / c rows of a sample are read and written as 16 consecutive units.)
+//   * every published word carries the epoch parity in bit 0: for a hi word that is the last mantissa bit of the even unit's hi -
+//     set BEFORE lo is taken, so lo absorbs it; for a lo word it moves the even unit's lo by one ulp (2^-22 of h).
+//   * Y, the saved gates and c are the f32 values; the recurrence sees h rounded to 22+ bits (as every f32 consumer of Y would
+//     see it rounded to 24).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int K16_TILE = 260 * 4;   // floats of one tile's partial sums: 4 source waves x 64 cells x f32x4, + 4 cells of padding
+constexpr int K16_LDS_FLOATS = 2 * 4 * K16_TILE + 4 * KS_STG * 64 + 4 * 2 * 256 + 4 * 2 * 64 + 16;
+
+template <int NBW>   // K-blocks (of 32 units) per wave: H <= 128 * NBW
+__device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const ClusterCommon& cm, int bg, int ug, float* smem, bool fast) {
+  static_assert(NBW >= 1 && NBW <= 4, "1..4 K-blocks per wave (H <= 512)");
+  unsigned* status = cm.status;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..3
+  const int H = jb.H, N = 4 * H, G = jb.G_;
+  const int NKB = (H + 31) >> 5;          // K-blocks of the layer
+  const int IMGB = NKB * 2048;            // bytes of one exchange slot
+  const int B = jb.B, T = jb.T, reverse = jb.reverse;
+  // operand roles (MFMA A / B / C lanes)
+  const int om = lane & 15, okg = lane >> 4;
+  // finishing role: cell (unit 16 ug + (lane & 15), sample 4 wave + (lane >> 4))
+  const int fn = 4 * wave + (lane >> 4), fu = lane & 15;
+  const int b = bg * 16 + fn;
+  const bool bvalid = b < B;
+  const int bc = bvalid ? b : B - 1;
+  const int unit = 16 * ug + fu;
+  const bool cvalid = unit < H;
+  const float* __restrict__ Z = jb.Z;
+  const float* __restrict__ Up = jb.Up;
+  const float* Rp = jb.R;
+  float *Yp = jb.Y, *Gp = jb.G, *Csp = jb.Cs;
+  int ldr = jb.ldr, ldy = jb.ldy;
+  asm volatile("" : "+s"(Rp), "+s"(Yp), "+s"(Gp), "+s"(Csp), "+s"(ldr), "+s"(ldy));   // (see cluster_run_ks)
+
+  const int qb = wave * NBW;     // K range of this wave: K-blocks [qb, qb + nb)
+  int nb = NKB - qb;
+  nb = nb < 0 ? 0 : (nb > NBW ? NBW : nb);
+  nb = __builtin_amdgcn_readfirstlane(nb);
+
+  float* red = smem;                                                          // [2][tile] K16_TILE
+  float* stg = smem + 2 * 4 * K16_TILE + wave * (KS_STG * 64);                // [KS_STG][64 lanes]
+  float* zring = smem + 2 * 4 * K16_TILE + 4 * KS_STG * 64 + wave * (2 * 256);                 // [2][64] f32x4
+  float* rring = smem + 2 * 4 * K16_TILE + 4 * KS_STG * 64 + 4 * 2 * 256 + wave * (2 * 64);   // [2][64]
+  float* wmax = smem + 2 * 4 * K16_TILE + 4 * KS_STG * 64 + 4 * 2 * 256 + 4 * 2 * 64;         // [4]
+  const unsigned zring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)zring);
+  const unsigned rring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)rring);
+
+  // ---- weights: the workgroup's slice of U as f16 (hi, lo) A fragments.  Lane (m = lane & 15, kg = lane >> 4) of tile tt, K-block kb
+  // holds U[32 kb + 8 kg + e][gate column m of tile tt], e < 8.  Two passes over the slice: its largest magnitude, then the split.
+  auto uval = [&](int tt, int i, int e) -> float {
+    const int k = 32 * (qb + i) + 8 * okg + e, uu = 16 * ug + 4 * tt + (om >> 2);
+    return (k < H && uu < H) ? Up[(size_t)k * N + uu * 4 + (om & 3)] : 0.f;
+  };
+  float umax = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) umax = fmaxf(umax, fabsf(uval(tt, i, e)));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) umax = fmaxf(umax, __shfl_xor(umax, o));
+  if (lane == 0) wmax[wave] = umax;
+  __syncthreads();
+  umax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  int ex = 0;
+  if (umax > 0.f && umax < 3.0e38f) (void)frexpf(umax, &ex);   // umax = m 2^ex, m in [0.5, 1)   (Inf / NaN weights: the products are
+  ex = ex < -60 ? -60 : ex;                                    //  NaN, the non-finite guard below reports the launch)
+  const float sU = ldexpf(1.f, 15 - ex);        // largest |U| sU in [2^14, 2^15)
+  const float inv = ldexpf(1.f, ex - 30);       // 1 / (sU 2^15)
+  f16x8 ah[4][NBW], al[4][NBW];
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = uval(tt, i, e) * sU;
+        const _Float16 hi = (_Float16)x;
+        ah[tt][i][e] = hi;
+        al[tt][i][e] = (_Float16)(x - (float)hi);
+      }
+
+  float* ytrow = nullptr;
+  if (jb.YT && cvalid && bvalid) {
+    ytrow = jb.YT + (size_t)b * jb.ytb + (size_t)unit * jb.ldt;
+#pragma unroll
+    for (int i = 0; i < KS_STG; ++i) stg[i * 64 + lane] = 0.f;
+  }
+  char* xb = reinterpret_cast<char*>(jb.xbuf) + (size_t)bg * 2 * IMGB;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, 2 * IMGB, 0x00020000);
+  // gather: byte offset of this lane's 16-byte chunk in the hi part of its K-blocks (the lo part is 1 KiB further).  A half whose
+  // workgroup does not exist (the last K-block of an odd G) or a K-block beyond nb re-reads a valid chunk: it meets zero weights.
+  unsigned goff[NBW];
+#pragma unroll
+  for (int i = 0; i < NBW; ++i) {
+    const int kb = qb + (i < nb ? i : 0);
+    const int half = (2 * kb + (okg >> 1) < G) ? (okg >> 1) : 0;
+    goff[i] = (unsigned)(kb * 2048 + half * 512 + (om >> 2) * 128 + (om & 3) * 32 + (okg & 1) * 16);
+  }
+  // publish: the even lane of a unit pair stores the hi word, the odd lane the lo word
+  const unsigned poff = (unsigned)((ug >> 1) * 2048 + (lane & 1) * 1024 + (ug & 1) * 512 + wave * 128 + (lane >> 4) * 32 + (fu >> 1) * 4);
+
+  const int zunit = cvalid ? unit : 0;   // (padding cells fetch a valid address and ignore it)
+  const unsigned zvoff = (unsigned)(((size_t)bc * T * N + (size_t)zunit * 4) * sizeof(float));
+  const unsigned rvoff = Rp ? (unsigned)(((size_t)bc * T * ldr + zunit) * sizeof(float)) : 0u;
+  auto prefetch = [&](int step) {   // (everything wave-uniform except the lane offsets)
+    if (step < T) {
+      const int t = reverse ? T - 1 - step : step;
+      mgr_dma_b128(Z + (size_t)t * N, zvoff, zring_lds + (step & 1) * 1024);
+      if (Rp) mgr_dma_b32(Rp + (size_t)t * ldr, rvoff, rring_lds + (step & 1) * 256);
+    }
+  };
+  prefetch(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the weight loads are retired before the time loop (see cluster_run_ks)
+
+  // partial sums in LDS: cell (unit-in-tile uq, sample n) of a tile sits at slot n*4 + ((uq + (n >> 2)) & 3) of its source wave's 64,
+  // tiles 260 slots apart: the writes (fixed uq, 16 samples) and the finishing reads (fixed sample, 16 units) are conflict-free
+  const int wslot = om * 4 + ((okg + (om >> 2)) & 3);
+  const int rslot = (fu >> 2) * 260 + fn * 4 + (((fu & 3) + (fn >> 2)) & 3);
+
+  float c = 0.f;
+  bool nonfinite = false;
+  bool failed = false;
+  unsigned rounds = 0;
+  auto tick = [&]() {
+    ++rounds;
+    if ((rounds & 255u) == 0) {
+      unsigned st;
+      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(st) : "v"(status) : "memory");
+      if (__builtin_amdgcn_readfirstlane(st) != 0u) failed = true;
+    }
+    if (rounds > KS_ROUND_LIMIT) {
+      failed = true;
+      if (lane == 0) __hip_atomic_store(status, MGR_ST_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+
+  for (int step = 0; step < T; ++step) {
+    const int t = reverse ? T - 1 - step : step;
+    f32x4 acc[4];
+    u32x4 v[2 * NBW];
+    const bool gather = step > 0 && nb > 0 && !failed;
+    if (gather) {
+      const unsigned sbase = (unsigned)(((step - 1) & 1) * IMGB);
+      const unsigned par = ((((unsigned)(step - 1)) >> 1) & 1u) ^ 1u;
+      for (;;) {
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+          v[2 * i] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i], sbase, 16);              // sc1
+          v[2 * i + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i] + 1024u, sbase, 16);   // sc1
+        }
+        unsigned a_and = 0xFFFFFFFFu, a_or = 0u;
+#pragma unroll
+        for (int i = 0; i < 2 * NBW; ++i) {
+          a_and &= v[i].x & v[i].y & v[i].z & v[i].w;
+          a_or |= v[i].x | v[i].y | v[i].z | v[i].w;
+        }
+        const bool lane_fresh = par ? (a_and & 1u) != 0u : (a_or & 1u) == 0u;
+        if (__all(lane_fresh) || failed) break;
+        tick();
+        if (failed) break;
+      }
+    }
+    if (gather && !failed) {
+#pragma unroll
+      for (int i = 0; i < NBW; ++i) {
+        if (i == (NBW > 1 ? 1 : 0)) prefetch(step + 1);
+        const f16x8 bh = __builtin_bit_cast(f16x8, v[2 * i]), bl = __builtin_bit_cast(f16x8, v[2 * i + 1]);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tt][i], bh, i == 0 ? zero : acc[tt], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tt][i], bh, acc[tt], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tt][i], bl, acc[tt], 0, 0, 0);
+      }
+    } else {   // the first step (h_{-1} = 0), a wave without K range, a launch that gave up
+      prefetch(step + 1);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float* rbuf = red + (step & 1) * (4 * K16_TILE);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(rbuf + tt * K16_TILE + (wave * 64 + wslot) * 4) = acc[tt];
+    if (Rp)
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    const f32x4 zt = *reinterpret_cast<const f32x4*>(zring + (step & 1) * 256 + lane * 4);
+    const float rt = Rp ? rring[(step & 1) * 64 + lane] : 0.f;
+    __syncthreads();
+    const unsigned par = (((unsigned)step >> 1) & 1u) ^ 1u;
+    unsigned packed = par | (par << 16);   // a padding cell: (hi, lo) = (0, 0) with the current parity
+    float h = 0.f, yv = 0.f;
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cvalid) {
+      const float* mine = rbuf + rslot * 4;
+      f32x4 sum = *reinterpret_cast<const f32x4*>(mine);
+#pragma unroll
+      for (int src = 1; src < 4; ++src) sum += *reinterpret_cast<const f32x4*>(mine + src * 64 * 4);
+      f32x4 tot;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) tot[g] = fmaf(sum[g], inv, zt[g]);
+      h = mgr_cell_fwd(tot[0], tot[1], tot[2], tot[3], c, g4);
+      if (!(fabsf(h) < 2.f) && !nonfinite) {
+        __hip_atomic_fetch_or(cm.sticky, MGR_ST_NONFINITE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nonfinite = true;
+      }
+      if (nonfinite) {
+        h = 0.f;
+        c = 0.f;
+      }
+      yv = nonfinite ? __uint_as_float(0x7FC00000u) : h;
+      // h 2^15 = hi + lo; the epoch parity rides in bit 0 of the words the even lane's values open (hi word and lo word)
+      const float hs = h * 32768.f;
+      unsigned hib = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)hs);
+      if (!(lane & 1)) hib = (hib & ~1u) | par;
+      const float hif = (float)__builtin_bit_cast(_Float16, (unsigned short)hib);
+      unsigned lob = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(hs - hif));
+      if (!(lane & 1)) lob = (lob & ~1u) | par;
+      packed = hib | (lob << 16);
+    }
+    if (step + 1 < T) {
+      const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)packed, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: the pair's other lane
+      const unsigned w = (lane & 1) ? ((other >> 16) | (packed & 0xFFFF0000u))      // (lo_even, lo_odd)
+                                    : ((packed & 0xFFFFu) | (other << 16));         // (hi_even, hi_odd)
+      if (fast)
+        __builtin_amdgcn_raw_buffer_store_b32(w, rs, poff, (step & 1) * IMGB, 0);
+      else
+        __builtin_amdgcn_raw_buffer_store_b32(w, rs, poff, (step & 1) * IMGB, 16);  // sc1
+    }
+    if (cvalid && bvalid) {
+      size_t row = (size_t)b * T + t;
+      const float yo = yv + rt;
+      typedef __attribute__((address_space(1))) float gfloat;
+      typedef __attribute__((address_space(1))) f32x4 gf32x4;
+      ((gfloat*)Yp)[row * ldy + unit] = yo;
+      if (Gp) *(gf32x4*)(Gp + (row * H + unit) * 4) = (f32x4){g4.x, g4.y, g4.z, g4.w};
+      if (Csp) ((gfloat*)Csp)[row * H + unit] = c;
+      if (ytrow) {
+        stg[(t & (KS_STG - 1)) * 64 + lane] = yo;
+        if (reverse ? (t & (KS_STG - 1)) == 0 : ((t & (KS_STG - 1)) == KS_STG - 1 || t == T - 1)) {
+          float* dst = ytrow + (t & ~(KS_STG - 1));
+          f32x4 o0, o1;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            o0[i] = stg[i * 64 + lane];
+            o1[i] = stg[(4 + i) * 64 + lane];
+          }
+          *reinterpret_cast<f32x4*>(dst) = o0;
+          *reinterpret_cast<f32x4*>(dst + 4) = o1;
+#pragma unroll
+          for (int i = 0; i < KS_STG; ++i) stg[i * 64 + lane] = 0.f;
+        }
+      }
+    }
+  }
+  if (ytrow) {
+    for (int t0 = (T + KS_STG - 1) / KS_STG * KS_STG; t0 + 4 <= jb.ldt; t0 += 4)
+      *reinterpret_cast<f32x4*>(ytrow + t0) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+}
+
 #define CLKS_FOREACH(X) X(125) X(75) X(32) X(25)
 
 #define CL_FOREACH(X) \
@@ -639,6 +927,50 @@ __global__ __launch_bounds__(256, 2) void k_scan_cluster_ks_s(ClusterLaunch L) {
   scan_cluster_ks_body<true>(L, smem);
 }
 
+// the split-f16 step (cluster_run_k16): same launch geometry and layouts as the two kernels above
+template <bool SMALL>
+__device__ __forceinline__ void scan_cluster_k16_body(const ClusterLaunch& L, float* smem) {
+  mgr_cluster_enter(L.cm);
+#define K16_RUN(NBW) \
+  if (nbw == NBW) { cluster_run_k16<NBW>(jb, L.cm, bg, ug, smem, same); return mgr_cluster_exit(L.cm); }
+#define K16_DISPATCH                                     \
+  {                                                      \
+    const int nbw = (((jb.H + 31) >> 5) + 3) >> 2;       \
+    K16_RUN(1)                                           \
+    if constexpr (!SMALL) { K16_RUN(2) K16_RUN(3) K16_RUN(4) } \
+    return;                                              \
+  }
+  if (L.xcd_local) {
+    for (int k_ = 0; k_ < L.njobs; ++k_) {
+      const ClusterJob& jb = L.job[k_];
+      const int w_ = (int)blockIdx.x - jb.cls_begin, G = jb.G_;
+      if (w_ < 0 || w_ >= (jb.cls_nclusters + 7) / 8 * 8 * G) continue;
+      int cl, ug;
+      const bool same = mgr_cluster_octet(L.cm, jb.cls_begin, G, jb.cls_rot, w_, cl, ug);
+      const int bg = cl - jb.cls_cluster0;
+      if (cl >= jb.cls_nclusters || bg < 0 || bg >= jb.nbg) continue;
+      K16_DISPATCH
+    }
+    return;
+  }
+  MGR_FOR_MY_JOB(L, jb, bg, ug) {
+    const bool same = false;
+    K16_DISPATCH
+  }
+#undef K16_DISPATCH
+#undef K16_RUN
+}
+
+__global__ __launch_bounds__(256, 2) void k_scan_cluster_k16(ClusterLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  scan_cluster_k16_body<false>(L, smem);
+}
+
+__global__ __launch_bounds__(256, 2) void k_scan_cluster_k16_s(ClusterLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  scan_cluster_k16_body<true>(L, smem);
+}
+
 }  // namespace
 
 bool mgr_cluster_supported(int ks, int tpw) {
@@ -709,6 +1041,8 @@ int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool a
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_ks), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_ks_s), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_k16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_k16_s), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     c->attr_done |= 1u;
   }
   MGR_REQUIRE(!L.xcd_local || ks_eligible(L, any_exchange, waves), "XCD-local layout is only understood by the K-split kernel");
@@ -716,7 +1050,12 @@ int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool a
     // partial-sum exchange, staging tiles of the transposed output, Z / R rings (no h image): 50 KiB, two workgroups per CU
     bool small = true;
     for (int i = 0; i < L.njobs; ++i) small = small && L.job[i].ks <= 32;
-    if (small)
+    if (L.split16) {
+      if (small)
+        hipLaunchKernelGGL(k_scan_cluster_k16_s, dim3(total_wgs), dim3(256), K16_LDS_FLOATS * sizeof(float), mgr_stream(c), L);
+      else
+        hipLaunchKernelGGL(k_scan_cluster_k16, dim3(total_wgs), dim3(256), K16_LDS_FLOATS * sizeof(float), mgr_stream(c), L);
+    } else if (small)
       hipLaunchKernelGGL(k_scan_cluster_ks_s, dim3(total_wgs), dim3(256), KS_LDS_FLOATS * sizeof(float), mgr_stream(c), L);
     else
       hipLaunchKernelGGL(k_scan_cluster_ks, dim3(total_wgs), dim3(256), KS_LDS_FLOATS * sizeof(float), mgr_stream(c), L);

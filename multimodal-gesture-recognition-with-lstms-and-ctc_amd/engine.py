@@ -395,8 +395,10 @@ class Engine:
                 m, Wp, bp, Z = pair[4 * d:4 * d + 4]
                 ws = Ls[d].ws_sp
                 if XT is not None:
+                    # (XT is the output of LSTM layers: |h| <= 1, with the residual sum of the encoder stacks <= 2 - the bound
+                    # the library's split-f16 kernel scales by, mgr.h)
                     self.dev.call("mgr_lstm_input_proj_dropout_t", XT, self.ldt, m, float(Ls[d].p), Wp, bp, Z, B, T, fin, H,
-                                  ws, ws.nbytes)
+                                  ws, ws.nbytes, 2.0)
                 else:
                     self.dev.call("mgr_lstm_input_proj_dropout", X, ldx, m, float(Ls[d].p), Wp, bp, Z, B, T, fin, H, ws, ws.nbytes)
         else:
@@ -1177,7 +1179,7 @@ class Engine:
                     if L.ws_pg.nbytes < need:          # (+ the transposed dZ; first use only)
                         L.ws_pg = self.mem.bytes(need)
                     dev.call("mgr_lstm_param_grads_dropout_t", XinT, self.ldt, mptr, float(L.p), Hbuf.view(di * H, (1,)), ldh, L.dZ,
-                             L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes)
+                             L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes, 2.0)   # (|XinT| <= 2: _project_pair)
                 elif mptr:   # input dropout was applied: dW only has rows for the kept features of each (gate, sample)
                     dev.call("mgr_lstm_param_grads_dropout", Xin, ldx, mptr, float(L.p), Hbuf.view(di * H, (1,)), ldh, L.dZ,
                              L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes)

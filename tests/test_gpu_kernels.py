@@ -508,8 +508,19 @@ def test_input_proj_dropout_sparse_equals_dense(device, B, T, F, H, p):
         xt = XT.download()
         assert np.array_equal(xt[:, :, :T], X.transpose(0, 2, 1)) and np.all(xt[:, :, T:] == 0)
         tr = dev.empty((B, T, N))
-        dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, dM, 0.5, dW, db, tr, B, T, F, H, ws, ws.nbytes)
-        assert np.array_equal(tr.download(), sparse.download())
+        dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, dM, 0.5, dW, db, tr, B, T, F, H, ws, ws.nbytes, 0.0)
+        assert np.array_equal(tr.download(), sparse.download())      # (no bound on |X| stated: the f32 MFMA kernel)
+        # with a bound on |X| the products run as split-f16 pairs on the f16 matrix pipe (k_gemm_nn_sparse16): the same tolerance
+        # against fp64 as the f32 kernels; a looser bound only moves the scale
+        for bound in (float(np.abs(X).max()), 4.0 * float(np.abs(X).max())):
+            tr.upload(np.full((B, T, N), np.nan, f32))
+            dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, dM, p if p < 0.99 else 0.5, dW, db, tr, B, T, F, H, ws, ws.nbytes, bound)
+            assert np.abs(tr.download() - ref).max() <= tol
+        # an input beyond the stated bound is not silently wrong: f16 overflows and Z carries Inf / NaN
+        if p < 0.99:
+            tr.upload(np.zeros((B, T, N), f32))
+            dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, dM, p, dW, db, tr, B, T, F, H, ws, ws.nbytes, float(np.abs(X).max()) / 1024.0)
+            assert not np.all(np.isfinite(tr.download()))
     assert dev.lib.mgr_lstm_input_proj_dropout_wants_transposed(dev.ctx, 0.5, 1000) == 1
     assert dev.lib.mgr_lstm_input_proj_dropout_wants_transposed(dev.ctx, 0.5, 39) == 0
     assert dev.lib.mgr_lstm_input_proj_dropout_wants_transposed(dev.ctx, 0.1, 1000) == 0
@@ -557,9 +568,26 @@ def test_param_grads_dropout_sparse_equals_dense(device, B, T, F, H, p, reverse)
             ws = dev.bytes(dev.lib.mgr_lstm_param_grads_dropout_t_ws_bytes(B, T, F, H, ldt))
             dev.call("mgr_memset", ws, 0xFF, ws.nbytes)        # the workspace arrives dirty (all-ones words are NaNs)
             gW, gU, gb = dev.empty((F, N)), dev.empty((H, N)), dev.empty((N,))
-            dev.call("mgr_lstm_param_grads_dropout_t", XT, ldt, dM, 0.5, dH, H, ddZ, gW, gU, gb, B, T, F, H, reverse, ws, ws.nbytes)
+            dev.call("mgr_lstm_param_grads_dropout_t", XT, ldt, dM, 0.5, dH, H, ddZ, gW, gU, gb, B, T, F, H, reverse, ws, ws.nbytes, 0.0)
             assert np.array_equal(gW.download(), outs[1][0])
             assert np.array_equal(gU.download(), outs[1][1]) and np.array_equal(gb.download(), outs[1][2])
+            # with a bound on |X|: split-f16 operands on the f16 matrix pipe (rows padded to 32 steps), dZ scaled per (sample, gate
+            # column) - here with dZ rows spread over 24 orders of magnitude; the same tolerance against fp64 as the f32 kernels
+            if ldt % 32 == 0:
+                spread = (10.0 ** rng.uniform(-12, 12, size=(B, 1, N))).astype(f32)
+                dZw = dZ * spread
+                refw = np.empty((F, N))
+                for g in range(4):
+                    refw[:, gate == g] = np.einsum("btf,btn->fn", X.astype(np.float64) * M[g][:, None, :], dZw[:, :, gate == g].astype(np.float64))
+                for zz, rr in ((dZ, ref), (dZw, refw)):
+                    dzz = dev.array(zz)
+                    dev.call("mgr_memset", ws, 0xFF, ws.nbytes)
+                    gW.upload(np.full((F, N), np.nan, f32))
+                    dev.call("mgr_lstm_param_grads_dropout_t", XT, ldt, dM, 0.5, dH, H, dzz, gW, gU, gb, B, T, F, H, reverse, ws, ws.nbytes,
+                             float(np.abs(X).max()))
+                    got = gW.download()
+                    colscale = np.maximum(np.abs(rr).max(axis=0, keepdims=True), 1e-30)   # per column: the spread is per column
+                    assert np.all(np.isfinite(got)) and (np.abs(got - rr) / colscale).max() <= 3e-5
 
 
 @pytest.mark.parametrize("H,B,T,path", [(300, 20, 75, 0), (500, 33, 70, 0), (100, 16, 64, 0), (128, 5, 33, 0), (300, 20, 75, 1),

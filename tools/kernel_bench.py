@@ -39,9 +39,11 @@ def gemm(dev, B, T, F, H, mask=True):
         ldt = (T + 127) // 128 * 128
         XT = dev.zeros((B, F, ldt))
         mt = timeit(dev, lambda: dev.call("mgr_transpose_bt", X, F, XT, ldt, B, T, F))
-        ms = timeit(dev, lambda: dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, m, 0.5, Wp, bp, Z, B, T, F, H, wsd, wsd.nbytes))
+        ms = timeit(dev, lambda: dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, m, 0.5, Wp, bp, Z, B, T, F, H, wsd, wsd.nbytes, 0.0))
         print("  dropout-aware (transposed copy)         : %7.3f ms  %6.1f TF executed  (+ transpose %.3f ms, %.0f GB/s)"
               % (ms, 0.5 * fl / ms / 1e9, mt, 2.0 * B * T * F * 4 / mt / 1e6))
+        ms = timeit(dev, lambda: dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, m, 0.5, Wp, bp, Z, B, T, F, H, wsd, wsd.nbytes, 8.0))
+        print("  dropout-aware (transposed, split f16)   : %7.3f ms  %6.1f TF executed (f32-equivalent)" % (ms, 0.5 * fl / ms / 1e9))
         XT.free(); wsd.free()
     dZ = Z
     gW, gU, gb = dev.empty((F, 4 * H)), dev.empty((H, 4 * H)), dev.empty((4 * H,))
@@ -57,8 +59,11 @@ def gemm(dev, B, T, F, H, mask=True):
         wsd = dev.bytes(dev.lib.mgr_lstm_param_grads_dropout_t_ws_bytes(B, T, F, H, ldt))
         gW2 = dev.empty((F, 4 * H))
         ms = timeit(dev, lambda: dev.call("mgr_lstm_param_grads_dropout", X, F, m, 0.5, Y, H, dZ, gW, gU, gb, B, T, F, H, 0, wsd, wsd.nbytes))
-        ms2 = timeit(dev, lambda: dev.call("mgr_lstm_param_grads_dropout_t", XT, ldt, m, 0.5, Y, H, dZ, gW2, gU, gb, B, T, F, H, 0, wsd, wsd.nbytes))
+        ms2 = timeit(dev, lambda: dev.call("mgr_lstm_param_grads_dropout_t", XT, ldt, m, 0.5, Y, H, dZ, gW2, gU, gb, B, T, F, H, 0, wsd, wsd.nbytes, 0.0))
         same = np.array_equal(gW.download(), gW2.download())
+        ms3 = timeit(dev, lambda: dev.call("mgr_lstm_param_grads_dropout_t", XT, ldt, m, 0.5, Y, H, dZ, gW2, gU, gb, B, T, F, H, 0, wsd, wsd.nbytes, 8.0))
+        print("  dropout-aware dW, split f16 operands: %7.3f ms (%5.1f TF f32-equivalent)  max |diff| / max |dW| = %.2e"
+              % (ms3, 2.0 * B * T * (0.5 * F + H) * 4 * H / ms3 / 1e9, np.abs(gW.download() - gW2.download()).max() / np.abs(gW.download()).max()))
         fx = 2.0 * B * T * (0.5 * F + H) * 4 * H
         print("  dropout-aware dW: gathered %7.3f ms (%5.1f TF executed) | transposed operands %7.3f ms (%5.1f TF)  bit-identical=%s"
               % (ms, fx / ms / 1e9, ms2, fx / ms2 / 1e9, same))

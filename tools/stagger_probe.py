@@ -39,7 +39,7 @@ audio, skel = layer(1000, 500), layer(600, 300)
 
 def proj(L):
     for D in L["dir"]:
-        dev.call("mgr_lstm_input_proj_dropout_t", L["XT"], ldt, D["m"], 0.5, D["W"], D["b"], D["Z"], B, T, L["F"], L["H"], D["ws"], D["ws"].nbytes)
+        dev.call("mgr_lstm_input_proj_dropout_t", L["XT"], ldt, D["m"], 0.5, D["W"], D["b"], D["Z"], B, T, L["F"], L["H"], D["ws"], D["ws"].nbytes, 2.0)
 
 
 def scan_jobs(layers):
@@ -79,7 +79,7 @@ def bptt():
 def dw():
     for D in fus:
         dev.call("mgr_lstm_param_grads_dropout_t", featT, ldt, D["m"], 0.5, YF.view(D["rev"] * Hf, (1,)), 2 * Hf, D["dZ"], D["gW"], D["gU"], D["gb"],
-                 B, T, Fw, Hf, D["rev"], D["ws"], D["ws"].nbytes)
+                 B, T, Fw, Hf, D["rev"], D["ws"], D["ws"].nbytes, 2.0)
 
 
 ES, S0, S3 = 1, 2, 3
