@@ -89,8 +89,12 @@ def scan(dev, B, T, H):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="gemm,scan")
+    ap.add_argument("--tune", action="append", default=[], help="mgr_tune KEY=VALUE (repeatable)")
     a = ap.parse_args()
     dev = _capi.Device(0)
+    for kv in a.tune:
+        k, v = kv.split("=")
+        dev.call("mgr_tune", int(k), int(v))
     print(dev.name, dev.cu_count, "CUs")
     if a.what == "gemm1":
         gemm(dev, 64, 1900, 1000, 500)
@@ -100,7 +104,9 @@ if __name__ == "__main__":
         gemm(dev, 64, 1900, 600, 300)
         gemm(dev, 64, 1900, 1600, 100)
         gemm(dev, 64, 1900, 39, 500)
-    if "scan" in a.what:
+    if a.what == "scan100":
+        scan(dev, 64, 1900, 100)
+    elif "scan" in a.what:
         scan(dev, 64, 1900, 100)
         scan(dev, 64, 1900, 128)
         scan(dev, 64, 1900, 300)
