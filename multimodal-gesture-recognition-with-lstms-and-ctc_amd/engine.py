@@ -8,6 +8,7 @@ multimodal_fusion/sequence_decoding.py:121); there is no CPU fallback.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -84,7 +85,10 @@ class Schedule:
     """
 
     def __init__(self, pipeline=True, defer_param_grads=True, encoders_run_ahead=True, resident_wait_us=2000,
-                 transposed_inputs=True):
+                 transposed_inputs=True, bptt_beside_deepest_scan=None):
+        if bptt_beside_deepest_scan is None:
+            bptt_beside_deepest_scan = os.environ.get("MGR_SCHED_BPTT_LATE", "1") != "0"
+        self.bptt_beside_deepest_scan = bool(bptt_beside_deepest_scan)
         self.transposed_inputs = bool(transposed_inputs)
         self.pipeline = bool(pipeline)
         self.defer_param_grads = bool(defer_param_grads)
@@ -1037,6 +1041,14 @@ class Engine:
                 dev.record(self.EV_PREV)   # only the launch that WRITES that buffer (the deepest scan) has to wait for it
             else:
                 dev.wait(ES, 0)
+        # Free-running encoder stream (Schedule.bptt_beside_deepest_scan): the next batch's encoder pass up to its deepest projections
+        # is handed to the encoder stream BEFORE this step's fusion work is enqueued - it depends on nothing of this step, and the
+        # host needs ~1-2 ms to enqueue the fusion layer and the head, during which that stream would sit idle
+        any_tr_stream_ = any(s_["trainable"] for s_ in sp.streams)
+        free_gen = None
+        if pipelined and ahead and sch.bptt_beside_deepest_scan and sp.fusion and not any_tr_stream_:
+            free_gen = self._next_encoders_free(next_inputs, depth, self.rng_step + 1, self._step_id + 1)
+            next(free_gen)
         # ---- 2. fusion layer, head, CTC, loss read-back point
         self._enqueue_fusion_head(True, rand, cur, self.rng_step, dense=False)
         self.rng_step += 1
@@ -1075,11 +1087,15 @@ class Engine:
             self._xin_user[self._xin_slot] = this_step + (1 if any_tr_stream else 0)
         # ---- 3. backward
         deferred = None
+        late_bptt = None    # (Schedule.bptt_beside_deepest_scan) the fusion layer's BPTT itself is held back with its GEMMs
         if sp.fusion:
             Hf = sp.fusion["H"]
-            deferred = self._bilstm_backward("fusion", self.dYF, 2 * Hf, self._featin, W, W, self.YF, 2 * Hf,
-                                             self.dFEAT if any_tr_stream else None, W, defer_param_grads=defer,
-                                             XinT=self._featT.get(self._featin.ptr))
+            bargs = ("fusion", self.dYF, 2 * Hf, self._featin, W, W, self.YF, 2 * Hf, self.dFEAT if any_tr_stream else None, W)
+            bkw = dict(defer_param_grads=defer, XinT=self._featT.get(self._featin.ptr))
+            if defer and sch.bptt_beside_deepest_scan and not any_tr_stream:
+                late_bptt = lambda: self._bilstm_backward(*bargs, **bkw)
+            else:
+                deferred = self._bilstm_backward(*bargs, **bkw)
         if any_tr_stream:
             col = 0
             for s in sp.streams:
@@ -1091,19 +1107,53 @@ class Engine:
 
         def finish():
             dev.stream(0)
-            if deferred is not None:
-                deferred()
+            d = late_bptt() if late_bptt is not None else deferred
+            if d is not None:
+                d()
             if apply_update:
                 self.apply_gradients()
 
         # ---- 4. parameter gradients + optimizer, and (pipelined) the next step's encoder pass
         if not pipelined:
             finish()
+        elif free_gen is not None:
+            free_gen.send(finish)
         else:
-            self._enqueue_next_encoders(next_inputs, finish, defer, ahead, depth)
+            self._enqueue_next_encoders(next_inputs, finish, defer, ahead, depth, free_running=late_bptt is not None)
         dev.stream(0)
 
-    def _enqueue_next_encoders(self, next_inputs, finish, defer, ahead, depth):
+    def _next_encoders_free(self, next_inputs, depth, rng_step, consumer_step):
+        """Schedule.bptt_beside_deepest_scan, as a two-part generator.  Part 1 (before this step's fusion work is enqueued): the next
+        batch's encoder pass on stream ES up to and including its deepest projection GEMMs.  Part 2 (after the loss read-back point,
+        resumed with send(finish)): stream 0 waits for those GEMMs, then - once the deepest scan launched behind them is resident -
+        runs `finish` (this step's BPTT, dW / dU / db GEMMs, optimizer) beside that scan."""
+        dev, ES = self.dev, self.ES
+        self._feat_idx ^= 1
+        nxt = self._feat_ring[self._feat_idx]
+        self._prefetched_for = next_inputs
+        if next_inputs is not None:
+            dev.stream(ES)
+            self._upload_inputs(next_inputs, None, True, stream=ES)
+            self._xin_user[self._xin_slot] = consumer_step
+        phases = self._encoder_phases(True, None, nxt, ES, rng_step)
+        for tag, k in phases:
+            if tag == "projected" and k == depth - 1:
+                break
+        dev.stream(0)
+        finish = yield
+        dev.wait(0, ES)
+        dev.stream(0)
+        if self.schedule.resident_wait_us > 0 and not getattr(self.comm, "host_blocking", False):
+            dev.call("mgr_stream_wait_next_resident", self.schedule.resident_wait_us)
+        finish()
+        dev.wait_event(ES, self.EV_PREV)   # (the deepest scan overwrites the FEAT buffer the previous step's dW GEMMs read)
+        for _ in phases:
+            pass
+        self._prefetched = nxt
+        dev.stream(0)
+        yield
+
+    def _enqueue_next_encoders(self, next_inputs, finish, defer, ahead, depth, free_running=False):
         """Encoder pass of the NEXT step on stream ES into the other FEAT buffer, concurrent with what enqueue_train_step
         has put on stream 0; `finish` (this step's parameter-gradient GEMMs + optimizer) is placed according to the schedule."""
         dev, ES = self.dev, self.ES
@@ -1129,7 +1179,7 @@ class Engine:
             for tag, k in self._encoder_phases(True, None, nxt, ES, self.rng_step):
                 if tag != "projected":
                     continue
-                if ahead and k == 0:
+                if ahead and k == 0 and not free_running:
                     dev.stream(ES)
                     dev.wait_event(ES, self.EV_FPROJ)
                 if k == depth - 1:
