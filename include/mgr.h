@@ -117,7 +117,10 @@ int mgr_lstm_input_proj_dropout(mgr_ctx* ctx, const float* X, int ldx, const flo
  * has none.  With a bound the products run on the f16 matrix pipe with every f32 operand split into an f16 (hi, lo) pair of its
  * scaled value and f32 accumulation (22+ significant bits per operand: gemm.hip, k_gemm_nn_sparse16; the representation error is
  * below the rounding an f32 accumulation of the same length commits); an input beyond the bound overflows f16 and shows as
- * Inf / NaN in Z.  0, or tune key 15 = 1: v_mfma_f32_32x32x2_f32. */
+ * Inf / NaN in Z.  0, or tune key 15 = 1: v_mfma_f32_32x32x2_f32.
+ * mask4 may be NULL (no dropout: inference) when a bound is given: the plain dense projection on the f16 pipe (k_gemm_nn_dense16: one
+ * K loop over all features, the A tile staged once for the four gates; tune key 10 = 2 takes it with a mask as well, the mask
+ * factors folded into the weight tiles). */
 int mgr_lstm_input_proj_dropout_wants_transposed(mgr_ctx* ctx, float drop_rate, int F);
 int mgr_lstm_input_proj_dropout_t(mgr_ctx* ctx, const float* XT, int ldt, const float* mask4, float drop_rate,
                                   const float* Wp, const float* bp, float* Z, int B, int T, int F, int H, void* ws,
@@ -162,6 +165,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
  * key 7: one-tile-per-wave clusters: 0 = K-split step (register-direct gather), 1 = LDS-image step.
  * key 8: 1 = the multi-CU BPTT keeps its 4-wave kernel instead of the split-role (4 compute + 4 gather waves) one, 2 = always split.
  * key 9: 1 = mgr_lstm_input_proj_dropout always takes the dense kernel.
+ * key 10: 2 = mgr_lstm_input_proj_dropout_t with a bound on |XT| takes the dense-K split-f16 kernel with a mask as well.
  * key 13: 1 = mgr_dense_softmax_fwd / mgr_dense_bwd keep their LDS-tiled vector-ALU kernels where the matrix-core forms would run.
  * key 14: K-split scan step: 0 = recurrent product on the f16 matrix pipe with every f32 operand split into an f16 (hi, lo) pair and
  *        f32 accumulation (22+ significant bits per operand; lstm_cluster.hip cluster_run_k16), 1 = v_mfma_f32_16x16x4_f32.

@@ -81,7 +81,7 @@ static inline size_t mgr_align_up(size_t x, size_t a) { return (x + a - 1) / a *
 // wait.  A kernel allocated MORE than 80 registers can only land on the single-workgroup CUs, where its instructions cost the scans
 // nothing.  (The clobber makes hipcc account v87: allocation 88.)
 #ifndef MGR_FLOOR_MASK
-#define MGR_FLOOR_MASK 7
+#define MGR_FLOOR_MASK 0   // (7 won 0.25 ms with f32 scans; with the split-f16 scans 0 wins 0.25 ms: profiles/r04_scan_probes.txt)
 #endif
 #define MGR_OFF_PAIRED_CUS(group) do { if constexpr (((MGR_FLOOR_MASK) >> (group)) & 1) asm volatile("" ::: "v87"); } while (0)
 

@@ -581,6 +581,16 @@ __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_gemm_nn_sparse(co
 // List position p = q + 4c of a stage (quad q, slot c: the staging threads' order) is MFMA k-slot (half q >> 1, element 4 (q & 1) + c).
 typedef _Float16 f16x8_ __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
+// x = hi + lo, both f16: hi = rn(x), lo = rn(x - hi), x an f32 VALUE.  The empty asm pins that value: without it hipcc contracts a
+// product that feeds x into the subtraction (v_fma_mix: exact product - hi') AND takes that hi' by rounding the exact product to
+// f16 in one step, while the hi it stores was rounded from the f32 product - two different roundings of x now and then, i.e. a lo
+// that belongs to another hi: one operand in a few hundred with 11 instead of 22 bits (seen with the mask factor 2.5; a power-of-two
+// factor makes the product exact and hides it).
+__device__ __forceinline__ void mgr_split_f16(float x, _Float16& hi, _Float16& lo) {
+  asm volatile("" : "+v"(x));
+  hi = (_Float16)x;
+  lo = (_Float16)(x - (float)hi);
+}
 __global__ __launch_bounds__(256, 2) void k_gemm_nn_sparse16(const float* __restrict__ X, int ldx, const int* __restrict__ kidx,
                                                              const float* __restrict__ kval, const int* __restrict__ kcnt,
                                                              const float* __restrict__ Wp, const float* __restrict__ bp,
@@ -648,9 +658,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sparse16(const float* __rest
     auto split4 = [](const float (&xs)[4], f16x4_& hi, f16x4_& lo) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const _Float16 h = (_Float16)xs[c];
+        _Float16 h, l;
+        mgr_split_f16(xs[c], h, l);
         hi[c] = h;
-        lo[c] = (_Float16)(xs[c] - (float)h);
+        lo[c] = l;
       }
     };
     auto stash = [&](const Regs& R, int buf) {
@@ -699,6 +710,141 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sparse16(const float* __rest
         }
       }
     }
+  }
+  const int unit = u0 + wc * 32 + l31;
+  if (unit < H) {
+    const float4 bias = *reinterpret_cast<const float4*>(bp + unit * 4);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = r0 + wr * 64 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        if (row < T)
+          *reinterpret_cast<float4*>(Z + ((size_t)b * T + row) * N + unit * 4) =
+              make_float4(fmaf(acc[0][mt][reg], inv, bias.x), fmaf(acc[1][mt][reg], inv, bias.y), fmaf(acc[2][mt][reg], inv, bias.z),
+                          fmaf(acc[3][mt][reg], inv, bias.w));
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ nn, split-f16, dense K
+// At f16 matrix rates the per-gate K loops of k_gemm_nn_sparse16 no longer pay: its stages are bound by staging (index reads, gathered
+// loads, the f32 -> (hi, lo) conversion of the A tile - once per GATE), not by the 6 MFMAs they feed.  This kernel walks ALL features
+// once: the A tile of a stage (128 rows x 16 features, from the transposed copy) is fetched, split and written to LDS ONCE for the four
+// gates, the B tiles carry the dropout mask as a factor (W_g[f, u] m_g[b, f] sw: a dropped feature is a zero row of that gate's B tile;
+// the factor is wave-uniform, a scalar load), and a stage is 24 MFMAs per wave (4 gates x 2 row blocks x (hi hi + lo hi + hi lo)).
+// Twice the MFMA work of the dropout-aware kernel at p = 0.5, a quarter of its A staging; without a mask (inference: mask4 = NULL) it
+// is the plain dense projection on the f16 pipe.  Scales and error: as k_gemm_nn_sparse16.
+__global__ __launch_bounds__(256, 2) void k_gemm_nn_dense16(const float* __restrict__ X, int ldx, const float* __restrict__ mask4,
+                                                            const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                            float* __restrict__ Z, int B, int T, int F, int H,
+                                                            const unsigned* __restrict__ wmax, float vmax, float sx) {
+  constexpr int TM = SP_TM, TU = 64, NT = 256, QT = 64, RPT = 2;
+  __shared__ __attribute__((aligned(16))) _Float16 Ah[2][2][TM][8], Al[2][2][TM][8];        // [buffer][k half][row][8 k-slots]
+  __shared__ __attribute__((aligned(16))) _Float16 Bh[2][4][2][TU][8], Bl[2][4][2][TU][8];  // [buffer][gate][k half][unit][8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int N = 4 * H;
+  const int q = __builtin_amdgcn_readfirstlane(tid / QT), r = tid % QT;   // quad of list positions (= the wave), unit / row
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int ncol = (H + TU - 1) / TU, nrow = (T + TM - 1) / TM;
+  float sw = 1.f;
+  {
+    const float m = __uint_as_float(*wmax) * vmax;
+    int ex = 0;
+    if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &ex);
+    ex = ex < -60 ? -60 : ex;
+    sw = m < 3.0e38f ? ldexpf(1.f, 15 - ex) : 0.f;
+  }
+  const float inv = sw > 0.f ? 1.f / (sw * sx) : __uint_as_float(0x7FC00000u);
+  const int x = blockIdx.x & 7, jj = blockIdx.x >> 3;   // XCD-aware tile order: see k_gemm_nn_sparse
+  const int rt = (jj / ncol) * 8 + x;
+  if (rt >= nrow * B) return;
+  const int u0 = (jj % ncol) * TU, r0 = (rt % nrow) * TM, b = rt / nrow;
+  const float* Xb = X + (size_t)b * F * ldx + r0 + r;
+  const int ucl = (u0 + r < H) ? u0 + r : H - 1;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[g][mt][e] = 0.f;
+  float ra[RPT * 4], rw[16], rm[16];
+  auto fetch = [&](int st) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int f = st * 16 + q + 4 * c;   // wave-uniform
+      const bool fv = f < F;
+      const int fc = fv ? f : F - 1;
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const float a = Xb[(size_t)fc * ldx + QT * i];
+        ra[i * 4 + c] = fv ? a : 0.f;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        rw[g * 4 + c] = Wp[((size_t)g * F + fc) * H + ucl];
+        const float m = mask4 ? mask4[((size_t)g * B + b) * F + fc] : 1.f;
+        rm[g * 4 + c] = fv ? m * sw : 0.f;
+      }
+    }
+  };
+  auto split4 = [](const float (&xs)[4], f16x4_& hi, f16x4_& lo) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      _Float16 h, l;
+      mgr_split_f16(xs[c], h, l);
+      hi[c] = h;
+      lo[c] = l;
+    }
+  };
+  auto stash = [&](int buf) {
+    f16x4_ hi, lo;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const float xs[4] = {ra[i * 4] * sx, ra[i * 4 + 1] * sx, ra[i * 4 + 2] * sx, ra[i * 4 + 3] * sx};
+      split4(xs, hi, lo);
+      *reinterpret_cast<f16x4_*>(&Ah[buf][q >> 1][r + QT * i][(q & 1) * 4]) = hi;
+      *reinterpret_cast<f16x4_*>(&Al[buf][q >> 1][r + QT * i][(q & 1) * 4]) = lo;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float ws[4] = {rw[g * 4] * rm[g * 4], rw[g * 4 + 1] * rm[g * 4 + 1], rw[g * 4 + 2] * rm[g * 4 + 2], rw[g * 4 + 3] * rm[g * 4 + 3]};
+      split4(ws, hi, lo);
+      *reinterpret_cast<f16x4_*>(&Bh[buf][g][q >> 1][r][(q & 1) * 4]) = hi;
+      *reinterpret_cast<f16x4_*>(&Bl[buf][g][q >> 1][r][(q & 1) * 4]) = lo;
+    }
+  };
+  auto mma = [&](int buf) {
+    const int ra_ = wr * 64 + l31, ub = wc * 32 + l31;
+    f16x8_ ah[2], al[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      ah[mt] = *reinterpret_cast<const f16x8_*>(&Ah[buf][lh][ra_ + 32 * mt][0]);
+      al[mt] = *reinterpret_cast<const f16x8_*>(&Al[buf][lh][ra_ + 32 * mt][0]);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f16x8_ bh = *reinterpret_cast<const f16x8_*>(&Bh[buf][g][lh][ub][0]);
+      const f16x8_ bl = *reinterpret_cast<const f16x8_*>(&Bl[buf][g][lh][ub][0]);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        acc[g][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[g][mt], 0, 0, 0);
+        acc[g][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[g][mt], 0, 0, 0);
+        acc[g][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[g][mt], 0, 0, 0);
+      }
+    }
+  };
+  const int nst = (F + 15) / 16;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    const bool more = st + 1 < nst;
+    if (more) fetch(st + 1);
+    mma(st & 1);
+    if (more) stash((st + 1) & 1);
+    __syncthreads();
   }
   const int unit = u0 + wc * 32 + l31;
   if (unit < H) {
@@ -949,9 +1095,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_sparse16(const float* __rest
     const float xs[8] = {v0.x * s, v0.y * s, v0.z * s, v0.w * s, v1.x * s, v1.y * s, v1.z * s, v1.w * s};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const _Float16 h = (_Float16)xs[e];
+      _Float16 h, l;
+      mgr_split_f16(xs[e], h, l);
       hi[e] = h;
-      lo[e] = (_Float16)(xs[e] - (float)h);
+      lo[e] = l;
     }
   };
   auto stash = [&](int buf) {
@@ -1261,8 +1408,15 @@ static int input_proj_dropout_impl(mgr_ctx* c, const float* X, int ldx, bool tra
   hipStream_t s = mgr_stream(c);
   // split-f16 kernel (tune key 15 = 1: never): transposed input with a stated bound on |X|, a drop rate that bounds the mask factor
   const bool f16 = transposed && x_absmax > 0.f && x_absmax < 1.0e30f && drop_rate < 0.99f && c->tune[15] == 0;
+  // dense K loop with the mask as a factor (k_gemm_nn_dense16): where there is no mask (inference); tune key 10 = 2: always.  With a
+  // mask the per-gate K loops over the kept features are faster (audio depth 2: 1.99 against 2.28 ms)
+  const bool dense = f16 && (!mask4 || c->tune[10] == 2);
+  MGR_REQUIRE(mask4 || dense, "a projection without a dropout mask needs the dense split-f16 kernel (a bound on |X|)");
   mgr_prof_begin(c, MGR_K_GEMM_NN);
-  hipLaunchKernelGGL(k_mask_compact, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp, kidx, kval, kcnt, (int*)nullptr, wmax);
+  if (!dense)
+    hipLaunchKernelGGL(k_mask_compact, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp, kidx, kval, kcnt, (int*)nullptr, wmax);
+  else
+    MGR_HIP(hipMemsetAsync(wmax, 0, sizeof(unsigned), s));
   {
     const size_t n = (size_t)F * H;
     const int wgs = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
@@ -1274,7 +1428,13 @@ static int input_proj_dropout_impl(mgr_ctx* c, const float* X, int ldx, bool tra
   const bool wide = c->tune[11] == 2 && !transposed;
   const int tu = wide ? 128 : 64;
   const int ntiles = ((H + tu - 1) / tu) * ((((T + SP_TM - 1) / SP_TM) * B + 7) / 8) * 8;   // (row tiles padded to the 8 XCDs)
-  if (f16) {
+  if (dense) {
+    int ex;
+    (void)frexpf(x_absmax, &ex);
+    const float sx = ldexpf(1.f, 15 - ex);
+    hipLaunchKernelGGL(k_gemm_nn_dense16, dim3(ntiles), dim3(256), 0, s, X, ldx, mask4, Wg, bp, Z, B, T, F, H, wmax,
+                       mask4 ? 1.f / (1.f - drop_rate) : 1.f, sx);
+  } else if (f16) {
     int ex;
     (void)frexpf(x_absmax, &ex);                       // x_absmax = m 2^ex, m in [0.5, 1): |X| sx < 2^15
     const float sx = ldexpf(1.f, 15 - ex);
@@ -1304,10 +1464,12 @@ int mgr_lstm_input_proj_dropout(mgr_ctx* c, const float* X, int ldx, const float
 
 int mgr_lstm_input_proj_dropout_t(mgr_ctx* c, const float* XT, int ldt, const float* mask4, float drop_rate, const float* Wp,
                                   const float* bp, float* Z, int B, int T, int F, int H, void* ws, size_t ws_bytes, float x_absmax) {
-  MGR_REQUIRE(c && XT && mask4 && Wp && bp && Z, "null argument");
+  MGR_REQUIRE(c && XT && Wp && bp && Z, "null argument");
   MGR_REQUIRE(B > 0 && T > 0 && F > 0 && H > 0, "bad shape");
   MGR_REQUIRE(ldt % 4 == 0 && ldt >= (T + SP_TM - 1) / SP_TM * SP_TM, "the transposed copy must be padded to whole row tiles of %d (ldt %d, T %d)", SP_TM, ldt, T);
-  MGR_REQUIRE(sparse_proj_shape(c, drop_rate, F), "shape / drop rate not handled by the dropout-aware kernel (ask mgr_lstm_input_proj_dropout_wants_transposed)");
+  MGR_REQUIRE(mask4 ? sparse_proj_shape(c, drop_rate, F) : (F >= 16 && F <= SP_MAXF),
+              "shape / drop rate not handled by the dropout-aware kernel (ask mgr_lstm_input_proj_dropout_wants_transposed)");
+  if (!mask4) drop_rate = 0.f;
   MGR_REQUIRE(aligned16(XT) && aligned16(bp) && aligned16(Z) && aligned16(Wp), "XT / bp / Z / Wp must be 16-byte aligned");
   MGR_REQUIRE((size_t)F * ldt < (1u << 31), "sample block too large");
   MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_input_proj_dropout_ws_bytes(B, F, H), "workspace too small");

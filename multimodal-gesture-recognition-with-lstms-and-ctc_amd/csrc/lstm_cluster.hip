@@ -657,7 +657,8 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
     for (int i = 0; i < NBW; ++i)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float x = uval(tt, i, e) * sU;
+        float x = uval(tt, i, e) * sU;
+        asm volatile("" : "+v"(x));   // (hi and the residual from ONE f32 value: gemm.hip, mgr_split_f16)
         const _Float16 hi = (_Float16)x;
         ah[tt][i][e] = hi;
         al[tt][i][e] = (_Float16)(x - (float)hi);
@@ -795,7 +796,8 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
       }
       yv = nonfinite ? __uint_as_float(0x7FC00000u) : h;
       // h 2^15 = hi + lo; the epoch parity rides in bit 0 of the words the even lane's values open (hi word and lo word)
-      const float hs = h * 32768.f;
+      float hs = h * 32768.f;
+      asm volatile("" : "+v"(hs));   // (as above)
       unsigned hib = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)hs);
       if (!(lane & 1)) hib = (hib & ~1u) | par;
       const float hif = (float)__builtin_bit_cast(_Float16, (unsigned short)hib);

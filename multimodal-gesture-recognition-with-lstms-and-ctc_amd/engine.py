@@ -229,7 +229,7 @@ class Engine:
         self.Y1T = {}
         self._featT = {}
         self._featT_ready = {}   # FEAT buffer -> its transposed copy was written by the scans of the current pass
-        if train and self.schedule.transposed_inputs:
+        if self.schedule.transposed_inputs:   # (training: dropout-aware GEMMs; inference: the dense split-f16 projection reads it too)
             want = lambda p, F: bool(self.lib.mgr_lstm_input_proj_dropout_wants_transposed(self.dev.ctx, C.c_float(float(p)), int(F)))
             for s in sp.streams:
                 if len(s["layers"]) == 2 and want(s["layers"][1]["dropout"], 2 * s["layers"][0]["H"]):
@@ -405,6 +405,15 @@ class Engine:
                                   ws, ws.nbytes, 2.0)
                 else:
                     self.dev.call("mgr_lstm_input_proj_dropout", X, ldx, m, float(Ls[d].p), Wp, bp, Z, B, T, fin, H, ws, ws.nbytes)
+        elif not pair[0] and XT is not None and 128 <= fin <= 2048 and Ls[0].ws_sp is not None:
+            # no dropout (inference) on a wide layer whose input the engine keeps transposed: the dense projection on the f16 matrix
+            # pipe (split-f16 operands; |XT| <= 2 as above) instead of the f32 MFMA pair kernel
+            if not xt_ready:
+                self.dev.call("mgr_transpose_bt", X, ldx, XT, self.ldt, B, T, fin)
+            for d in range(2):
+                m, Wp, bp, Z = pair[4 * d:4 * d + 4]
+                ws = Ls[d].ws_sp
+                self.dev.call("mgr_lstm_input_proj_dropout_t", XT, self.ldt, 0, 0.0, Wp, bp, Z, B, T, fin, H, ws, ws.nbytes, 2.0)
         else:
             self.dev.call("mgr_lstm_input_proj_pair", X, ldx, *pair, B, T, fin, H)
 

@@ -512,10 +512,22 @@ def test_input_proj_dropout_sparse_equals_dense(device, B, T, F, H, p):
         assert np.array_equal(tr.download(), sparse.download())      # (no bound on |X| stated: the f32 MFMA kernel)
         # with a bound on |X| the products run as split-f16 pairs on the f16 matrix pipe (k_gemm_nn_sparse16): the same tolerance
         # against fp64 as the f32 kernels; a looser bound only moves the scale
-        for bound in (float(np.abs(X).max()), 4.0 * float(np.abs(X).max())):
-            tr.upload(np.full((B, T, N), np.nan, f32))
-            dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, dM, p if p < 0.99 else 0.5, dW, db, tr, B, T, F, H, ws, ws.nbytes, bound)
-            assert np.abs(tr.download() - ref).max() <= tol
+        # (tune key 10: 0 = per-gate K loops over the kept features, 2 = one dense K loop with the mask as a factor of the weight tiles)
+        for kernel in (0, 2):
+            dev.call("mgr_tune", 10, kernel)
+            for bound in (float(np.abs(X).max()), 4.0 * float(np.abs(X).max())):
+                tr.upload(np.full((B, T, N), np.nan, f32))
+                dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, dM, p if p < 0.99 else 0.5, dW, db, tr, B, T, F, H, ws, ws.nbytes, bound)
+                assert np.abs(tr.download() - ref).max() <= tol
+        dev.call("mgr_tune", 10, 0)
+        # no mask at all (inference): the dense kernel is the plain projection
+        plain = dev.empty((B, T, N))
+        dev.call("mgr_lstm_input_proj", dX, F, 0, dW, db, plain, B, T, F, H)
+        tr.upload(np.full((B, T, N), np.nan, f32))
+        dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, 0, 0.0, dW, db, tr, B, T, F, H, ws, ws.nbytes, float(np.abs(X).max()))
+        ref0 = X.astype(np.float64) @ W.astype(np.float64) + bias
+        assert np.abs(tr.download() - ref0).max() <= 2e-5 * max(1.0, np.abs(ref0).max())
+        assert np.abs(tr.download() - plain.download()).max() <= 2e-5 * max(1.0, np.abs(ref0).max())
         # an input beyond the stated bound is not silently wrong: f16 overflows and Z carries Inf / NaN
         if p < 0.99:
             tr.upload(np.zeros((B, T, N), f32))

@@ -43,7 +43,13 @@ def gemm(dev, B, T, F, H, mask=True):
         print("  dropout-aware (transposed copy)         : %7.3f ms  %6.1f TF executed  (+ transpose %.3f ms, %.0f GB/s)"
               % (ms, 0.5 * fl / ms / 1e9, mt, 2.0 * B * T * F * 4 / mt / 1e6))
         ms = timeit(dev, lambda: dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, m, 0.5, Wp, bp, Z, B, T, F, H, wsd, wsd.nbytes, 8.0))
-        print("  dropout-aware (transposed, split f16)   : %7.3f ms  %6.1f TF executed (f32-equivalent)" % (ms, 0.5 * fl / ms / 1e9))
+        print("  split f16, per-gate K loops (kept only) : %7.3f ms  %6.1f TF executed (f32-equivalent)" % (ms, 0.5 * fl / ms / 1e9))
+        dev.call("mgr_tune", 10, 2)
+        ms = timeit(dev, lambda: dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, m, 0.5, Wp, bp, Z, B, T, F, H, wsd, wsd.nbytes, 8.0))
+        dev.call("mgr_tune", 10, 0)
+        print("  split f16, dense K, mask as a factor    : %7.3f ms  %6.1f TF (f32-equivalent, dense)" % (ms, fl / ms / 1e9))
+        ms = timeit(dev, lambda: dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, 0, 0.0, Wp, bp, Z, B, T, F, H, wsd, wsd.nbytes, 8.0))
+        print("  split f16, dense K, no mask (inference) : %7.3f ms  %6.1f TF (f32-equivalent)" % (ms, fl / ms / 1e9))
         XT.free(); wsd.free()
     dZ = Z
     gW, gU, gb = dev.empty((F, 4 * H)), dev.empty((H, 4 * H)), dev.empty((4 * H,))
