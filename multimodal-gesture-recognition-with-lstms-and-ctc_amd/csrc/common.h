@@ -75,16 +75,6 @@ int mgr_prof_end(mgr_ctx* c, int family);
 
 static inline size_t mgr_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// Register floor of the small kernels that run beside the resident encoder scans (round 4).  A CU that holds TWO scan workgroups has
-// 512 - 2 x 216 = 80 registers per lane and SIMD left; the waves on those CUs pace their whole cluster (their step is the audio
-// wave's own plus its partner's issue time), whereas the workgroups that sit alone on a CU finish their step early and
-// wait.  A kernel allocated MORE than 80 registers can only land on the single-workgroup CUs, where its instructions cost the scans
-// nothing.  (The clobber makes hipcc account v87: allocation 88.)
-#ifndef MGR_FLOOR_MASK
-#define MGR_FLOOR_MASK 0   // (7 won 0.25 ms with f32 scans; with the split-f16 scans 0 wins 0.25 ms: profiles/r04_scan_probes.txt)
-#endif
-#define MGR_OFF_PAIRED_CUS(group) do { if constexpr (((MGR_FLOOR_MASK) >> (group)) & 1) asm volatile("" ::: "v87"); } while (0)
-
 // ---- device-side RNG: one 64-bit mix per element index (splitmix64 finaliser); stateless ---------------
 __host__ __device__ static inline uint64_t mgr_mix64(uint64_t z) {
   z += 0x9E3779B97F4A7C15ull;

@@ -76,7 +76,6 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
                                              int skip, int blank, float eps, float gscale, float* __restrict__ loss,
                                              float* __restrict__ dLogits, float* __restrict__ LY,
                                              float* __restrict__ AL, float* __restrict__ BE) {
-  MGR_OFF_PAIRED_CUS(0);
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [256][C+1] occupancy rows, then labels
   constexpr int CH = Chunk<PPL>::CH;
   const int b = blockIdx.x;

@@ -20,7 +20,6 @@ __global__ __launch_bounds__(256) void k_dense_softmax_fwd(const float* __restri
                                                            uint64_t seed, const float* __restrict__ Wd,
                                                            const float* __restrict__ bd, float* __restrict__ P,
                                                            size_t nframes, int D, int C) {
-  MGR_OFF_PAIRED_CUS(2);
   __shared__ float As[FR][DC + 1];
   __shared__ float Ws[DC][CP];
   __shared__ float Ls[FR][CP + 1];
@@ -90,7 +89,6 @@ __global__ __launch_bounds__(256) void k_dense_bwd(const float* __restrict__ A, 
                                                    float* __restrict__ slabW, float* __restrict__ slabB,
                                                    float* __restrict__ dA, int ldda, size_t nframes,
                                                    int frames_per_wg, int D, int C) {
-  MGR_OFF_PAIRED_CUS(2);
   __shared__ float dLs[FR][CM];
   const int tid = threadIdx.x;
   size_t fbeg = (size_t)blockIdx.x * frames_per_wg;
@@ -160,7 +158,6 @@ __global__ __launch_bounds__(256, 6) void k_dense_softmax_fwd_mfma(const float* 
                                                                    float p, float inv_keep, uint64_t seed,
                                                                    const float* __restrict__ Wd, const float* __restrict__ bd,
                                                                    float* __restrict__ P, size_t nframes, int D, int C) {
-  MGR_OFF_PAIRED_CUS(1);
   // B fragments, fragment order: [q][half][lane] = { (r, nt) = (2 half, 0), (2 half, 1), (2 half + 1, 0), (2 half + 1, 1) }
   // of k-step (q, r), class tile nt: B[k = kk][n] = Wd[16 q + 4 kk + r][16 nt + n]
   __shared__ f32x4_ wfs[DB][2][64];
@@ -244,7 +241,6 @@ __global__ __launch_bounds__(256, 6) void k_dense_bwd_mfma(const float* __restri
                                                            const float* __restrict__ Wd, float* __restrict__ slabW,
                                                            float* __restrict__ slabB, float* __restrict__ dA, int ldda, size_t nframes,
                                                            int D, int C) {
-  MGR_OFF_PAIRED_CUS(1);
   __shared__ f32x4_ red[4][NTH * 2][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, kk = lane >> 4;
@@ -362,7 +358,6 @@ static bool dense_mfma_ok(const mgr_ctx* c, const float* A, int lda, int ldo, in
 // both reductions of the backward pass in one launch (each launch of the step queues behind the resident scans)
 __global__ void k_slab_reduce2(const float* __restrict__ slabW, float* __restrict__ outW, size_t nW, const float* __restrict__ slabB,
                                float* __restrict__ outB, size_t nB, int nslab) {
-  MGR_OFF_PAIRED_CUS(2);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nW + nB; i += (size_t)gridDim.x * blockDim.x) {
     const bool w = i < nW;
     const float* src = w ? slabW + i : slabB + (i - nW);

@@ -13,7 +13,6 @@ static inline int grid_for(size_t n, int per_block = kBlock) {
 }
 
 __global__ void k_add_noise(const float* __restrict__ X, float* __restrict__ Y, size_t n, float stddev, uint64_t seed) {
-  MGR_OFF_PAIRED_CUS(2);
   // Box-Muller on two 24-bit uniforms per pair of elements
   size_t npair = (n + 1) / 2;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npair; i += (size_t)gridDim.x * blockDim.x) {
@@ -30,7 +29,6 @@ __global__ void k_add_noise(const float* __restrict__ X, float* __restrict__ Y, 
 }
 
 __global__ void k_dropout_mask(float* __restrict__ m, size_t n, float p, float inv_keep, uint64_t seed) {
-  MGR_OFF_PAIRED_CUS(2);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     m[i] = mgr_drop_scale(seed, i, p, inv_keep);
 }
@@ -74,7 +72,6 @@ __global__ void k_transpose(const float* __restrict__ src, float* __restrict__ d
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                        size_t n, float lr_t, float b1, float b2, float eps, float clipvalue, float gscale,
                        const float* __restrict__ gate, unsigned* __restrict__ skipped) {
-  MGR_OFF_PAIRED_CUS(2);
   if (gate && gate[0] != 0.f) {
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1u);
     return;
@@ -96,7 +93,6 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
 constexpr int MN_RG = 32;
 __global__ __launch_bounds__(32 * MN_RG) void k_maxnorm(float* __restrict__ W, int rows, int cols, float maxv, float eps,
                                                          const float* __restrict__ gate) {
-  MGR_OFF_PAIRED_CUS(2);
   __shared__ float part[MN_RG][32];
   if (gate && gate[0] != 0.f) return;   // update gate closed (k_adam): the weights stay exactly as they were
   int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -123,7 +119,6 @@ __global__ __launch_bounds__(32 * MN_RG) void k_maxnorm(float* __restrict__ W, i
 
 __global__ void k_add2d(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb, float* __restrict__ O,
                         int ldo, size_t rows, int cols) {
-  MGR_OFF_PAIRED_CUS(2);
   size_t n = rows * (size_t)cols;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     size_t r = i / cols;
@@ -133,7 +128,6 @@ __global__ void k_add2d(const float* __restrict__ A, int lda, const float* __res
 }
 
 __global__ void k_mean(const float* __restrict__ x, int n, float* __restrict__ out) {
-  MGR_OFF_PAIRED_CUS(2);
   __shared__ double sh[kBlock];
   double s = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)x[i];

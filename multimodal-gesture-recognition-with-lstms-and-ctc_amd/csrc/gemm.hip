@@ -346,7 +346,6 @@ __global__ __launch_bounds__(64) void k_mask_compact(const float* __restrict__ m
                                                      float* __restrict__ kval, int* __restrict__ kcnt,
                                                      int* __restrict__ kpos /* [4B][F] list position of a kept feature, -1 if dropped; may be null */,
                                                      unsigned* __restrict__ zero_word /* set to 0 (the max |W| word k_gate_major fills next); may be null */) {
-  MGR_OFF_PAIRED_CUS(2);
   const int gb = blockIdx.x, lane = threadIdx.x;
   if (zero_word && gb == 0 && lane == 0) *zero_word = 0u;
   const float* m = mask4 + (size_t)gb * F;
@@ -380,7 +379,6 @@ __global__ __launch_bounds__(64) void k_mask_compact(const float* __restrict__ m
 // wmax (may be null): the largest |W| of the call as float bits, by atomic max (zeroed by k_mask_compact in front) - the scale of
 // the split-f16 projection.
 __global__ __launch_bounds__(256) void k_gate_major(const float* __restrict__ Wp, float* __restrict__ Wg, int F, int H, unsigned* __restrict__ wmax) {
-  MGR_OFF_PAIRED_CUS(2);
   const size_t n = (size_t)F * H;
   float m = 0.f;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -1169,7 +1167,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_sparse16(const float* __rest
 // dWp[f][4u+g] = sum over the samples that kept feature f for gate g, in sample order
 __global__ __launch_bounds__(256) void k_dw_gather(const float* __restrict__ P, const int* __restrict__ kpos, float* __restrict__ dWp,
                                                    int B, int F, int Fp, int H) {
-  MGR_OFF_PAIRED_CUS(2);
   const size_t n = (size_t)4 * F * H;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const int u = (int)(i % H);
@@ -1263,7 +1260,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const float* __restrict__ dZ
 
 // slab reduce: out[i] = sum_k slab[k][i]
 __global__ void k_reduce(const float* __restrict__ slab, float* __restrict__ out, size_t n, int nslab) {
-  MGR_OFF_PAIRED_CUS(2);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < nslab; ++k) s += slab[(size_t)k * n + i];
@@ -1275,7 +1271,6 @@ __global__ void k_reduce(const float* __restrict__ slab, float* __restrict__ out
 // float4 loads, two row lanes summed through LDS (N = 4H is a multiple of 4)
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dZ, float* __restrict__ slab, size_t rows, int N,
                                                 int rows_per_wg) {
-  MGR_OFF_PAIRED_CUS(2);
   __shared__ float4 part[128];
   const size_t rbeg = (size_t)blockIdx.x * rows_per_wg;
   const size_t rend = rbeg + rows_per_wg < rows ? rbeg + rows_per_wg : rows;
@@ -1304,7 +1299,6 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dZ, fl
 // out[i] = sum_k slab[k][i] for MANY slabs of a SHORT vector (the bias gradient: hundreds of row-block partial sums of 4H
 // numbers): 8 slab lanes per element, summed through LDS in a fixed order
 __global__ __launch_bounds__(256) void k_reduce_tall(const float* __restrict__ slab, float* __restrict__ out, int n, int nslab) {
-  MGR_OFF_PAIRED_CUS(2);
   __shared__ float part[8][32];
   const int e = blockIdx.x * 32 + (threadIdx.x & 31), kl = threadIdx.x >> 5;
   float s = 0.f;
@@ -1481,7 +1475,6 @@ namespace {
 __global__ __launch_bounds__(256) void k_transpose_bt(const float* __restrict__ X, int ldx, float* __restrict__ XT, int ldt, int T, int F,
                                                       long long xtb /* batch stride of XT; 0: F * ldt */, int fill /* columns written: ldt or less */,
                                                       unsigned* __restrict__ rowmax /* [B][F] largest |x| of a row of XT as float bits, by atomic max (zeroed by the caller); may be null */) {
-  MGR_OFF_PAIRED_CUS(2);
   __shared__ float tile[64][65];
   const int b = blockIdx.z, t0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
