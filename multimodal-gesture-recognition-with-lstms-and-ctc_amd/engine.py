@@ -8,7 +8,6 @@ multimodal_fusion/sequence_decoding.py:121); there is no CPU fallback.
 """
 import ctypes as C
 import math
-import os
 
 import numpy as np
 
@@ -82,12 +81,14 @@ class Schedule:
     transposed_inputs   keep a transposed copy of the inputs of the wide dropout layers for the dropout-aware projection GEMMs
     resident_wait_us    upper bound of the device-side wait that lets the deepest encoder scan become resident before the
                         deferred GEMMs are released (mgr_stream_wait_next_resident); 0 = no wait
+    bptt_beside_deepest_scan  (round 4; needs the three switches above) the trainable layer's BPTT is held back together with its
+                        GEMMs: recurrence beside recurrence, GEMM beside GEMM.  The encoder stream then runs free - the next batch's
+                        encoder pass up to its deepest projections is enqueued BEFORE this step's fusion work, and its depth-1
+                        projections no longer wait for this step's fusion projections
     """
 
     def __init__(self, pipeline=True, defer_param_grads=True, encoders_run_ahead=True, resident_wait_us=2000,
-                 transposed_inputs=True, bptt_beside_deepest_scan=None):
-        if bptt_beside_deepest_scan is None:
-            bptt_beside_deepest_scan = os.environ.get("MGR_SCHED_BPTT_LATE", "1") != "0"
+                 transposed_inputs=True, bptt_beside_deepest_scan=True):
         self.bptt_beside_deepest_scan = bool(bptt_beside_deepest_scan)
         self.transposed_inputs = bool(transposed_inputs)
         self.pipeline = bool(pipeline)
