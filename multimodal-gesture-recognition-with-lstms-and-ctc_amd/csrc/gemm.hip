@@ -631,13 +631,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sparse16(const float* __rest
       for (int e = 0; e < 16; ++e) acc[g][mt][e] = 0.f;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const int nst = (kcnt[g * B + b] + SK - 1) / SK;
+    const int nst1 = (kcnt[g * B + b] + SK - 1) / SK;
+    // an EVEN number of stages (a padding stage has factor 0), and no conditional load in the time loop below: hipcc merges its
+    // wait-count scoreboard over the branches of a loop body, and with `if (st + 2 < nst) fetch(...)` it assumes the fetch did not
+    // happen - the s_waitcnt in front of the stash then counts down to vmcnt(0) and waits for the loads issued two stages AHEAD as
+    // well, i.e. every stage paid a memory latency (the f32 kernel hid that under 1024 cycles of MFMA per stage): 1.99 -> 1.63 ms
+    const int nst = (nst1 + 1) & ~1;
     {
       const int* list = kidx + ((size_t)g * B + b) * Fp;
       const float* lval = kval + ((size_t)g * B + b) * Fp;
       for (int i = tid; i < nst * SK; i += NT) {
-        Ls[i] = (unsigned short)list[i];
-        Vs[i] = lval[i];
+        const bool in = i < nst1 * SK;
+        Ls[i] = in ? (unsigned short)list[i] : (unsigned short)0;
+        Vs[i] = in ? lval[i] : 0.f;
       }
     }
     __syncthreads();
@@ -692,20 +698,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sparse16(const float* __rest
     if (nst > 0) {
       Regs R0, R1;
       fetch(R0, 0);
-      if (nst > 1) fetch(R1, 1);
+      fetch(R1, 1);
       stash(R0, 0);
       __syncthreads();
-      for (int st = 0; st < nst; st += 2) {
-        if (st + 2 < nst) fetch(R0, st + 2);
+      for (int st = 0; st < nst; st += 2) {   // (fetches beyond the last stage re-read it; what they stash is never multiplied)
+        fetch(R0, st + 2 < nst ? st + 2 : nst - 1);
         mma(0);
-        if (st + 1 < nst) stash(R1, 1);
+        stash(R1, 1);
         __syncthreads();
-        if (st + 1 < nst) {
-          if (st + 3 < nst) fetch(R1, st + 3);
-          mma(1);
-          if (st + 2 < nst) stash(R0, 0);
-          __syncthreads();
-        }
+        fetch(R1, st + 3 < nst ? st + 3 : nst - 1);
+        mma(1);
+        stash(R0, 0);
+        __syncthreads();
       }
     }
   }
@@ -767,8 +771,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_dense16(const float* __restr
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[g][mt][e] = 0.f;
-  float ra[RPT * 4], rw[16], rm[16];
-  auto fetch = [&](int st) {
+  struct Regs {
+    float ra[RPT * 4], rw[16], rm[16];
+  };
+  auto fetch = [&](Regs& R, int st) {
+    float (&ra)[RPT * 4] = R.ra;
+    float (&rw)[16] = R.rw;
+    float (&rm)[16] = R.rm;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int f = st * 16 + q + 4 * c;   // wave-uniform
@@ -796,7 +805,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_dense16(const float* __restr
       lo[c] = l;
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](const Regs& R, int buf) {
+    const float (&ra)[RPT * 4] = R.ra;
+    const float (&rw)[16] = R.rw;
+    const float (&rm)[16] = R.rm;
     f16x4_ hi, lo;
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
@@ -833,15 +845,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_dense16(const float* __restr
       }
     }
   };
+  // (two register sets, loads two stages ahead, no conditional load in the loop: k_gemm_nn_sparse16; a stage index beyond the
+  // last stage has no valid feature: its tiles are zero)
   const int nst = (F + 15) / 16;
-  fetch(0);
-  stash(0);
+  Regs R0, R1;
+  fetch(R0, 0);
+  fetch(R1, 1);
+  stash(R0, 0);
   __syncthreads();
-  for (int st = 0; st < nst; ++st) {
-    const bool more = st + 1 < nst;
-    if (more) fetch(st + 1);
-    mma(st & 1);
-    if (more) stash((st + 1) & 1);
+  for (int st = 0; st < nst; st += 2) {
+    fetch(R0, st + 2);
+    mma(0);
+    stash(R1, 1);
+    __syncthreads();
+    fetch(R1, st + 3);
+    if (st + 1 < nst) mma(1);
+    stash(R0, 0);
     __syncthreads();
   }
   const int unit = u0 + wc * 32 + l31;
@@ -1081,12 +1100,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_sparse16(const float* __rest
   const float sz = zscale(un);
   f32x16 acc[2][2];
   zero_acc(acc);
-  float4 ra[4], rb[4];
-  auto fetch = [&](int t0) {   // (t0 + 32 <= the padded row length; the pad is zero)
+  struct Regs {
+    float4 a[4], b[4];
+  };
+  auto fetch = [&](Regs& R, int t0) {   // (t0 + 32 <= the padded row length; the pad is zero)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ra[i] = *reinterpret_cast<const float4*>(xrow + t0 + 4 * i);
-      rb[i] = *reinterpret_cast<const float4*>(zrow + t0 + 4 * i);
+      R.a[i] = *reinterpret_cast<const float4*>(xrow + t0 + 4 * i);
+      R.b[i] = *reinterpret_cast<const float4*>(zrow + t0 + 4 * i);
     }
   };
   auto split8 = [](const float4& v0, const float4& v1, float s, f16x8_& hi, f16x8_& lo) {
@@ -1099,14 +1120,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_sparse16(const float* __rest
       lo[e] = l;
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](const Regs& R, int buf) {
     f16x8_ hi, lo;
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-      split8(ra[2 * hf], ra[2 * hf + 1], sx, hi, lo);
+      split8(R.a[2 * hf], R.a[2 * hf + 1], sx, hi, lo);
       *reinterpret_cast<f16x8_*>(&Ah[buf][kb][hf][m][0]) = hi;
       *reinterpret_cast<f16x8_*>(&Al[buf][kb][hf][m][0]) = lo;
-      split8(rb[2 * hf], rb[2 * hf + 1], sz, hi, lo);
+      split8(R.b[2 * hf], R.b[2 * hf + 1], sz, hi, lo);
       *reinterpret_cast<f16x8_*>(&Bh[buf][kb][hf][m][0]) = hi;
       *reinterpret_cast<f16x8_*>(&Bl[buf][kb][hf][m][0]) = lo;
     }
@@ -1136,18 +1157,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_sparse16(const float* __rest
         for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
     }
   };
+  // global loads run two stages ahead in two register sets, and NO load of the loop is conditional (a conditional fetch makes
+  // hipcc count its s_waitcnt down to vmcnt(0): k_gemm_nn_sparse16); fetches beyond the last stage re-read it, what they stash is
+  // never multiplied
   const int nst = (T + TK - 1) / TK;
-  fetch(0);
-  stash(0);
+  Regs R0, R1;
+  fetch(R0, 0);
+  fetch(R1, (nst > 1 ? 1 : 0) * TK);
+  stash(R0, 0);
   __syncthreads();
-  int buf = 0;
-  for (int st = 0; st < nst; ++st) {
-    const bool more = st + 1 < nst;
-    if (more) fetch((st + 1) * TK);
-    mma(buf);
-    if (more) stash(buf ^ 1);
+  for (int st = 0; st < nst; st += 2) {
+    fetch(R0, (st + 2 < nst ? st + 2 : nst - 1) * TK);
+    mma(0);
+    stash(R1, 1);
     __syncthreads();
-    buf ^= 1;
+    fetch(R1, (st + 3 < nst ? st + 3 : nst - 1) * TK);
+    if (st + 1 < nst) mma(1);
+    stash(R0, 0);
+    __syncthreads();
   }
   float* out = P + (size_t)gb * Fp * H;
 #pragma unroll
