@@ -32,7 +32,8 @@ typedef __attribute__((address_space(3))) float lds_float;
 constexpr unsigned POLL_LIMIT = 1u << 20;
 constexpr int BW_WAVES = 4;
 constexpr int BW_RING_FLOATS = 3 * (256 + 64 + 64);   // per compute wave: 3 slots x { gates [64] float4 | dy [64] | c [64] }
-constexpr int BW_LDS_FLOATS = 4 * 256 + 5 * 256 + BW_WAVES * BW_RING_FLOATS;
+constexpr int BW_LDS_FLOATS = 4 * 256 + 5 * 256 + BW_WAVES * BW_RING_FLOATS + 16;   // (+16: the four dz factors of the split-f16 form)
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // LDS-DMA: one wave-instruction copies 64 x 16 B (64 x 4 B) from global memory [gbase + voff] (gbase wave-uniform, voff per
 // lane) to LDS [lds_addr + 16 (4) * lane]; M0 carries the LDS address and is restored (hipcc does not know it was touched)
@@ -56,7 +57,14 @@ __device__ __forceinline__ void mgr_dma_b32(const void* gbase, unsigned voff, un
 //   never stores, so the s_waitcnt in front of its gathered data no longer covers write-through stores (on gfx9 stores and
 //   loads share vmcnt; the acknowledgement of a wave's 8 x 16-byte stores per step was 2.7 of 7.8 us at H = 500), and the
 //   compute waves never wait on vmcnt for the exchange at all.  Plain compiler-managed loads - no register polling.
-template <int H, bool SPLIT>
+// F16 (round 4): the partial products on the f16 matrix pipe with split-f16 operands (lstm_cluster.hip, cluster_run_k16).  The B
+// operand is the workgroup's own dz slice, a gate GRADIENT without an a-priori bound: every wave scales what IT contributes by the
+// power of two that puts its own largest |dz| of the step in [2^14, 2^15) and leaves the factor beside the image; K is ordered so
+// that a wave's 16 gate columns are ONE K-block of v_mfma_f32_16x16x16_f16 (k = 16 wave + 4 uq + gate: the four gate gradients of a
+// thread's cell are exactly its lane's operand of that block - it writes its own (hi, lo) pair, nobody gathers), the K loop keeps
+// one accumulator per source wave and the four partial sums meet as f32, each divided by its source's factor: exact scaling, no
+// maximum to agree on, no extra barrier.  12 MFMAs of 16 cycles per tile instead of 16 of 35.
+template <int H, bool SPLIT, bool F16>
 __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg, int ug, float* smem, unsigned* status, bool fast) {
   constexpr int N = 4 * H;
   constexpr int GT = (H + 15) / 16;          // tiles of 16 units = workgroups per cluster
@@ -79,15 +87,55 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
 
   // A fragments: tile m (units 16m..16m+15) x this workgroup's 64 gate columns: k-step s (own unit s), kk = gate
   //   A[i = lane&15][kk = lane>>4] = Up[unit 16m+i][4*(16*ug + s) + kk]
-  float uf[TPW][16];
+  float uf[F16 ? 1 : TPW][16];
+  f16x4 ah[F16 ? TPW : 1][4], al[F16 ? TPW : 1][4];   // F16: tile i, K-block w' (source wave): U[16 m + j][64 ug + 16 uq + 4 w' + e], e < 4
+  float* scl = smem + 4 * 256 + 5 * 256 + BW_WAVES * BW_RING_FLOATS;   // [4] 1 / (factor of wave w's dz), [8..11] prologue scratch
+  float sUinv = 1.f;
+  if constexpr (F16) {
+    auto uval = [&](int i, int wsrc, int e) -> float {
+      const int m = wave + BW_WAVES * i, ur = m * 16 + j, su = ug * 16 + 4 * uq + wsrc;
+      return (computer && m < GT && ur < H && su < H) ? jb.Up[(size_t)ur * N + 4 * su + e] : 0.f;
+    };
+    float umax = 0.f;
 #pragma unroll
-  for (int i = 0; i < TPW; ++i) {
-    const int m = wave + BW_WAVES * i;
-    const int ur = m * 16 + j;
+    for (int i = 0; i < TPW; ++i)
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int su = ug * 16 + s;
-      uf[i][s] = (computer && m < GT && ur < H && su < H) ? jb.Up[(size_t)ur * N + 4 * su + uq] : 0.f;
+      for (int wsrc = 0; wsrc < 4; ++wsrc)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) umax = fmaxf(umax, fabsf(uval(i, wsrc, e)));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) umax = fmaxf(umax, __shfl_xor(umax, o));
+    if (lane == 0 && computer) scl[8 + wave] = umax;
+    if (tid < 4) scl[tid] = 0.f;
+    __syncthreads();
+    umax = fmaxf(fmaxf(scl[8], scl[9]), fmaxf(scl[10], scl[11]));
+    int ex = 0;
+    if (umax > 0.f && umax < 3.0e38f) (void)frexpf(umax, &ex);
+    ex = ex < -60 ? -60 : ex;
+    const float sU = ldexpf(1.f, 15 - ex);   // largest |U| sU in [2^14, 2^15)
+    sUinv = ldexpf(1.f, ex - 15);
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int wsrc = 0; wsrc < 4; ++wsrc)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = uval(i, wsrc, e) * sU;
+          asm volatile("" : "+v"(x));   // (hi and the residual from ONE f32 value: gemm.hip, mgr_split_f16)
+          const _Float16 hi = (_Float16)x;
+          ah[i][wsrc][e] = hi;
+          al[i][wsrc][e] = (_Float16)(x - (float)hi);
+        }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const int m = wave + BW_WAVES * i;
+      const int ur = m * 16 + j;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int su = ug * 16 + s;
+        uf[i][s] = (computer && m < GT && ur < H && su < H) ? jb.Up[(size_t)ur * N + 4 * su + uq] : 0.f;
+      }
     }
   }
   for (int i = tid; i < 4 * 256; i += (int)blockDim.x) dzi[i] = 0.f;
@@ -225,12 +273,35 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
     }
     if (!has_prev) break;   // the first forward step has no predecessor: nothing to send (workgroup-uniform; it is the last iteration)
     if (computer) {
-      // own unit index s = 4*uq + wave -> image [q = s>>2 = uq][kk = gate][j][r = s&3 = wave]
-      float* p = dzi + ((uq * 4) * 16 + j) * 4 + wave;
-      p[0 * 64] = dz.x;
-      p[1 * 64] = dz.y;
-      p[2 * 64] = dz.z;
-      p[3 * 64] = dz.w;
+      if constexpr (F16) {
+        // this wave's factor, then the thread's own lane operand of K-block `wave`: image [wave][hi | lo][lane] 8 bytes
+        float m = fmaxf(fmaxf(fabsf(dz.x), fabsf(dz.y)), fmaxf(fabsf(dz.z), fabsf(dz.w)));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        int e2 = 0;
+        if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &e2);
+        e2 = e2 < -100 ? -100 : e2;
+        const float sz = ldexpf(1.f, 15 - e2);   // (an Inf / NaN gradient: NaN products - it stays visible in dZ)
+        if (lane == 0) scl[wave] = ldexpf(1.f, e2 - 15) * sUinv;
+        float vs[4] = {dz.x * sz, dz.y * sz, dz.z * sz, dz.w * sz};
+        f16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          asm volatile("" : "+v"(vs[e]));
+          const _Float16 h = (_Float16)vs[e];
+          hi[e] = h;
+          lo[e] = (_Float16)(vs[e] - (float)h);
+        }
+        *reinterpret_cast<f16x4*>(dzi + ((wave * 2) * 64 + lane) * 2) = hi;
+        *reinterpret_cast<f16x4*>(dzi + ((wave * 2 + 1) * 64 + lane) * 2) = lo;
+      } else {
+        // own unit index s = 4*uq + wave -> image [q = s>>2 = uq][kk = gate][j][r = s&3 = wave]
+        float* p = dzi + ((uq * 4) * 16 + j) * 4 + wave;
+        p[0 * 64] = dz.x;
+        p[1 * 64] = dz.y;
+        p[2 * 64] = dz.z;
+        p[3 * 64] = dz.w;
+      }
     }
     __syncthreads();
     // ---- 3. partial sums for every tile of 16 units from this workgroup's 64 gate columns; send tile m to workgroup m
@@ -238,24 +309,47 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
       const int slot = k & 1;
       const unsigned par = (((unsigned)k >> 1) & 1u) ^ 1u;
       f32x4 dv[4];
+      f16x4 bh[4], bl[4];
+      float fs[4];
+      if constexpr (F16) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) dv[q] = *reinterpret_cast<const f32x4*>(dzi + ((q * 4 + uq) * 16 + j) * 4);
+        for (int q = 0; q < 4; ++q) {
+          bh[q] = *reinterpret_cast<const f16x4*>(dzi + ((q * 2) * 64 + lane) * 2);
+          bl[q] = *reinterpret_cast<const f16x4*>(dzi + ((q * 2 + 1) * 64 + lane) * 2);
+          fs[q] = scl[q];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dv[q] = *reinterpret_cast<const f32x4*>(dzi + ((q * 4 + uq) * 16 + j) * 4);
+      }
 #pragma unroll
       for (int i = 0; i < TPW; ++i) {
         const int m = wave + BW_WAVES * i;
         if (m < GT) {  // wave-uniform
           f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (F16) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            f32x4 as[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 4; ++q) as[q] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[i][q], bh[q], zero, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              if (r & 1)
-                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[i][4 * q + r], dv[q][r], a1, 0, 0, 0);
-              else
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[i][4 * q + r], dv[q][r], a0, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) as[q] = __builtin_amdgcn_mfma_f32_16x16x16f16(al[i][q], bh[q], as[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) as[q] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[i][q], bl[q], as[q], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a0[r] = fmaf(as[3][r], fs[3], fmaf(as[2][r], fs[2], fmaf(as[1][r], fs[1], as[0][r] * fs[0])));
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                if (r & 1)
+                  a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[i][4 * q + r], dv[q][r], a1, 0, 0, 0);
+                else
+                  a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[i][4 * q + r], dv[q][r], a0, 0, 0, 0);
+              }
             }
-          }
-          a0 += a1;
+            }
           if (m == ug) {
             own_tile = a0;
           } else {
@@ -282,7 +376,7 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
 
 // SMALL: every job of the launch is narrow (H <= 128) - its own kernel, so that the fusion layer's BPTT (56 workgroups beside
 // the projection GEMMs of the other stream) is allocated ~100 VGPRs instead of the 256 the H = 500 instantiation needs
-template <bool SPLIT, bool SMALL = false>
+template <bool SPLIT, bool SMALL = false, bool F16 = false>
 __device__ __forceinline__ void scan_cluster_bwd_body(const ClusterBwdLaunch& L, float* smem) {
   mgr_cluster_enter(L.cm);
   const int bid = blockIdx.x;
@@ -304,7 +398,7 @@ __device__ __forceinline__ void scan_cluster_bwd_body(const ClusterBwdLaunch& L,
     const int bg = cl - jb.cls_cluster0;
     if (bg < 0 || bg >= jb.nbg) continue;
 #define BW_CASE(HH) \
-  if (jb.H == HH) { cluster_bwd_run<HH, SPLIT>(jb, bg, ug, smem, L.cm.status, fast); return mgr_cluster_exit(L.cm); }
+  if (jb.H == HH) { cluster_bwd_run<HH, SPLIT, F16>(jb, bg, ug, smem, L.cm.status, fast); return mgr_cluster_exit(L.cm); }
     if constexpr (SMALL) {
       BW_SMALL(BW_CASE)
     } else {
@@ -329,6 +423,20 @@ __global__ __launch_bounds__(BW_WAVES * 64) void k_scan_cluster_bwd(ClusterBwdLa
 __global__ __launch_bounds__(2 * BW_WAVES * 64) void k_scan_cluster_bwd_split(ClusterBwdLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   scan_cluster_bwd_body<true>(L, smem);
+}
+
+// the same three with split-f16 operands (cluster_bwd_run<.., true>; tune key 14 = 1 keeps the f32 MFMA kernels above)
+__global__ __launch_bounds__(BW_WAVES * 64) void k_scan_cluster_bwd16_s(ClusterBwdLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  scan_cluster_bwd_body<false, true, true>(L, smem);
+}
+__global__ __launch_bounds__(BW_WAVES * 64, 2) void k_scan_cluster_bwd16(ClusterBwdLaunch L) {   // (two workgroups per CU: <= 256 VGPRs)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  scan_cluster_bwd_body<false, false, true>(L, smem);
+}
+__global__ __launch_bounds__(2 * BW_WAVES * 64) void k_scan_cluster_bwd16_split(ClusterBwdLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  scan_cluster_bwd_body<true, false, true>(L, smem);
 }
 
 }  // namespace
@@ -373,17 +481,28 @@ int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs)
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd_s), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd16_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd16_s), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     c->attr_done |= 2u;
   }
+  const bool f16 = c->tune[14] == 0;   // split-f16 operands (tune key 14 = 1: f32 MFMA)
   if (bwd_split(c, L, total_wgs)) {
     size_t lds = 84 * 1024;
-    hipLaunchKernelGGL(k_scan_cluster_bwd_split, dim3(total_wgs), dim3(2 * BW_WAVES * 64), lds, mgr_stream(c), L);
+    if (f16)
+      hipLaunchKernelGGL(k_scan_cluster_bwd16_split, dim3(total_wgs), dim3(2 * BW_WAVES * 64), lds, mgr_stream(c), L);
+    else
+      hipLaunchKernelGGL(k_scan_cluster_bwd_split, dim3(total_wgs), dim3(2 * BW_WAVES * 64), lds, mgr_stream(c), L);
   } else {
     size_t lds = (size_t)BW_LDS_FLOATS * sizeof(float);
     bool small = true;
     for (int i = 0; i < L.njobs; ++i) small = small && L.job[i].H <= 128;
-    if (small)
+    if (small && f16)
+      hipLaunchKernelGGL(k_scan_cluster_bwd16_s, dim3(total_wgs), dim3(BW_WAVES * 64), lds, mgr_stream(c), L);
+    else if (small)
       hipLaunchKernelGGL(k_scan_cluster_bwd_s, dim3(total_wgs), dim3(BW_WAVES * 64), lds, mgr_stream(c), L);
+    else if (f16)
+      hipLaunchKernelGGL(k_scan_cluster_bwd16, dim3(total_wgs), dim3(BW_WAVES * 64), lds, mgr_stream(c), L);
     else
       hipLaunchKernelGGL(k_scan_cluster_bwd, dim3(total_wgs), dim3(BW_WAVES * 64), lds, mgr_stream(c), L);
   }
