@@ -61,8 +61,18 @@ FAMILY = {"k_scan_cluster_ks": "scan_fwd", "k_scan_cluster_ks_s": "scan_fwd", "k
           "k_scan_fwd_mfma": "scan_fwd", "k_scan_cluster_bwd": "scan_bwd", "k_scan_bwd_mfma": "scan_bwd", "k_gemm_nn": "gemm_nn",
           "k_gemm_tn": "gemm_tn", "k_gemm_nt": "gemm_nt"}
 fam_bytes, fam_n = collections.defaultdict(float), collections.Counter()
+def family_of(k):   # (kernel names carry variant suffixes: _ks, _k16, _s, 16_split, ...)
+    if k in FAMILY:
+        return FAMILY[k]
+    for prefix, fam in (("k_scan_cluster_bwd", "scan_bwd"), ("k_scan_cluster", "scan_fwd"), ("k_gemm_nn", "gemm_nn"),
+                        ("k_gemm_tn", "gemm_tn")):
+        if k.startswith(prefix):
+            return fam
+    return None
+
+
 for k in f:
-    fam = FAMILY.get(k)
+    fam = family_of(k)
     if fam and fc[k]:
         fam_bytes[fam] += (2 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"]) * 1024.0
         fam_n[fam] += fc[k]
