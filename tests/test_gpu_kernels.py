@@ -438,6 +438,77 @@ def test_bwd_multi_matches_oracle(device, B, T, H, path):
         dev.call("mgr_tune", 1, 0)
 
 
+@pytest.mark.parametrize("H,B,T", [(100, 20, 24), (300, 18, 16), (500, 33, 12)])
+@pytest.mark.parametrize("scale", [1e-4, 1.0, 1.5])
+def test_split_f16_scan_over_weight_scales(device, H, B, T, scale):
+    """The split-f16 recurrence (operands as f16 (hi, lo) pairs of scaled f32 values) picks its weight scale from the
+    weights it finds: tiny, ordinary and large recurrent weights give the f32 MFMA step's accuracy against the fp64 oracle, and
+    both steps agree to rounding.  (Much larger weights make the recurrence chaotic: at 6 x the f32 step itself leaves the fp64
+    trajectory at H = 100, at 3 x still.)"""
+    dev = device
+    rng = np.random.default_rng(H + int(scale * 7))
+    F, f32 = 5, np.float32
+    x, W, U, b, _ = _lstm_case(rng, B, T, F, H, 0.0)
+    U = U * (0.1 if H >= 300 else 1.0) * scale
+    y_ref, cache = kr.lstm_forward(x, W, U, b, None, False)
+    Wp, Up, bp = dev.empty((F, 4 * H)), dev.empty((H, 4 * H)), dev.empty((4 * H,))
+    dev.call("mgr_lstm_pack", dev.array(W.astype(f32)), Wp, F, H, 0)
+    dev.call("mgr_lstm_pack", dev.array(U.astype(f32)), Up, H, H, 0)
+    dev.call("mgr_lstm_pack", dev.array(b.astype(f32)), bp, 1, H, 0)
+    Z = dev.empty((B, T, 4 * H))
+    dev.call("mgr_lstm_input_proj", dev.array(x.astype(f32)), F, 0, Wp, bp, Z, B, T, F, H)
+    ws = dev.bytes(dev.lib.mgr_lstm_scan_ws_bytes(B, T, H))
+    got = {}
+    dev.call("mgr_tune", 0, 3)   # clusters with an exchange at every H (the K-split step)
+    dev.call("mgr_tune", 1, 1)
+    try:
+        for f32_mfma in (0, 1):
+            dev.call("mgr_tune", 14, f32_mfma)
+            Y, Cs = dev.zeros((B, T, H)), dev.zeros((B, T, H))
+            dev.call("mgr_lstm_scan_fwd", Z, Up, Y, H, 0, 0, 0, Cs, B, T, H, 0, ws, ws.nbytes)
+            got[f32_mfma] = (Y.download(), Cs.download())
+        for f32_mfma in (0, 1):
+            assert rel_err(got[f32_mfma][0], y_ref) < 3e-5
+            assert rel_err(got[f32_mfma][1], cache["c"]) < 3e-5
+        assert rel_err(got[0][0], got[1][0]) < 1e-5
+    finally:
+        dev.call("mgr_tune", 14, 0)
+        dev.call("mgr_tune", 0, 0)
+        dev.call("mgr_tune", 1, 0)
+
+
+@pytest.mark.parametrize("H,B,T", [(100, 20, 12), (300, 18, 9)])
+def test_split_f16_bptt_is_homogeneous_over_80_binary_orders_of_magnitude(device, H, B, T):
+    """The multi-CU BPTT on the f16 pipe scales the gate gradients per wave and step by a power of two: scaling dY by
+    2^k scales every dZ by exactly 2^k - bit for bit - for k from -40 to +40, i.e. no gradient magnitude is special."""
+    dev = device
+    rng = np.random.default_rng(H)
+    F, f32 = 5, np.float32
+    x, W, U, b, _ = _lstm_case(rng, B, T, F, H, 0.0)
+    U = U * (0.1 if H >= 300 else 1.0)
+    Wp, Up, bp = dev.empty((F, 4 * H)), dev.empty((H, 4 * H)), dev.empty((4 * H,))
+    dev.call("mgr_lstm_pack", dev.array(W.astype(f32)), Wp, F, H, 0)
+    dev.call("mgr_lstm_pack", dev.array(U.astype(f32)), Up, H, H, 0)
+    dev.call("mgr_lstm_pack", dev.array(b.astype(f32)), bp, 1, H, 0)
+    Z = dev.empty((B, T, 4 * H))
+    dev.call("mgr_lstm_input_proj", dev.array(x.astype(f32)), F, 0, Wp, bp, Z, B, T, F, H)
+    Y, G, Cs = dev.empty((B, T, H)), dev.empty((B, T, H, 4)), dev.empty((B, T, H))
+    ws = dev.bytes(dev.lib.mgr_lstm_scan_ws_bytes(B, T, H))
+    dev.call("mgr_lstm_scan_fwd", Z, Up, Y, H, 0, 0, G, Cs, B, T, H, 0, ws, ws.nbytes)
+    dy = rng.standard_normal((B, T, H)).astype(f32)
+    base = None
+    for k in (0, -40, 40):
+        dYd = dev.array((dy * f32(2.0 ** k)).astype(f32))
+        dZ = dev.zeros((B, T, 4 * H))
+        dev.call("mgr_lstm_scan_bwd", dYd, H, G, Cs, Up, dZ, B, T, H, 0, ws, ws.nbytes)
+        out = dZ.download()
+        assert np.all(np.isfinite(out)) and np.abs(out).max() > 0
+        if base is None:
+            base = out
+        else:
+            assert np.array_equal(out, base * f32(2.0 ** k)), k
+
+
 @pytest.mark.parametrize("B,T,F,H,masked", [(3, 130, 64, 100, True), (2, 257, 1600, 100, True), (2, 100, 32, 25, False),
                                             (1, 128, 48, 300, True), (2, 90, 16, 20, True)])
 def test_input_proj_pair_equals_two_calls(device, B, T, F, H, masked):
