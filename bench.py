@@ -291,7 +291,7 @@ def main():
         parity = None
         dog.limit = max(dog.limit, 600.0) if dog.limit > 0 else 0   # (the CPU legs below are minutes of host work, not a hang)
         if not args.no_parity and world == 1:
-            parity = loss_parity(spec, dev, T)
+            parity = loss_parity(spec, dev, T, dict(kv.split("=") for kv in args.tune))
         cpu = None
         if not args.no_cpu and world == 1:   # the CPU leg is reported at N=1 only (torchrun also pins OMP_NUM_THREADS=1)
             cpu_T = args.cpu_T or T
@@ -335,7 +335,7 @@ def main():
     return out
 
 
-def loss_parity(spec, dev, T_full):
+def loss_parity(spec, dev, T_full, tuned=None):
     """CTC-loss delta vs the fp64 oracle on identical inputs: same network, the config's full sequence length, two
     sequences (the fp64 CPU side then takes a few seconds)."""
     from mgr_amd.engine import Engine
@@ -350,10 +350,32 @@ def loss_parity(spec, dev, T_full):
     rng = np.random.default_rng(4)
     rand = nr.draw_rand(sd, B, T, rng)
     w64 = {k: v.astype(np.float64) for k, v in w.items()}
-    ref, _, _, _ = nr.loss_and_grads(sd, w64, xs, labels, il, ll, rand)
-    eng.enqueue_train_step(xs, labels, il, ll, rand=rand, apply_update=False)
-    got = float(eng.loss_mean.download()[0])
-    return {"gpu": got, "oracle_fp64": ref, "rel_delta": abs(got - ref) / abs(ref), "shape": "B=%d,T=%d" % (B, T)}
+    ref, _, gref, _ = nr.loss_and_grads(sd, w64, xs, labels, il, ll, rand)
+
+    def run():
+        eng.enqueue_train_step(xs, labels, il, ll, rand=rand, apply_update=False)
+        got = float(eng.loss_mean.download()[0])
+        g = eng.get_grads()
+        # largest error of any trainable gradient tensor, relative to that tensor's largest entry
+        gerr = max(float(np.abs(g[k] - gref[k]).max() / max(np.abs(gref[k]).max(), 1e-30)) for k in gref)
+        return got, gerr
+
+    got, gerr = run()
+    out = {"gpu": got, "oracle_fp64": ref, "rel_delta": abs(got - ref) / abs(ref), "grad_max_rel_err": gerr,
+           "shape": "B=%d,T=%d" % (B, T)}
+    # the same step with the products on the f32 MFMA kernels (tune keys 14 / 15): what the split-f16 arithmetic of the default
+    # path costs in accuracy against the same fp64 oracle - nothing
+    tuned = tuned or {}
+    dev.call("mgr_tune", 14, 1)
+    dev.call("mgr_tune", 15, 1)
+    try:
+        got32, gerr32 = run()
+    finally:
+        dev.call("mgr_tune", 14, int(tuned.get("14", 0)))
+        dev.call("mgr_tune", 15, int(tuned.get("15", 0)))
+    out["f32_mfma_path"] = {"gpu": got32, "rel_delta": abs(got32 - ref) / abs(ref), "grad_max_rel_err": gerr32}
+    eng.close()
+    return out
 
 
 if __name__ == "__main__":

@@ -349,7 +349,8 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
                   a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[i][4 * q + r], dv[q][r], a0, 0, 0, 0);
               }
             }
-            }
+            a0 += a1;
+          }
           if (m == ug) {
             own_tile = a0;
           } else {

@@ -387,8 +387,10 @@ def test_scan_paths_agree(device, path):
 
 @pytest.mark.parametrize("B,T,H,path", [(5, 9, 32, 0), (33, 6, 100, 0), (17, 7, 128, 0), (20, 5, 16, 0), (3, 6, 8, 0), (19, 8, 100, 2), (18, 5, 300, 0), (33, 4, 500, 0),
                                         (7, 1, 100, 0), (20, 2, 500, 0), (33, 1, 300, 0), (64, 2, 128, 0)])   # T = 1, 2
-def test_bwd_multi_matches_oracle(device, B, T, H, path):
-    """BPTT of both directions in one call (multi-CU clusters exchanging dz_t when path == 0) vs the oracle."""
+@pytest.mark.parametrize("f32_mfma", [0, 1])
+def test_bwd_multi_matches_oracle(device, B, T, H, path, f32_mfma):
+    """BPTT of both directions in one call (multi-CU clusters exchanging dz_t when path == 0) vs the oracle - with the partial
+    products on the f16 matrix pipe (split-f16 operands, the default) and on the f32 matrix instruction (tune key 14 = 1)."""
     from mgr_amd import _capi
     dev = device
     rng = np.random.default_rng(H * 7 + B)
@@ -418,6 +420,7 @@ def test_bwd_multi_matches_oracle(device, B, T, H, path):
         outs.append((dX, Y, dZ, Wp))
     dev.call("mgr_tune", 0, path)
     dev.call("mgr_tune", 1, 1)
+    dev.call("mgr_tune", 14, f32_mfma)
     try:
         arr = _capi.make_scan_bwd_jobs(jobs)
         ws = dev.bytes(dev.lib.mgr_lstm_scan_bwd_multi_ws_bytes(2, arr))
@@ -434,6 +437,7 @@ def test_bwd_multi_matches_oracle(device, B, T, H, path):
                 dev.call("mgr_lstm_input_grad", dZ, Wp, 0, gX, F, 0, B, T, F, H)
                 assert rel_err(gX.download(), dx_ref) < 1e-4
     finally:
+        dev.call("mgr_tune", 14, 0)
         dev.call("mgr_tune", 0, 0)
         dev.call("mgr_tune", 1, 0)
 
