@@ -51,6 +51,30 @@ def cpu_baseline(spec_dict, seed, T_cpu, B_cpu):
     return B_cpu * T_cpu / dt, dt, float(loss)
 
 
+def rank_environments(n, port, base=None):
+    """The environments `python bench.py --gpus N` gives its N rank processes when it is its own launcher: what
+    torch.distributed.run would set (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), N distinct LOCAL_RANKs on one node."""
+    envs = []
+    for r in range(n):
+        env = dict(os.environ if base is None else base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        for v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):   # the ranks share the host's CPU quota
+            env[v] = str(max(1, effective_cores() // n))
+        envs.append(env)
+    return envs
+
+
+def rank_device(local_rank, ndev, world, comm):
+    """Device index of a rank and how many ranks share a GPU: rank r of a node binds GPU r (LOCAL_RANK, one process per GPU);
+    more ranks than GPUs is only legal with the host communicator (RCCL refuses two ranks on one device) and wraps around."""
+    if ndev < 1:
+        raise SystemExit("bench.py: no GPU visible")
+    if world > ndev and comm != "host":
+        raise SystemExit("bench.py: %d ranks on %d GPU(s) needs --comm host" % (world, ndev))
+    share = (world + ndev - 1) // ndev if world > ndev else 1
+    return local_rank % ndev, share
+
+
 def _spawn_ranks(n):
     """`python bench.py --gpus N` without torchrun: start N copies of this command, one rank per GPU, rendezvous on
     127.0.0.1; rank 0's JSON line goes to stdout.  Returns the first non-zero exit code."""
@@ -59,13 +83,7 @@ def _spawn_ranks(n):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
-        for v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):   # the ranks share the host's CPU quota
-            env[v] = str(max(1, effective_cores() // n))
-        procs.append(subprocess.Popen([sys.executable] + sys.argv, env=env))
+    procs = [subprocess.Popen([sys.executable] + sys.argv, env=env) for env in rank_environments(n, port)]
     rc = 0
     live = list(procs)
     while live:
@@ -120,6 +138,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the next step's frozen-encoder pass")
     ap.add_argument("--scan-path", type=int, default=0, help="0 auto, 3/4 clusters of 4/8 tiles per workgroup")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the second timed leg on the f32 MFMA kernels (tune 14 = 15 = 1)")
     ap.add_argument("--tune", action="append", default=[], help="KEY=VALUE for mgr_tune (A/B of kernel variants; may be repeated)")
     ap.add_argument("--no-transposed", action="store_true", help="dropout-aware projections gather columns of the row-major input")
     ap.add_argument("--cpu-T", type=int, default=0, help="T of the CPU leg's sample; 0 (default) = the configuration's own T: the full step")
@@ -156,16 +175,11 @@ def main():
     if args.maxlen:
         T = args.maxlen
     ndev = _capi.device_count()
-    share = 1
-    if world > ndev:
-        # more ranks than GPUs: only the host communicator can do that (RCCL refuses two ranks on one device).  Each rank's
-        # persistent scans must be co-resident with the other ranks' on the shared GPU, so the per-rank batch is divided.
-        if args.comm != "host":
-            raise SystemExit("bench.py: %d ranks on %d GPU(s) needs --comm host" % (world, ndev))
-        share = (world + ndev - 1) // ndev
-        if not args.batch:
-            B = max(16, B // share)
-    dev = _capi.Device(local_rank % max(1, ndev))
+    dev_index, share = rank_device(local_rank, ndev, world, args.comm)
+    if share > 1 and not args.batch:
+        # ranks that share a GPU: each rank's persistent scans must be co-resident with the other ranks', so the per-rank batch is divided
+        B = max(16, B // share)
+    dev = _capi.Device(dev_index)
     dog.beat("device")
     if args.show_plan:
         dev.call("mgr_tune", 2, 1)
@@ -210,22 +224,28 @@ def main():
             time.sleep(1e6)
         return loss
 
-    for i in range(args.warmup):
-        loss = step(i + 1 < args.warmup)
-    dev.prof_enable((1 << 10) - 1)
-    dev.prof_reset()
-    if comm:
-        comm.barrier()
-    dev.sync()
-    t0 = time.perf_counter()
-    losses, marks = [], [t0]
-    for i in range(args.steps):
-        losses.append(step(i + 1 < args.steps))
-        marks.append(time.perf_counter())     # (the moment the host has step i's loss: diagnostic only, `value` is frames / dt)
-    dev.sync()
-    if comm:
-        comm.barrier()
-    dt = time.perf_counter() - t0
+    def timed_region():
+        """W untimed warm-up steps, then exactly K steps between barrier + device-sync pairs."""
+        for i in range(args.warmup):
+            step(i + 1 < args.warmup)
+        dev.prof_enable((1 << len(_capi.KERNEL_FAMILIES)) - 1)
+        dev.prof_reset()
+        if isinstance(comm, HostComm):
+            comm.allreduce_ms(reset=True)
+        if comm:
+            comm.barrier()
+        dev.sync()
+        t0 = time.perf_counter()
+        losses, marks = [], [t0]
+        for i in range(args.steps):
+            losses.append(step(i + 1 < args.steps))
+            marks.append(time.perf_counter())     # (the moment the host has step i's loss: diagnostic only, `value` is frames / dt)
+        dev.sync()
+        if comm:
+            comm.barrier()
+        return time.perf_counter() - t0, losses, marks
+
+    dt, losses, marks = timed_region()
     if comm and world > 1:
         losses[-1] = eng.read_global_loss()     # mean over the global batch, identical on every rank
     if comm:
@@ -243,6 +263,38 @@ def main():
     frames = B * T * world * args.steps
     value = frames / dt
     ms_per_step = dt / args.steps * 1e3
+
+    # ---- what the communicator itself saw: a multi-GPU line must prove "N ranks met" from the line alone.
+    # rccl: ncclCommCount / ncclCommUserRank of the communicator + the device time of the gradient all-reduces (HIP events on
+    # stream 0 around ncclAllReduce); host: the ranks that connected at rank 0 + the host wall time of the exchange.
+    comm_info = None
+    if comm is not None:
+        seen, me = comm.ranks_seen()
+        n_ar, ms_ar = comm.allreduce_ms() if isinstance(comm, HostComm) else (fam["allreduce"]["launches"], fam["allreduce"]["ms"])
+        comm_info = {"backend": args.comm, "nranks_seen": seen, "rank_seen": me, "world_size_env": world,
+                     "local_rank_env": local_rank, "device_index": dev.index, "allreduces": n_ar,
+                     "allreduce_ms_per_step": round(ms_ar / max(1, args.steps), 4),
+                     "allreduce_timing": "host wall time (download excluded)" if isinstance(comm, HostComm) else "HIP events around ncclAllReduce on stream 0"}
+        if seen != world:
+            raise SystemExit("bench.py: the communicator reports %d ranks, the launcher %d" % (seen, world))
+
+    # ---- the same K steps on the f32 MFMA kernels (tune keys 14 = 15 = 1), same process, same warm-up: the strict-f32 time beside
+    # the split-f16 headline.  `value` above is never touched by it.
+    f32_leg = None
+    tuned0 = dict(kv.split("=") for kv in args.tune)
+    if not args.no_f32_leg and world == 1 and tuned0.get("14", "0") == "0" and tuned0.get("15", "0") == "0":
+        dev.call("mgr_tune", 14, 1)
+        dev.call("mgr_tune", 15, 1)
+        try:
+            dt32, losses32, _ = timed_region()
+        finally:
+            dev.call("mgr_tune", 14, 0)
+            dev.call("mgr_tune", 15, 0)
+            dev.prof_enable(0)
+        f32_leg = {"ms_per_step": round(dt32 / args.steps * 1e3, 3), "value": round(B * T * args.steps / dt32, 1), "unit": "frames/s",
+                   "steps": args.steps, "warmup": args.warmup, "loss": losses32[-1],
+                   "what": "the same engine and schedule with --tune 14=1 --tune 15=1: every product on v_mfma_f32_*_f32"}
+        dog.beat("f32 leg done")
 
     out = None
     if rank == 0:
@@ -323,7 +375,7 @@ def main():
                "whole_step_tflops_executed": round(whole_ex, 3),
                "whole_step_frac_of_f32_mfma_peak_executed": round(whole_ex / MFMA_F32_PEAK_TFLOPS, 5),
                "persistent_launches": {"total": n_persist.value, "serialised_by_admission": n_serial.value},
-               "loss": losses[-1], "ctc_loss_parity": parity, "kernel_ms": fam,
+               "loss": losses[-1], "ctc_loss_parity": parity, "f32_mfma_path": f32_leg, "comm": comm_info, "kernel_ms": fam,
                "host_step_ms": {"median": round(sorted(b - a for a, b in zip(marks, marks[1:]))[len(marks) // 2 - 1 if len(marks) > 1 else 0] * 1e3, 3),
                                 "max": round(max(b - a for a, b in zip(marks, marks[1:])) * 1e3, 3),
                                 "argmax": int(max(range(len(marks) - 1), key=lambda i: marks[i + 1] - marks[i]))},

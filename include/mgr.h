@@ -72,7 +72,7 @@ int mgr_event_elapsed_ms(mgr_ctx* ctx, int ev0, int ev1, float* ms);
  * family ids: MGR_K_*.  mgr_prof_get syncs the device and returns accumulated launches / milliseconds. */
 enum {
   MGR_K_GEMM_NN = 0, MGR_K_GEMM_TN = 1, MGR_K_GEMM_NT = 2, MGR_K_SCAN_FWD = 3, MGR_K_SCAN_BWD = 4,
-  MGR_K_DENSE_FWD = 5, MGR_K_DENSE_BWD = 6, MGR_K_CTC = 7, MGR_K_ADAM = 8, MGR_K_MISC = 9, MGR_K_COUNT = 10
+  MGR_K_DENSE_FWD = 5, MGR_K_DENSE_BWD = 6, MGR_K_CTC = 7, MGR_K_ADAM = 8, MGR_K_MISC = 9, MGR_K_ALLREDUCE = 10, MGR_K_COUNT = 11
 };
 int mgr_prof_enable(mgr_ctx* ctx, int family_mask);
 int mgr_prof_get(mgr_ctx* ctx, int family, int* launches, float* ms);
@@ -113,14 +113,19 @@ int mgr_lstm_input_proj_dropout(mgr_ctx* ctx, const float* X, int ldx, const flo
  * 128, zeros behind T; mgr_transpose_bt writes it): a kept feature is then a contiguous row, and the kernel's A operand is
  * staged with coalesced 16-byte loads instead of one scattered 4-byte load per element.  Only for shapes the dropout-aware
  * kernel handles - mgr_lstm_input_proj_dropout_wants_transposed says whether a copy is worth making for (drop_rate, F).
- * x_absmax: an upper bound on |XT| the caller can vouch for (the output of an LSTM layer: 1; with a residual sum: 2), or 0 if it
- * has none.  With a bound the products run on the f16 matrix pipe with every f32 operand split into an f16 (hi, lo) pair of its
- * scaled value and f32 accumulation (22+ significant bits per operand: gemm.hip, k_gemm_nn_sparse16; the representation error is
- * below the rounding an f32 accumulation of the same length commits); an input beyond the bound overflows f16 and shows as
- * Inf / NaN in Z.  0, or tune key 15 = 1: v_mfma_f32_32x32x2_f32.
- * mask4 may be NULL (no dropout: inference) when a bound is given: the plain dense projection on the f16 pipe (k_gemm_nn_dense16: one
+ * x_absmax: a bound on |XT|, or 0 if there is none.  With a bound the products run on the f16 matrix pipe with every f32 operand
+ * split into an f16 (hi, lo) pair of its scaled value and f32 accumulation (22+ significant bits per operand: gemm.hip,
+ * k_gemm_nn_sparse16; the representation error is below the rounding an f32 accumulation of the same length commits).
+ *   x_absmax > 0: a bound the CALLER states.  It is checked on the device in front of the product (k_absmax_gate: one pass over
+ *     XT); data that would leave the f16 range at the scale the bound implies make the call fall back - on the device, without a
+ *     host round trip - to the f32 MFMA kernel, so a wrong bound costs time, never Inf / NaN in Z.
+ *   x_absmax < 0: |x_absmax| is a bound the PRODUCER of XT guarantees by construction - the transposed copies the scans of this
+ *     library write (mgr_scan_job.YT) hold h = o * tanh(c), |h| <= 1, or the sum of two of them (residual input), <= 2 - and no
+ *     check is made.  This is what the engine passes for the buffers its own scans fill.
+ *   0, or tune key 15 = 1: v_mfma_f32_32x32x2_f32.
+ * mask4 may be NULL (no dropout: inference): with a bound the plain dense projection on the f16 pipe (k_gemm_nn_dense16: one
  * K loop over all features, the A tile staged once for the four gates; tune key 10 = 2 takes it with a mask as well, the mask
- * factors folded into the weight tiles). */
+ * factors folded into the weight tiles), without one the f32 kernel over all features. */
 int mgr_lstm_input_proj_dropout_wants_transposed(mgr_ctx* ctx, float drop_rate, int F);
 int mgr_lstm_input_proj_dropout_t(mgr_ctx* ctx, const float* XT, int ldt, const float* mask4, float drop_rate,
                                   const float* Wp, const float* bp, float* Z, int B, int T, int F, int H, void* ws,
@@ -190,7 +195,10 @@ int mgr_scan_status_ex(mgr_ctx* ctx, unsigned out[4]);
 int mgr_scan_status_clear(mgr_ctx* ctx);
 /* Several engines may share one context: each binds its OWN status block (>= 64 zeroed bytes from mgr_alloc, 16-byte aligned)
  * before it enqueues work; scans launched while a block is bound report into it and mgr_scan_status* / the update gate read
- * it.  NULL binds the context's own block again.  Host-side state only (no stream order). */
+ * it.  NULL binds the context's own block again.  Host-side state only (no stream order).
+ * Words of a block: [0] status bits, [2] skipped updates, [8, 16) WHICH samples met a non-finite hidden state - bit (b mod 256) of
+ * the 256-bit field is set together with MGR_SCAN_NONFINITE by the scan that saw sample b of its job go NaN / Inf, so that a
+ * consumer can hand out NaN for exactly those samples (Engine.predict: a block of its own per inference pass). */
 int mgr_scan_status_bind(mgr_ctx* ctx, void* block);
 /* Test hook: OR `bits` into the bound status block on the current stream, as a scan that gave up would. */
 int mgr_scan_status_inject(mgr_ctx* ctx, unsigned bits);
@@ -261,7 +269,8 @@ int mgr_lstm_param_grads_dropout(mgr_ctx* ctx, const float* X, int ldx, const fl
  * x_absmax: as for mgr_lstm_input_proj_dropout_t - with a bound on |XT| (and ldt >= T rounded up to 32) the dW product runs on the
  * f16 matrix pipe with split-f16 (hi, lo) operands and f32 accumulation (k_gemm_tn_sparse16; dZ is scaled per (sample, gate
  * column) by its own largest magnitude, so its dynamic range costs nothing); then equal to mgr_lstm_param_grads_dropout to the
- * f32 tolerance instead of bit for bit.  0, or tune key 15 = 1: the f32 MFMA kernel. */
+ * f32 tolerance instead of bit for bit.  > 0: checked on the device, f32 MFMA kernel if violated; < 0: guaranteed by the producer of
+ * XT, unchecked; 0, or tune key 15 = 1: the f32 MFMA kernel. */
 int mgr_lstm_param_grads_dropout_wants_transposed(mgr_ctx* ctx, float drop_rate, int F);
 size_t mgr_lstm_param_grads_dropout_t_ws_bytes(int B, int T, int F, int H, int ldt);
 int mgr_lstm_param_grads_dropout_t(mgr_ctx* ctx, const float* XT, int ldt, const float* mask4, float drop_rate,
@@ -322,6 +331,10 @@ int mgr_comm_init_rank(mgr_ctx* ctx, int nranks, int rank, const uint8_t id[MGR_
 int mgr_allreduce_sum(mgr_comm* comm, float* dbuf, size_t n); /* in place, on the ctx's current stream */
 int mgr_allreduce_max(mgr_comm* comm, float* dbuf, size_t n);
 int mgr_comm_destroy(mgr_comm* comm);
+/* What RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank), not what the caller passed to
+ * mgr_comm_init_rank: bench.py prints it, so that a multi-GPU line proves from the library's side that N ranks met.
+ * The gradient all-reduce's device time is profiling family MGR_K_ALLREDUCE (events on the stream it is enqueued on). */
+int mgr_comm_count(mgr_comm* comm, int* nranks_seen, int* rank_seen);
 
 /* ---- K9: decode (multimodal_fusion/sequence_decoding.py:38-53; audio_network/sequence_decoding.py:38-53) */
 /* best[b,t-skip] = argmax_c P[b,t,c] (first index on ties, numpy semantics), prob = that max. */

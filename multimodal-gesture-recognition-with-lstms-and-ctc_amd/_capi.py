@@ -100,6 +100,7 @@ SIGNATURES = {
     "mgr_allreduce_sum": (i32, [vp, vp, sz]),
     "mgr_allreduce_max": (i32, [vp, vp, sz]),
     "mgr_comm_destroy": (i32, [vp]),
+    "mgr_comm_count": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
     "mgr_frame_argmax": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
     "mgr_ctc_beam_ws_bytes": (sz, [i32, i32, i32, i32]),
     "mgr_ctc_beam_search": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_float, i32, vp, vp, vp, vp, sz]),
@@ -107,8 +108,8 @@ SIGNATURES = {
 
 SCAN_GAVE_UP, SCAN_NONFINITE = 1, 8   # enum in include/mgr.h (mgr_scan_status)
 
-(K_GEMM_NN, K_GEMM_TN, K_GEMM_NT, K_SCAN_FWD, K_SCAN_BWD, K_DENSE_FWD, K_DENSE_BWD, K_CTC, K_ADAM, K_MISC) = range(10)
-KERNEL_FAMILIES = ["gemm_nn", "gemm_tn", "gemm_nt", "scan_fwd", "scan_bwd", "dense_fwd", "dense_bwd", "ctc", "adam", "misc"]
+(K_GEMM_NN, K_GEMM_TN, K_GEMM_NT, K_SCAN_FWD, K_SCAN_BWD, K_DENSE_FWD, K_DENSE_BWD, K_CTC, K_ADAM, K_MISC, K_ALLREDUCE) = range(11)
+KERNEL_FAMILIES = ["gemm_nn", "gemm_tn", "gemm_nt", "scan_fwd", "scan_bwd", "dense_fwd", "dense_bwd", "ctc", "adam", "misc", "allreduce"]
 
 
 

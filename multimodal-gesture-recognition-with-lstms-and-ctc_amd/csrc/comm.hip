@@ -23,6 +23,8 @@ struct Rccl {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
 };
 Rccl g_rccl;
 
@@ -44,6 +46,8 @@ int rccl_load() {
   g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
   g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
   g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(dlsym(h, "ncclCommCount"));
+  g_rccl.CommUserRank = reinterpret_cast<decltype(g_rccl.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce)
     return mgr_fail(-3, "librccl.so lacks required symbols");
   g_rccl.lib = h;
@@ -93,13 +97,26 @@ int mgr_comm_init_rank(mgr_ctx* c, int nranks, int rank, const uint8_t id[MGR_UN
 static int allreduce(mgr_comm* m, float* dbuf, size_t n, int op) {
   MGR_REQUIRE(m && dbuf, "null argument");
   if (n == 0) return 0;
+  // (family MGR_K_ALLREDUCE times the SUM reductions - the gradient all-reduce of a step; the max reductions are bench.py's barriers)
+  if (op == ncclSum) mgr_prof_begin(m->ctx, MGR_K_ALLREDUCE);
   ncclResult_t e = g_rccl.AllReduce(dbuf, dbuf, n, ncclFloat, op, m->comm, mgr_stream(m->ctx));
+  if (op == ncclSum) mgr_prof_end(m->ctx, MGR_K_ALLREDUCE);
   if (e) return mgr_fail(-3, "ncclAllReduce: %s", rccl_err(e));
   return 0;
 }
 
 int mgr_allreduce_sum(mgr_comm* m, float* dbuf, size_t n) { return allreduce(m, dbuf, n, ncclSum); }
 int mgr_allreduce_max(mgr_comm* m, float* dbuf, size_t n) { return allreduce(m, dbuf, n, ncclMax); }
+
+int mgr_comm_count(mgr_comm* m, int* nranks_seen, int* rank_seen) {
+  MGR_REQUIRE(m && nranks_seen && rank_seen, "null argument");
+  MGR_REQUIRE(g_rccl.CommCount && g_rccl.CommUserRank, "librccl.so lacks ncclCommCount / ncclCommUserRank");
+  ncclResult_t e = g_rccl.CommCount(m->comm, nranks_seen);
+  if (e) return mgr_fail(-3, "ncclCommCount: %s", rccl_err(e));
+  e = g_rccl.CommUserRank(m->comm, rank_seen);
+  if (e) return mgr_fail(-3, "ncclCommUserRank: %s", rccl_err(e));
+  return 0;
+}
 
 int mgr_comm_destroy(mgr_comm* m) {
   if (!m) return 0;

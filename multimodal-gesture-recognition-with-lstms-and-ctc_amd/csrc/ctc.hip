@@ -113,6 +113,14 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
       LYRb[(size_t)c * TS + (Tp - 1 - t)] = v;
     }
   }
+  // the two-chunks-ahead prefetch of the recursions reads up to 2 CH + 2 = 18 floats behind the last emission of a row (values it
+  // never uses): they are zeros, not whatever the workspace held (forward rows: [Tp + 3, Tp + 24), reversed rows: [Tp, Tp + 21);
+  // TS >= To + 24 holds both)
+  for (int i = tid; i < C * 21; i += 256) {
+    const int c = i / 21, k = i % 21;
+    LYTb[(size_t)c * TS + Tp + 3 + k] = 0.f;
+    LYRb[(size_t)c * TS + Tp + k] = 0.f;
+  }
   __syncthreads();
 
   // ---- phase 1: alpha (wave 0) / beta (wave 1) --------------------------------------------------------

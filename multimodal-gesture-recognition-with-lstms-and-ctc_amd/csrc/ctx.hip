@@ -248,6 +248,7 @@ int mgr_scan_status_clear(mgr_ctx* c) {
   unsigned* blk = mgr_status_block(c);
   MGR_HIP(hipMemsetAsync(blk, 0, sizeof(unsigned), mgr_stream(c)));
   MGR_HIP(hipMemsetAsync(blk + 2, 0, sizeof(unsigned), mgr_stream(c)));
+  MGR_HIP(hipMemsetAsync(blk + 8, 0, 8 * sizeof(unsigned), mgr_stream(c)));   // the per-sample non-finite bits
   return 0;
 }
 

@@ -334,6 +334,22 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nn2(const float* __restrict__ X
 }
 
 
+// A stated bound on |X| that the data violate (mgr.h, x_absmax): k_absmax_gate looks at the operand BEFORE the split-f16 kernel that
+// trusts the bound, and raises a device word when a scaled value would leave the f16 range (the split would hold Inf).  Both kernels
+// of the call are enqueued: the split-f16 one returns at once when the word is raised, the f32 MFMA one when it is not - the
+// decision never travels to the host.  (NaN / Inf inputs are not violations: both kernels carry them into the output.)
+#define MGR_GATED(gate, run_if_raised) \
+  if ((gate) && ((*(gate) != 0u) != (run_if_raised))) return
+__global__ __launch_bounds__(256) void k_absmax_gate(const float* __restrict__ X, size_t n4, float limit, unsigned* __restrict__ gate) {
+  bool over = false;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(X)[i];
+    const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    over = over || (m > limit && m < __uint_as_float(0x7F800000u));
+  }
+  if (__any(over) && (threadIdx.x & 63) == 0) atomicOr(gate, 1u);
+}
+
 // ------------------------------------------------------------------------------------------------ nn, dropout-aware
 // Keras input dropout zeroes a fraction p of the input features per (gate, sample) (speech_lstm_ctc_words.py:61,73:
 // p = 0.4 / 0.5; skeletal_lstm_ctc.py:313,327: 0.6; multimodal.py:159-168: 0.5): (x (.) m_g) . W_g only needs the kept
@@ -372,6 +388,18 @@ __global__ __launch_bounds__(64) void k_mask_compact(const float* __restrict__ m
     out[i] = 0;
     val[i] = 0.f;
   }
+}
+
+// the lists of a projection WITHOUT a mask: every feature kept with factor 1 (the f32 kernel as the plain dense projection)
+__global__ __launch_bounds__(64) void k_mask_all(int F, int Fp, int* __restrict__ kidx, float* __restrict__ kval, int* __restrict__ kcnt,
+                                                 unsigned* __restrict__ zero_word) {
+  const int gb = blockIdx.x, lane = threadIdx.x;
+  if (zero_word && gb == 0 && lane == 0) *zero_word = 0u;
+  for (int i = lane; i < Fp; i += 64) {
+    kidx[(size_t)gb * Fp + i] = i < F ? i : 0;
+    kval[(size_t)gb * Fp + i] = i < F ? 1.f : 0.f;
+  }
+  if (lane == 0) kcnt[gb] = F;
 }
 
 // Wg[g][f][u] = Wp[f][4u + g]: gate-major copy of the packed kernel, so that the row gather of one gate pass reads
@@ -415,7 +443,9 @@ template <int WC, bool TR>
 __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_gemm_nn_sparse(const float* __restrict__ X, int ldx, const int* __restrict__ kidx,
                                                         const float* __restrict__ kval, const int* __restrict__ kcnt,
                                                         const float* __restrict__ Wp, const float* __restrict__ bp,
-                                                        float* __restrict__ Z, int B, int T, int Fp, int F, int H) {
+                                                        float* __restrict__ Z, int B, int T, int Fp, int F, int H,
+                                                        const unsigned* __restrict__ gate /* may be null: MGR_GATED */) {
+  MGR_GATED(gate, true);
   constexpr int TM = SP_TM, TU = 32 * WC, SK = SP_SK, NT = 128 * WC;
   constexpr int QT = NT / 4;          // threads per k-quad of a stage: thread (quad q = tid / QT, r = tid % QT)
   constexpr int RPT = TM / QT;        // A rows per thread (r, r + QT, ...): 2 (WC = 2) or 1 (WC = 4)
@@ -593,7 +623,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sparse16(const float* __rest
                                                              const float* __restrict__ kval, const int* __restrict__ kcnt,
                                                              const float* __restrict__ Wp, const float* __restrict__ bp,
                                                              float* __restrict__ Z, int B, int T, int Fp, int F, int H,
-                                                             const unsigned* __restrict__ wmax, float vmax, float sx) {
+                                                             const unsigned* __restrict__ wmax, float vmax, float sx, const unsigned* __restrict__ gate) {
+  MGR_GATED(gate, false);
   constexpr int TM = SP_TM, TU = 64, SK = SP_SK, NT = 256, QT = 64, RPT = 2;
   __shared__ __attribute__((aligned(16))) _Float16 Ah[2][2][TM][8], Al[2][2][TM][8];   // [buffer][k half][row][8 k-slots]
   __shared__ __attribute__((aligned(16))) _Float16 Bh[2][2][TU][8], Bl[2][2][TU][8];
@@ -740,7 +771,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn_sparse16(const float* __rest
 __global__ __launch_bounds__(256, 2) void k_gemm_nn_dense16(const float* __restrict__ X, int ldx, const float* __restrict__ mask4,
                                                             const float* __restrict__ Wp, const float* __restrict__ bp,
                                                             float* __restrict__ Z, int B, int T, int F, int H,
-                                                            const unsigned* __restrict__ wmax, float vmax, float sx) {
+                                                            const unsigned* __restrict__ wmax, float vmax, float sx, const unsigned* __restrict__ gate) {
+  MGR_GATED(gate, false);
   constexpr int TM = SP_TM, TU = 64, NT = 256, QT = 64, RPT = 2;
   __shared__ __attribute__((aligned(16))) _Float16 Ah[2][2][TM][8], Al[2][2][TM][8];        // [buffer][k half][row][8 k-slots]
   __shared__ __attribute__((aligned(16))) _Float16 Bh[2][4][2][TU][8], Bl[2][4][2][TU][8];  // [buffer][gate][k half][unit][8]
@@ -981,7 +1013,8 @@ template <bool TR>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn_sparse(const float* __restrict__ X, int ldx, const int* __restrict__ kidx,
                                                         const float* __restrict__ kval, const int* __restrict__ kcnt,
                                                         const float* __restrict__ dZ, int ldz, float* __restrict__ P, int B, int T,
-                                                        int Fp, int F, int H) {
+                                                        int Fp, int F, int H, const unsigned* __restrict__ gate /* may be null: MGR_GATED */) {
+  MGR_GATED(gate, true);
   __shared__ __attribute__((aligned(16))) float As2[NBUF][BK][LDS_LD];
   __shared__ __attribute__((aligned(16))) float Bs2[NBUF][BK][LDS_LD];
   __shared__ float rowf[BM];
@@ -1070,7 +1103,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_sparse(const float* __restri
 __global__ __launch_bounds__(256, 2) void k_gemm_tn_sparse16(const float* __restrict__ X, int ldx, const int* __restrict__ kidx,
                                                              const float* __restrict__ kval, const int* __restrict__ kcnt,
                                                              const float* __restrict__ dZ, int ldz, const unsigned* __restrict__ zmax,
-                                                             float* __restrict__ P, int B, int T, int Fp, int F, int H, float sx) {
+                                                             float* __restrict__ P, int B, int T, int Fp, int F, int H, float sx, const unsigned* __restrict__ gate) {
+  MGR_GATED(gate, false);
   constexpr int TK = 32;   // time steps per stage
   __shared__ __attribute__((aligned(16))) _Float16 Ah[2][2][2][BM][8], Al[2][2][2][BM][8];   // [buffer][k-step][k half][row][8]
   __shared__ __attribute__((aligned(16))) _Float16 Bh[2][2][2][BN][8], Bl[2][2][2][BN][8];
@@ -1182,11 +1216,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_sparse16(const float* __rest
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int u = u0 + ACC_COL(wc, nt, lane);
-      const float cf = 1.f / (zscale(u < H ? u : H - 1) * sx);
+      // (the two reciprocals apart: zscale reaches 2^115 for a row of tiny gradients, and zscale * sx would overflow to Inf there -
+      // cf = 0 flushed such a row's dW contribution to zero instead of rescaling it; both are powers of two, the products are exact)
+      const float cz = 1.f / zscale(u < H ? u : H - 1), cx = 1.f / sx;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int r = ACC_ROW(wr, mt, reg, lane);
-        if (q0 + r < cnt && u < H) out[(size_t)(q0 + r) * H + u] = acc[mt][nt][reg] * cf * kval[(size_t)gb * Fp + q0 + r];
+        if (q0 + r < cnt && u < H) out[(size_t)(q0 + r) * H + u] = acc[mt][nt][reg] * cx * cz * kval[(size_t)gb * Fp + q0 + r];
       }
     }
 }
@@ -1427,15 +1463,23 @@ static int input_proj_dropout_impl(mgr_ctx* c, const float* X, int ldx, bool tra
   unsigned* wmax = reinterpret_cast<unsigned*>(w + 2 * lbytes + mgr_align_up((size_t)4 * B * sizeof(int), 256));
   float* Wg = reinterpret_cast<float*>(w + 2 * lbytes + mgr_align_up((size_t)4 * B * sizeof(int), 256) + 256);
   hipStream_t s = mgr_stream(c);
-  // split-f16 kernel (tune key 15 = 1: never): transposed input with a stated bound on |X|, a drop rate that bounds the mask factor
-  const bool f16 = transposed && x_absmax > 0.f && x_absmax < 1.0e30f && drop_rate < 0.99f && c->tune[15] == 0;
+  // x_absmax > 0: a bound the CALLER states - checked on the device (k_absmax_gate), f32 kernel if violated; < 0: |x_absmax| is a bound
+  // the PRODUCER of XT guarantees (mgr.h): no check
+  const bool trusted = x_absmax < 0.f;
+  const float xb = fabsf(x_absmax);
+  // split-f16 kernel (tune key 15 = 1: never): transposed input with a bound on |X|, a drop rate that bounds the mask factor
+  const bool f16 = transposed && xb > 0.f && xb < 1.0e30f && drop_rate < 0.99f && c->tune[15] == 0;
   // dense K loop with the mask as a factor (k_gemm_nn_dense16): where there is no mask (inference); tune key 10 = 2: always.  With a
   // mask the per-gate K loops over the kept features are faster (audio depth 2: 1.99 against 2.28 ms)
   const bool dense = f16 && (!mask4 || c->tune[10] == 2);
-  MGR_REQUIRE(mask4 || dense, "a projection without a dropout mask needs the dense split-f16 kernel (a bound on |X|)");
+  MGR_REQUIRE(mask4 || transposed, "a projection without a dropout mask is only handled from the transposed copy");
+  unsigned* gate = (f16 && !trusted) ? wmax + 1 : nullptr;
+  const bool lists = !dense || gate;   // the kept-feature lists: what every kernel but the dense one walks (no mask: all features)
   mgr_prof_begin(c, MGR_K_GEMM_NN);
-  if (!dense)
+  if (lists && mask4)
     hipLaunchKernelGGL(k_mask_compact, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp, kidx, kval, kcnt, (int*)nullptr, wmax);
+  else if (lists)
+    hipLaunchKernelGGL(k_mask_all, dim3(4 * B), dim3(64), 0, s, F, Fp, kidx, kval, kcnt, wmax);
   else
     MGR_HIP(hipMemsetAsync(wmax, 0, sizeof(unsigned), s));
   {
@@ -1449,24 +1493,29 @@ static int input_proj_dropout_impl(mgr_ctx* c, const float* X, int ldx, bool tra
   const bool wide = c->tune[11] == 2 && !transposed;
   const int tu = wide ? 128 : 64;
   const int ntiles = ((H + tu - 1) / tu) * ((((T + SP_TM - 1) / SP_TM) * B + 7) / 8) * 8;   // (row tiles padded to the 8 XCDs)
-  if (dense) {
+  if (f16) {
     int ex;
-    (void)frexpf(x_absmax, &ex);
+    (void)frexpf(xb, &ex);                       // xb = m 2^ex, m in [0.5, 1): |X| sx < 2^15
     const float sx = ldexpf(1.f, 15 - ex);
-    hipLaunchKernelGGL(k_gemm_nn_dense16, dim3(ntiles), dim3(256), 0, s, X, ldx, mask4, Wg, bp, Z, B, T, F, H, wmax,
-                       mask4 ? 1.f / (1.f - drop_rate) : 1.f, sx);
-  } else if (f16) {
-    int ex;
-    (void)frexpf(x_absmax, &ex);                       // x_absmax = m 2^ex, m in [0.5, 1): |X| sx < 2^15
-    const float sx = ldexpf(1.f, 15 - ex);
-    hipLaunchKernelGGL(k_gemm_nn_sparse16, dim3(ntiles), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H, wmax,
-                       1.f / (1.f - drop_rate), sx);
+    if (gate) {   // what |X| the f16 range holds at this scale: beyond it the split would carry Inf (ldx is the padded row length)
+      MGR_HIP(hipMemsetAsync(gate, 0, sizeof(unsigned), s));
+      const size_t n4 = (size_t)B * F * ldx / 4;
+      hipLaunchKernelGGL(k_absmax_gate, dim3((int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096)), dim3(256), 0, s, X, n4, 65000.f / sx, gate);
+    }
+    if (dense)
+      hipLaunchKernelGGL(k_gemm_nn_dense16, dim3(ntiles), dim3(256), 0, s, X, ldx, mask4, Wg, bp, Z, B, T, F, H, wmax,
+                         mask4 ? 1.f / (1.f - drop_rate) : 1.f, sx, gate);
+    else
+      hipLaunchKernelGGL(k_gemm_nn_sparse16, dim3(ntiles), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H, wmax,
+                         1.f / (1.f - drop_rate), sx, gate);
+    if (gate)   // the f32 MFMA kernel over the same lists: runs only if the gate was raised
+      hipLaunchKernelGGL((k_gemm_nn_sparse<2, true>), dim3(ntiles), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H, gate);
   } else if (transposed)
-    hipLaunchKernelGGL((k_gemm_nn_sparse<2, true>), dim3(ntiles), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H);
+    hipLaunchKernelGGL((k_gemm_nn_sparse<2, true>), dim3(ntiles), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H, (const unsigned*)nullptr);
   else if (wide)
-    hipLaunchKernelGGL((k_gemm_nn_sparse<4, false>), dim3(ntiles), dim3(512), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H);
+    hipLaunchKernelGGL((k_gemm_nn_sparse<4, false>), dim3(ntiles), dim3(512), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H, (const unsigned*)nullptr);
   else
-    hipLaunchKernelGGL((k_gemm_nn_sparse<2, false>), dim3(ntiles), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H);
+    hipLaunchKernelGGL((k_gemm_nn_sparse<2, false>), dim3(ntiles), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, Wg, bp, Z, B, T, Fp, F, H, (const unsigned*)nullptr);
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_GEMM_NN);
   return 0;
@@ -1634,22 +1683,32 @@ static int param_grads_dropout_impl(mgr_ctx* c, const float* X, int ldx, const f
     if (XT) {
       float* dZT = reinterpret_cast<float*>(w);   // [B][4H][ldt]
       w += mgr_align_up((size_t)B * 4 * H * ldt * sizeof(float), 256);
-      // split-f16 kernel (tune key 15 = 1: never): a stated bound on |X|, whole stages of 32 time steps in the padded rows
-      const bool f16 = x_absmax > 0.f && x_absmax < 1.0e30f && c->tune[15] == 0 && ldt >= (T + 31) / 32 * 32;
-      unsigned* zmax = reinterpret_cast<unsigned*>(w);   // [B][4H] largest |dZ| of a (sample, gate column)
-      if (f16) MGR_HIP(hipMemsetAsync(zmax, 0, (size_t)B * 4 * H * sizeof(unsigned), s));
+      // split-f16 kernel (tune key 15 = 1: never): a bound on |X| (stated: checked on the device, f32 kernel if violated; negative:
+      // guaranteed by the producer of XT), whole stages of 32 time steps in the padded rows
+      const bool trusted = x_absmax < 0.f;
+      const float xb = fabsf(x_absmax);
+      const bool f16 = xb > 0.f && xb < 1.0e30f && c->tune[15] == 0 && ldt >= (T + 31) / 32 * 32;
+      unsigned* zmax = reinterpret_cast<unsigned*>(w);   // [B][4H] largest |dZ| of a (sample, gate column), + the gate word
+      unsigned* gate = (f16 && !trusted) ? zmax + (size_t)B * 4 * H : nullptr;
+      if (f16) MGR_HIP(hipMemsetAsync(zmax, 0, ((size_t)B * 4 * H + 1) * sizeof(unsigned), s));
       hipLaunchKernelGGL(k_transpose_bt, dim3((ldt + 63) / 64, (4 * H + 63) / 64, B), dim3(256), 0, s, dZ, 4 * H, dZT, ldt, T, 4 * H, 0LL, ldt,
                          f16 ? zmax : (unsigned*)nullptr);
       if (f16) {
         int ex;
-        (void)frexpf(x_absmax, &ex);
-        hipLaunchKernelGGL(k_gemm_tn_sparse16, dim3(grid), dim3(256), 0, s, XT, ldt, kidx, kval, kcnt, dZT, ldt, zmax, P, B, T, Fp, F, H,
-                           ldexpf(1.f, 15 - ex));
+        (void)frexpf(xb, &ex);
+        const float sx = ldexpf(1.f, 15 - ex);
+        if (gate) {
+          const size_t n4 = (size_t)B * F * ldt / 4;
+          hipLaunchKernelGGL(k_absmax_gate, dim3((int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096)), dim3(256), 0, s, XT, n4, 65000.f / sx, gate);
+        }
+        hipLaunchKernelGGL(k_gemm_tn_sparse16, dim3(grid), dim3(256), 0, s, XT, ldt, kidx, kval, kcnt, dZT, ldt, zmax, P, B, T, Fp, F, H, sx, gate);
+        if (gate)
+          hipLaunchKernelGGL((k_gemm_tn_sparse<true>), dim3(grid), dim3(256), 0, s, XT, ldt, kidx, kval, kcnt, dZT, ldt, P, B, T, Fp, F, H, gate);
       } else {
-        hipLaunchKernelGGL((k_gemm_tn_sparse<true>), dim3(grid), dim3(256), 0, s, XT, ldt, kidx, kval, kcnt, dZT, ldt, P, B, T, Fp, F, H);
+        hipLaunchKernelGGL((k_gemm_tn_sparse<true>), dim3(grid), dim3(256), 0, s, XT, ldt, kidx, kval, kcnt, dZT, ldt, P, B, T, Fp, F, H, (const unsigned*)nullptr);
       }
     } else {
-      hipLaunchKernelGGL((k_gemm_tn_sparse<false>), dim3(grid), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, dZ, 0, P, B, T, Fp, F, H);
+      hipLaunchKernelGGL((k_gemm_tn_sparse<false>), dim3(grid), dim3(256), 0, s, X, ldx, kidx, kval, kcnt, dZ, 0, P, B, T, Fp, F, H, (const unsigned*)nullptr);
     }
     const size_t n = (size_t)4 * F * H;
     hipLaunchKernelGGL(k_dw_gather, dim3((int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, P, kpos, dWp, B, F, Fp, H);
@@ -1681,7 +1740,7 @@ int mgr_lstm_param_grads_dropout_wants_transposed(mgr_ctx* c, float drop_rate, i
 
 size_t mgr_lstm_param_grads_dropout_t_ws_bytes(int B, int T, int F, int H, int ldt) {
   return mgr_lstm_param_grads_dropout_ws_bytes(B, T, F, H) + mgr_align_up((size_t)B * 4 * H * ldt * sizeof(float), 256) +
-         mgr_align_up((size_t)B * 4 * H * sizeof(unsigned), 256);   // (dZT, the row maxima of dZT)
+         mgr_align_up(((size_t)B * 4 * H + 1) * sizeof(unsigned), 256);   // (dZT, the row maxima of dZT + the bound-violation word)
 }
 
 int mgr_lstm_param_grads_dropout_t(mgr_ctx* c, const float* XT, int ldt, const float* mask4, float drop_rate, const float* Hs, int ldh,

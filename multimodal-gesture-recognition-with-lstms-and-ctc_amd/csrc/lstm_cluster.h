@@ -14,6 +14,7 @@ constexpr size_t kScanHdrBytes = 4096;   //   [64, 1024) XCC (XCD) id + 1 of eve
 //   [1] (context's own block only) highest launch sequence number whose workgroups have ALL started (mgr_stream_wait_next_resident)
 //   [16, 32) (context's own block only) the same per launch: word 16 + seq % 16 holds seq once launch `seq` is resident
 //   [2] optimizer updates skipped by the update gate since the last clear
+//   [8, 16) which samples met a non-finite hidden state: bit (sample mod 256), set with MGR_ST_NONFINITE
 enum : unsigned {
   MGR_ST_GAVE_UP = MGR_SCAN_GAVE_UP,       // a bounded spin expired: a peer workgroup never showed up / never published
   MGR_ST_NONFINITE = MGR_SCAN_NONFINITE,   // a hidden state became NaN / Inf: outputs carry NaN from that step on (not a hang)
@@ -141,6 +142,10 @@ __device__ __forceinline__ bool mgr_cluster_octet(const ClusterCommon& cm, int c
     }
   }
   return same;
+}
+// which SAMPLE met a non-finite hidden state: bit (b mod 256) of words [8, 16) of the status block (mgr.h, mgr_scan_status_bind)
+__device__ __forceinline__ void mgr_mark_sample(const ClusterCommon& cm, int b) {
+  __hip_atomic_fetch_or(cm.sticky + 8 + ((b & 255) >> 5), 1u << (b & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // last thing: fold this launch's status bits into the context's sticky word
 __device__ __forceinline__ void mgr_cluster_exit(const ClusterCommon& cm) {

@@ -502,6 +502,7 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
         // NaN / Inf (diverged weights, bad checkpoint): what is published - and fed back - stays finite (0), Y of this (sample,
         // unit) is NaN from here on (latched) and the launch raises MGR_SCAN_NONFINITE (mgr.h)
         __hip_atomic_fetch_or(cm.sticky, MGR_ST_NONFINITE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mgr_mark_sample(cm, b);
         nonfinite = true;
       }
       if (nonfinite) {
@@ -788,6 +789,7 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
       h = mgr_cell_fwd(tot[0], tot[1], tot[2], tot[3], c, g4);
       if (!(fabsf(h) < 2.f) && !nonfinite) {
         __hip_atomic_fetch_or(cm.sticky, MGR_ST_NONFINITE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mgr_mark_sample(cm, b);
         nonfinite = true;
       }
       if (nonfinite) {

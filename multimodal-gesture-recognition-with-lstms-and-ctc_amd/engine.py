@@ -137,6 +137,9 @@ class Engine:
         self.params = dev.zeros((max(off, 4),))
         # this engine's own scan-status block (several engines may share one Device): [0] status bits, [2] skipped updates
         self.status = dev.zeros((16,), np.uint32)
+        # inference passes (predict / loss_on_batch / predict_stream) report into a block of their OWN per pass (two: batches of a
+        # pipelined run alternate), so that one batch with a NaN input marks ITS samples and nothing else (words [8, 16): mgr.h)
+        self._pass_status = [dev.zeros((16,), np.uint32) for _ in range(2)]
         self.loss_host = dev.pinned((4,), np.float32)
         self.status_host = dev.pinned((4,), np.uint32)
         # data parallel: [gate flag, sum over ranks of the local mean losses, -, -] of step s in slot s & 1, copied from behind the
@@ -281,9 +284,42 @@ class Engine:
         return self.grads.view(off, (n,))
 
     # ------------------------------------------------------------------------------------------ weights
-    def _bind(self):
-        """Scans enqueued from here on report into THIS engine's status block (the Device may be shared)."""
-        self.dev.call("mgr_scan_status_bind", self.status)
+    def _bind(self, block=None):
+        """Scans enqueued from here on report into THIS engine's status block (the Device may be shared) - or into `block`."""
+        self.dev.call("mgr_scan_status_bind", self.status if block is None else block)
+
+    def _begin_pass(self, slot=0):
+        """An inference pass gets a zeroed status block of its own (current stream): what its scans report - a give-up, WHICH
+        samples met a non-finite state - belongs to this pass only, whatever earlier passes or the training loop recorded."""
+        blk = self._pass_status[slot]
+        blk.zero()
+        self._bind(blk)
+        return blk
+
+    def _end_pass(self, blk_words, out, what="inference pass"):
+        """blk_words: the 16 words of the pass's status block on the host (read behind the pass).  Raises on a give-up; returns
+        `out` with NaN in the rows of exactly the samples whose hidden state went NaN / Inf in THIS pass (the multi-CU exchange
+        feeds 0 back for such a state, so other units of the sample may look finite where the reference's whole sample is NaN)."""
+        self._bind()
+        bits = int(blk_words[0])
+        if bits & ~_capi.SCAN_NONFINITE:
+            raise _capi.MgrError("a persistent scan of this %s gave up on a bounded spin (status %d): its outputs are invalid" % (what, bits))
+        if not bits & _capi.SCAN_NONFINITE:
+            return out
+        field = np.asarray(blk_words[8:16], np.uint32)
+        bad = np.array([bool((int(field[(b & 255) >> 5]) >> (b & 31)) & 1) for b in range(self.B)])
+        return self._nan_rows(out, bad)
+
+    def _nan_rows(self, out, bad):
+        """NaN (floats) / -1 (integer label outputs) / empty paths in the rows of the samples marked in `bad`."""
+        if isinstance(out, tuple):
+            return tuple(self._nan_rows(o, bad) for o in out)
+        if isinstance(out, list) and len(out) == len(bad):            # decoded label sequences: no labels for an invalid sample
+            return [[] if bad[b] else o for b, o in enumerate(out)]
+        if isinstance(out, np.ndarray) and out.shape[:1] == bad.shape:
+            out = out.copy()
+            out[bad] = np.nan if out.dtype.kind == "f" else -1
+        return out
 
     def set_weights(self, weights):
         """weights: dict name -> numpy array in Keras layout (see NetworkSpec.weight_table).  Fresh weights start with a clean
@@ -388,6 +424,12 @@ class Engine:
         self.Xin = self._xin_ring[slot]
         dev.stream(stream)
 
+    # Bound on the transposed activation copies the engine keeps (Y1T, FEAT^T), in the convention of mgr.h's x_absmax: NEGATIVE =
+    # guaranteed by the producer, not checked.  Every such copy holds outputs of LSTM layers of this library - h = o * tanh(c) with
+    # o in [0, 1], so |h| <= 1 - or the residual sum of two of them (encoder stacks, multimodal.py:111,117): <= 2 by construction,
+    # whether the scans wrote the copy themselves or mgr_transpose_bt made it from such a buffer.  A diverged state is NaN, not large.
+    XT_BOUND = -2.0
+
     def _project_pair(self, X, ldx, pair, Ls, B, T, fin, H, XT=None, xt_ready=False):
         """Input projections of the two directions of one Bidirectional layer (pair = [mask, Wp, bp, Z] x 2).  With input
         dropout active the library runs each direction's K loops over the kept features only (from p >= 0.3 on) - from the
@@ -400,21 +442,19 @@ class Engine:
                 m, Wp, bp, Z = pair[4 * d:4 * d + 4]
                 ws = Ls[d].ws_sp
                 if XT is not None:
-                    # (XT is the output of LSTM layers: |h| <= 1, with the residual sum of the encoder stacks <= 2 - the bound
-                    # the library's split-f16 kernel scales by, mgr.h)
                     self.dev.call("mgr_lstm_input_proj_dropout_t", XT, self.ldt, m, float(Ls[d].p), Wp, bp, Z, B, T, fin, H,
-                                  ws, ws.nbytes, 2.0)
+                                  ws, ws.nbytes, self.XT_BOUND)
                 else:
                     self.dev.call("mgr_lstm_input_proj_dropout", X, ldx, m, float(Ls[d].p), Wp, bp, Z, B, T, fin, H, ws, ws.nbytes)
         elif not pair[0] and XT is not None and 128 <= fin <= 2048 and Ls[0].ws_sp is not None:
             # no dropout (inference) on a wide layer whose input the engine keeps transposed: the dense projection on the f16 matrix
-            # pipe (split-f16 operands; |XT| <= 2 as above) instead of the f32 MFMA pair kernel
+            # pipe (split-f16 operands; XT_BOUND) instead of the f32 MFMA pair kernel (tune key 15 = 1: the f32 kernel over all features)
             if not xt_ready:
                 self.dev.call("mgr_transpose_bt", X, ldx, XT, self.ldt, B, T, fin)
             for d in range(2):
                 m, Wp, bp, Z = pair[4 * d:4 * d + 4]
                 ws = Ls[d].ws_sp
-                self.dev.call("mgr_lstm_input_proj_dropout_t", XT, self.ldt, 0, 0.0, Wp, bp, Z, B, T, fin, H, ws, ws.nbytes, 2.0)
+                self.dev.call("mgr_lstm_input_proj_dropout_t", XT, self.ldt, 0, 0.0, Wp, bp, Z, B, T, fin, H, ws, ws.nbytes, self.XT_BOUND)
         else:
             self.dev.call("mgr_lstm_input_proj_pair", X, ldx, *pair, B, T, fin, H)
 
@@ -669,33 +709,19 @@ class Engine:
 
     def predict(self, inputs):
         """Softmax output (B,T,C) with learning phase 0 (sequence_decoding.py:81)."""
-        self._bind()
         self._upload_inputs(inputs, None, False)
+        blk = self._begin_pass()
         self._forward(False, None)
         P = self.P.download()
-        self._check_scans()
-        return self._nan_if_nonfinite(P)
+        return self._end_pass(blk.download(), P)
 
     def forward_train_phase(self, inputs, rand=None):
         """Softmax output with learning phase 1 (dropout / noise active) - no gradient."""
-        self._bind()
         self._upload_inputs(inputs, rand, True)
+        blk = self._begin_pass()
         self._forward(True, rand)
         P = self.P.download()
-        self._check_scans()
-        return self._nan_if_nonfinite(P)
-
-    def _nan_if_nonfinite(self, out):
-        """A hidden state that went NaN / Inf is fed back as 0 by the multi-CU exchange (mgr.h, MGR_SCAN_NONFINITE): the OTHER
-        units of that sample - and everything computed from them - may look finite where the reference's whole sample would be
-        NaN.  Whoever hands out results of such a pass hands out NaN, as read_loss does."""
-        if not self.nonfinite_seen:
-            return out
-        if isinstance(out, tuple):
-            return tuple(self._nan_if_nonfinite(o) for o in out)
-        if isinstance(out, np.ndarray) and out.dtype.kind == "f":
-            return np.full_like(out, np.nan)
-        return out
+        return self._end_pass(blk.download(), P)
 
     # ------------------------------------------------------------------------------------------ pipelined inference / validation
     EV_ENC = (46, 47)     # the encoder pass into FEAT buffer 0 / 1 is complete
@@ -764,15 +790,11 @@ class Engine:
             # batch i + 1's losses in the buffer - stream 0 waits for EV_OUT[o] of batch i - 2 before it reuses slot o
             lring = bufs("lring", lambda: [self.loss_b, self.mem.empty((B,))])
 
-        spin = bufs("status", lambda: [dev.pinned((4,), np.uint32) for _ in range(2)])
+        spin = bufs("status16", lambda: [dev.pinned((16,), np.uint32) for _ in range(2)])
 
         def collect(i):
             o = i & 1
             dev.event_sync(self.EV_OUT[o])
-            # the engine's scan status travels with every result (no extra synchronisation): a pass over diverged weights hands
-            # out NaN, not plausible numbers (_nan_if_nonfinite)
-            if int(spin[o][0]) & _capi.SCAN_NONFINITE:
-                self.nonfinite_seen = True
             if output == "posteriors":
                 r = pins[o].copy()
             elif output == "argmax":
@@ -782,7 +804,9 @@ class Engine:
                 r = ([[int(v) for v in po[b, :pl[b]]] for b in range(B)], ps.copy())
             else:
                 r = pins[o].copy()
-            return self._nan_if_nonfinite(r)
+            # the status block of THIS batch's pass travels with its result (no extra synchronisation): the samples whose hidden
+            # state went NaN / Inf in it get NaN scores and no labels - not plausible numbers, and not every later batch
+            return self._end_pass(spin[o].copy(), r, what="batch %d of the pipelined run" % i)
 
         # Depth-1 projections of the NEXT batch on stream 0 (round 4).  The cycle of the pipeline is the encoder stream's chain
         # (depth-1 projections 4.4 | depth-1 scans 8.2 | depth-2 projections 11.0 | depth-2 scans 8.3 ms at config F) while stream 0
@@ -825,6 +849,8 @@ class Engine:
             f = i % len(ring)
             dev.stream(ES)
             dev.wait_event(ES, self.EV_FUSED[f])            # the fusion pass that read this FEAT buffer two batches ago
+            dev.wait_event(ES, self.EV_OUT[i & 1])          # ... and the copy of that batch's status block: this batch's pass
+            self._begin_pass(i & 1)                         # zeroes it (stream ES) and reports into it from here on
             if two_stage:
                 dev.wait_event(ES, self.EV_D1P[i & 1])
                 nl, ns = C.c_int(), C.c_int()
@@ -874,6 +900,7 @@ class Engine:
                 if output == "loss":
                     self._upload_labels(item[1], item[2], item[3])
                 self.P = pring[o]
+                self._bind(self._pass_status[o])        # (batch i + 1's encoder pass, enqueued above, bound the other block)
                 self._enqueue_fusion_head(train_phase, None, ring[f], self.rng_step + (i - started[0]))
                 dev.stream(0)
                 if output == "loss":
@@ -899,7 +926,7 @@ class Engine:
                     dev.d2h_async(pins[o][2], dlogp)
                 else:
                     dev.d2h_async(pins[o], lring[o])
-                dev.d2h_async(spin[o], self.status)
+                dev.d2h_async(spin[o], self._pass_status[o])
                 dev.record(self.EV_OUT[o])
                 dev.stream(0)
                 n = i + 1
@@ -913,7 +940,7 @@ class Engine:
                 self.rng_step += n          # (one draw of randomness per batch, as the one-batch-at-a-time calls)
             dev.stream(0)
             dev.sync()
-            self._check_scans()
+            self._bind()
 
     def _upload_labels(self, labels, input_length, label_length):
         lab = np.asarray(labels)
@@ -943,15 +970,16 @@ class Engine:
 
     def loss_on_batch(self, inputs, labels, input_length, label_length, rand=None, train_phase=True):
         """Per-sample CTC loss (validation inside fit_generator: learning phase stays 1, multimodal.py:66)."""
-        self._bind()
         self._upload_inputs(inputs, rand, train_phase)
         self._upload_labels(labels, input_length, label_length)
+        blk = self._begin_pass()
         self._forward(train_phase, rand)
         sp = self.spec
         self.dev.call("mgr_ctc_loss_grad", self.P, self.labels_d, self.ilen_d, self.llen_d, self.B, self.T,
                       sp.num_classes, self.Lmax, int(sp.ctc["skip"]), sp.num_classes - 1, float(sp.ctc["eps"]),
                       1.0, self.loss_b, 0, self.ws_ctc, self.ws_ctc.nbytes)
-        return self.loss_b.download()
+        lb = self.loss_b.download()
+        return self._end_pass(blk.download(), lb)
 
     def train_step(self, inputs, labels, input_length, label_length, rand=None, apply_update=True, next_inputs=None):
         """One optimizer step (Keras train_on_batch).  Returns the mean CTC loss of the local batch.
@@ -1115,9 +1143,16 @@ class Engine:
             dev.stream(0)
             dev.record(self.EV_IN[self._xin_slot])   # trainable first layers read the inputs again in their dW GEMMs
 
-        def finish():
+        def finish(gate=None):
+            """This step's (held-back) BPTT, its dW / dU / db GEMMs and the optimizer on stream 0.  gate: enqueues the device-side
+            wait for the residency of the next persistent launch of the context - the deepest encoder scan the caller enqueues
+            right after this returns.  It goes BEHIND the BPTT (a persistent launch itself: in front of it, "the next persistent
+            launch" would be the BPTT queued behind the gate) and in FRONT of the chip-filling GEMMs, which are what
+            must not be placed before the scan's workgroups: recurrence beside recurrence starts at once, GEMMs wait."""
             dev.stream(0)
             d = late_bptt() if late_bptt is not None else deferred
+            if gate is not None:
+                gate()
             if d is not None:
                 d()
             if apply_update:
@@ -1153,15 +1188,22 @@ class Engine:
         finish = yield
         dev.wait(0, ES)
         dev.stream(0)
-        if self.schedule.resident_wait_us > 0 and not getattr(self.comm, "host_blocking", False):
-            dev.call("mgr_stream_wait_next_resident", self.schedule.resident_wait_us)
-        finish()
+        finish(self._resident_gate())
         dev.wait_event(ES, self.EV_PREV)   # (the deepest scan overwrites the FEAT buffer the previous step's dW GEMMs read)
         for _ in phases:
             pass
         self._prefetched = nxt
         dev.stream(0)
         yield
+
+    def _resident_gate(self):
+        """The device-side wait (current stream) until the persistent launch enqueued NEXT on this context - the deepest encoder scan -
+        reports every workgroup resident, bounded by Schedule.resident_wait_us; None where it must not be used (switched off; in
+        front of a host-blocking all-reduce: HostComm holds the host inside finish(), the scan the gate waits for would only be
+        enqueued after it - the gate would always run into its bound)."""
+        if self.schedule.resident_wait_us <= 0 or getattr(self.comm, "host_blocking", False):
+            return None
+        return lambda: self.dev.call("mgr_stream_wait_next_resident", self.schedule.resident_wait_us)
 
     def _enqueue_next_encoders(self, next_inputs, finish, defer, ahead, depth, free_running=False):
         """Encoder pass of the NEXT step on stream ES into the other FEAT buffer, concurrent with what enqueue_train_step
@@ -1201,9 +1243,7 @@ class Engine:
                     # the scan launched next on this context reports every workgroup resident.
                     # (not in front of a host-blocking all-reduce: HostComm holds the host inside finish(), the scan the gate waits
                     # for would only be enqueued after it - the gate would always run into its bound)
-                    if self.schedule.resident_wait_us > 0 and not getattr(self.comm, "host_blocking", False):
-                        dev.call("mgr_stream_wait_next_resident", self.schedule.resident_wait_us)
-                    finish()
+                    finish(self._resident_gate())
                     if ahead:
                         dev.wait_event(ES, self.EV_PREV)
         self._prefetched = nxt
@@ -1239,7 +1279,7 @@ class Engine:
                     if L.ws_pg.nbytes < need:          # (+ the transposed dZ; first use only)
                         L.ws_pg = self.mem.bytes(need)
                     dev.call("mgr_lstm_param_grads_dropout_t", XinT, self.ldt, mptr, float(L.p), Hbuf.view(di * H, (1,)), ldh, L.dZ,
-                             L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes, 2.0)   # (|XinT| <= 2: _project_pair)
+                             L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes, self.XT_BOUND)
                 elif mptr:   # input dropout was applied: dW only has rows for the kept features of each (gate, sample)
                     dev.call("mgr_lstm_param_grads_dropout", Xin, ldx, mptr, float(L.p), Hbuf.view(di * H, (1,)), ldh, L.dZ,
                              L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes)

@@ -66,6 +66,18 @@ class RcclComm:
     def allreduce_sum(self, darr, n):
         _capi.check(self.dev.lib.mgr_allreduce_sum(self.comm, darr.ptr, n))
 
+    def ranks_seen(self):
+        """(ranks, own rank) as RCCL itself reports them for this communicator (ncclCommCount / ncclCommUserRank) - not what this
+        process was told by its launcher.  bench.py prints it: a multi-GPU line then proves that N ranks met inside RCCL."""
+        n, r = C.c_int(-1), C.c_int(-1)
+        _capi.check(self.dev.lib.mgr_comm_count(self.comm, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def allreduce_ms(self):
+        """(gradient all-reduces, their summed device time in ms) since the last Device.prof_reset(): profiling family
+        `allreduce` (HIP events around ncclAllReduce on the stream it is enqueued on; needs Device.prof_enable)."""
+        return self.dev.prof_get(_capi.K_ALLREDUCE)
+
     def allreduce_max_scalar(self, value):
         self._scratch.upload(np.array([value, 0, 0, 0], np.float32))
         _capi.check(self.dev.lib.mgr_allreduce_max(self.comm, self._scratch.ptr, 1))
@@ -104,6 +116,8 @@ class HostComm:
         self.port = int(port or int(os.environ.get("MASTER_PORT", "29500")) + self.PORT_OFFSET)
         self.peers = {}        # rank 0: rank -> socket
         self.sock = None       # other ranks: socket to rank 0
+        self._seen = 1         # ranks that met at rank 0 (ranks_seen)
+        self._ar_n, self._ar_s = 0, 0.0     # gradient all-reduces and their host wall time (allreduce_ms)
         if self.world == 1:
             return
         if self.rank == 0:
@@ -121,6 +135,9 @@ class HostComm:
             srv.close()
             if sorted(self.peers) != list(range(1, self.world)):
                 raise RuntimeError("HostComm: expected ranks 1..%d, got %s" % (self.world - 1, sorted(self.peers)))
+            self._seen = len(self.peers) + 1
+            for c in self.peers.values():      # every rank learns how many ranks really met at rank 0 (ranks_seen)
+                c.sendall(self._seen.to_bytes(4, "little"))
         else:
             deadline = time.time() + timeout
             while True:
@@ -134,6 +151,7 @@ class HostComm:
             c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             c.settimeout(timeout)
             c.sendall(self.rank.to_bytes(4, "little"))
+            self._seen = int.from_bytes(self._recv_exact(c, 4), "little")
             self.sock = c
 
     @staticmethod
@@ -169,8 +187,24 @@ class HostComm:
         return self._reduce_host(a.ravel(), np.add).reshape(a.shape)
 
     def allreduce_sum(self, darr, n):
+        import time
         view = darr.view(0, (int(n),))
-        view.upload(self._reduce_host(view.download(), np.add))    # both copies synchronise the engine's current stream
+        local = view.download()               # (synchronises the engine's current stream: the gradient kernels are done)
+        t0 = time.perf_counter()
+        view.upload(self._reduce_host(local, np.add))
+        self._ar_n += 1
+        self._ar_s += time.perf_counter() - t0
+
+    def ranks_seen(self):
+        """(ranks that connected at rank 0, own rank): the counterpart of RcclComm.ranks_seen for the host communicator."""
+        return self._seen, self.rank
+
+    def allreduce_ms(self, reset=False):
+        """(gradient all-reduces, their summed host wall time in ms: TCP exchange + host sum + upload) since the last reset."""
+        out = (self._ar_n, self._ar_s * 1e3)
+        if reset:
+            self._ar_n, self._ar_s = 0, 0.0
+        return out
 
     def allreduce_max_scalar(self, value):
         return float(self._reduce_host(np.array([value], np.float32), np.maximum)[0])

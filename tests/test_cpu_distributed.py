@@ -139,8 +139,9 @@ def _hostcomm_rank(rank, world, port, q):
     s2 = comm.allreduce_sum_host(a.reshape(7, 143))           # a second collective on the same connections, another shape
     mx = comm.allreduce_max_scalar(float(rank) + 0.5)
     comm.barrier()
+    seen = comm.ranks_seen()
     comm.close()
-    q.put((rank, a, s1, s2, mx))
+    q.put((rank, a, s1, s2, mx, seen))
 
 
 def test_hostcomm_sums_in_rank_order_and_every_rank_gets_the_same_bits():
@@ -156,8 +157,9 @@ def test_hostcomm_sums_in_rank_order_and_every_rank_gets_the_same_bits():
         p.start()
     got = {}
     for _ in range(world):
-        r, a, s1, s2, mx = q.get(timeout=60)
+        r, a, s1, s2, mx, seen = q.get(timeout=60)
         got[r] = (a, s1, s2, mx)
+        assert seen == (world, r)      # what bench.py prints as comm.nranks_seen: the ranks that really met at rank 0
     for p in procs:
         p.join(30)
     expect = (got[0][0] + got[1][0]) + got[2][0]                # fp32, rank order

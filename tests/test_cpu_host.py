@@ -319,6 +319,26 @@ def test_bench_launcher_terminates_the_other_ranks_when_one_fails(tmp_path, monk
         assert not os.path.exists("/proc/%d" % pid) or open("/proc/%d/stat" % pid).read().split()[2] == "Z", k
 
 
+def test_bench_launcher_hands_out_distinct_local_ranks_and_rank_r_binds_device_r():
+    """`python bench.py --gpus N` as its own launcher: N distinct RANK / LOCAL_RANK values, one rendezvous address for all; a
+    rank binds the GPU of its LOCAL_RANK (one process per GPU) - more ranks than GPUs only with the host communicator, where
+    they wrap around and `ranks_per_gpu` says so."""
+    import bench
+    for n in (1, 2, 4, 8):
+        envs = bench.rank_environments(n, 29511, base={})
+        assert [e["RANK"] for e in envs] == [str(r) for r in range(n)]
+        assert [e["LOCAL_RANK"] for e in envs] == [str(r) for r in range(n)]
+        assert {e["WORLD_SIZE"] for e in envs} == {str(n)} and {e["LOCAL_WORLD_SIZE"] for e in envs} == {str(n)}
+        assert {(e["MASTER_ADDR"], e["MASTER_PORT"]) for e in envs} == {("127.0.0.1", "29511")}
+        assert [bench.rank_device(int(e["LOCAL_RANK"]), n, n, "rccl") for e in envs] == [(r, 1) for r in range(n)]
+    assert [bench.rank_device(r, 1, 2, "host") for r in range(2)] == [(0, 2), (0, 2)]
+    assert [bench.rank_device(r, 2, 4, "host") for r in range(4)] == [(0, 2), (1, 2), (0, 2), (1, 2)]
+    with pytest.raises(SystemExit):
+        bench.rank_device(1, 1, 2, "rccl")          # RCCL refuses two ranks on one device: say so before it does
+    with pytest.raises(SystemExit):
+        bench.rank_device(0, 0, 1, "rccl")
+
+
 def test_effective_cores_honours_the_cgroup_quota_and_import_caps_blas_pools(tmp_path):
     """mgr_amd/_hostenv.py: the GPU boxes show 256 cores and grant 16 cores' worth of CPU time; a BLAS pool sized by the core
     count got the whole process frozen for tens of ms (profiles/r03_host_stalls.txt).  Importing the package (before numpy

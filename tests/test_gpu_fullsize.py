@@ -83,9 +83,8 @@ def _oracle_chunk(args):
 @pytest.mark.slow
 def test_config_F_bench_shape_every_sample_and_the_gradients_against_the_oracle(device):
     """BASELINE configs[2] at the bench line's own shape, B = 64, T = 1900, injected randomness: ALL 64 per-sample CTC losses
-    (1e-4 relative, north_star's bound) and every trainable gradient against the fp64 oracle.  The gradients are held to the error
-    model of tests/test_gpu_baseline_configs.py: within 4x the distance of the SAME oracle run in float32 (floor 1e-4), and never
-    beyond 5e-3 of the tensor's maximum.  B = 64 means 4 batch groups x 2 directions x multi-CU clusters in every scan - what the
+    (1e-4 relative, north_star's bound) and every trainable gradient against the fp64 oracle: within 1e-4 of the tensor's largest
+    entry (the kernels measure 1e-5; the distance of the SAME oracle run in float32 is printed beside it).  B = 64 means 4 batch groups x 2 directions x multi-CU clusters in every scan - what the
     B = 2 full-T case cannot show.  The oracle runs in a process pool forked from the clean fork server (8 slices of 8 samples)."""
     from mgr_amd.configs import baseline_config
     from mgr_amd.engine import Engine
@@ -123,7 +122,9 @@ def test_config_F_bench_shape_every_sample_and_the_gradients_against_the_oracle(
         r32 = sum(r[2][k] for r in res)
         eg, eg32 = rel_err(g[k], ref), rel_err(r32, ref)
         print("   grad %-20s gpu %.2e, numpy-f32 %.2e" % (k, eg, eg32))
-        assert eg < 5e-3 and eg < max(4.0 * eg32, 1e-4), (k, eg, eg32)
+        # (round 5: the bound is what the kernels achieve with a margin of ten - measured 8e-6 ... 2e-5 - not the 5e-3 of the
+        # numpy-float32 error model: a regression of the split-f16 path by one order of magnitude fails here)
+        assert eg < 1e-4, (k, eg, eg32)
 
 
 def _oracle_decode_chunk(args):

@@ -603,11 +603,28 @@ def test_input_proj_dropout_sparse_equals_dense(device, B, T, F, H, p):
         ref0 = X.astype(np.float64) @ W.astype(np.float64) + bias
         assert np.abs(tr.download() - ref0).max() <= 2e-5 * max(1.0, np.abs(ref0).max())
         assert np.abs(tr.download() - plain.download()).max() <= 2e-5 * max(1.0, np.abs(ref0).max())
-        # an input beyond the stated bound is not silently wrong: f16 overflows and Z carries Inf / NaN
+        # an input beyond the STATED bound (x_absmax > 0) is found on the device and the call falls back to the f32 MFMA kernel: the
+        # result is the f32 kernel's, bit for bit - never Inf / NaN; a bound GUARANTEED by the producer (x_absmax < 0) is not checked:
+        # there the violation overflows f16 and shows
         if p < 0.99:
+            wrong = float(np.abs(X).max()) / 1024.0
             tr.upload(np.zeros((B, T, N), f32))
-            dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, dM, p, dW, db, tr, B, T, F, H, ws, ws.nbytes, float(np.abs(X).max()) / 1024.0)
+            dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, dM, p, dW, db, tr, B, T, F, H, ws, ws.nbytes, wrong)
+            assert np.array_equal(tr.download(), sparse.download())
+            dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, 0, 0.0, dW, db, tr, B, T, F, H, ws, ws.nbytes, wrong)      # no mask
+            assert np.abs(tr.download() - ref0).max() <= 2e-5 * max(1.0, np.abs(ref0).max())
+            dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, dM, p, dW, db, tr, B, T, F, H, ws, ws.nbytes, -wrong)
             assert not np.all(np.isfinite(tr.download()))
+            # ... and a guaranteed bound that holds gives the checked call's result bit for bit (the same kernel, no gate)
+            okb = float(np.abs(X).max())
+            dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, dM, p, dW, db, tr, B, T, F, H, ws, ws.nbytes, okb)
+            a = tr.download()
+            dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, dM, p, dW, db, tr, B, T, F, H, ws, ws.nbytes, -okb)
+            assert np.array_equal(tr.download(), a)
+        # no mask and no bound (or tune key 15 = 1 - the f32 A/B switch - in an inference pass): the f32 kernel over all features
+        tr.upload(np.full((B, T, N), np.nan, f32))
+        dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, 0, 0.0, dW, db, tr, B, T, F, H, ws, ws.nbytes, 0.0)
+        assert np.abs(tr.download() - ref0).max() <= 2e-5 * max(1.0, np.abs(ref0).max())
     assert dev.lib.mgr_lstm_input_proj_dropout_wants_transposed(dev.ctx, 0.5, 1000) == 1
     assert dev.lib.mgr_lstm_input_proj_dropout_wants_transposed(dev.ctx, 0.5, 39) == 0
     assert dev.lib.mgr_lstm_input_proj_dropout_wants_transposed(dev.ctx, 0.1, 1000) == 0
@@ -675,6 +692,12 @@ def test_param_grads_dropout_sparse_equals_dense(device, B, T, F, H, p, reverse)
                     got = gW.download()
                     colscale = np.maximum(np.abs(rr).max(axis=0, keepdims=True), 1e-30)   # per column: the spread is per column
                     assert np.all(np.isfinite(got)) and (np.abs(got - rr) / colscale).max() <= 3e-5
+                # a stated bound the data violate: found on the device, the f32 MFMA kernel's result bit for bit
+                dev.call("mgr_memset", ws, 0xFF, ws.nbytes)
+                gW.upload(np.full((F, N), np.nan, f32))
+                dev.call("mgr_lstm_param_grads_dropout_t", XT, ldt, dM, 0.5, dH, H, ddZ, gW, gU, gb, B, T, F, H, reverse, ws, ws.nbytes,
+                         float(np.abs(X).max()) / 1024.0)
+                assert np.array_equal(gW.download(), outs[1][0])
 
 
 @pytest.mark.parametrize("H,B,T,path", [(300, 20, 75, 0), (500, 33, 70, 0), (100, 16, 64, 0), (128, 5, 33, 0), (300, 20, 75, 1),

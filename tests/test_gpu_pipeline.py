@@ -96,3 +96,77 @@ def test_model_predict_generator_pads_a_short_last_batch_and_decodes_on_the_devi
     assert a == b and open(tmp_path / "a.mlf", "rb").read() == open(tmp_path / "b.mlf", "rb").read()
     paths, logp = m.predict_generator(iter(data), steps=5, decode="beam", beam_width=10)
     assert len(paths) == P.shape[0] and logp.shape == (P.shape[0],)
+
+
+def test_a_nan_input_marks_its_own_sample_of_its_own_batch_and_nothing_else(device):
+    """One corrupt sequence in a decode run (a NaN in sample 3 of batch 1): the reference yields NaN for that sample only.  Here a
+    non-finite hidden state is fed back as 0 by the multi-CU exchange, so OTHER units of the sample may look finite - the engine
+    hands out NaN scores / no labels for exactly the samples the scans of THAT pass marked (status block words [8, 16), one block
+    per inference pass), not for every sample of every later batch (round 4's sticky flag), and the engine's own
+    training status is not touched by inference passes."""
+    from mgr_amd.configs import fusion_spec
+    from mgr_amd.engine import Engine
+    from mgr_amd.synthetic import synthetic_weights
+    spec = fusion_spec()
+    B, T, Lmax = 16, 72, 6
+    eng = Engine(spec, B, T, Lmax, device=device, seed=5, inference_only=True)
+    eng.set_weights(synthetic_weights(spec, 11))
+    data = [b[0] for b in _batches(spec, B, T, Lmax, 4)]
+    clean = [eng.predict(x) for x in data]
+    bad = {k: v.copy() for k, v in data[1].items()}
+    bad["the_input_audio"][3, 10, 7] = np.nan
+    feed = [data[0], bad, data[2], data[3]]
+    other = np.arange(B) != 3
+    for out in ("posteriors", "argmax", "beam"):
+        res = list(eng.predict_stream(iter(feed), output=out, beam_width=10))
+        ref = list(eng.predict_stream(iter(data), output=out, beam_width=10))
+        for i in (0, 2, 3):                                   # the batches around it: bit for bit the clean run
+            a, b = res[i], ref[i]
+            if out == "posteriors":
+                assert np.array_equal(a, b) and np.array_equal(a, clean[i])
+            elif out == "argmax":
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+            else:
+                assert a[0] == b[0] and np.array_equal(a[1], b[1])
+        a, b = res[1], ref[1]
+        if out == "posteriors":
+            assert np.all(np.isnan(a[3])) and np.array_equal(a[other], b[other])
+        elif out == "argmax":
+            assert np.all(a[0][3] == -1) and np.all(np.isnan(a[1][3]))
+            assert np.array_equal(a[0][other], b[0][other]) and np.array_equal(a[1][other], b[1][other])
+        else:
+            assert a[0][3] == [] and np.isnan(a[1][3])
+            assert [p for k, p in enumerate(a[0]) if k != 3] == [p for k, p in enumerate(b[0]) if k != 3]
+            assert np.array_equal(a[1][other], b[1][other])
+    # one batch at a time: the same marking, and the next call is clean again
+    P = eng.predict(bad)
+    assert np.all(np.isnan(P[3])) and np.array_equal(P[other], clean[1][other])
+    assert np.array_equal(eng.predict(data[2]), clean[2])
+    assert eng.scan_health() == (0, 0) and not eng.nonfinite_seen
+    eng.close()
+
+
+def test_inference_on_the_f32_mfma_kernels_equals_the_split_f16_path(device):
+    """tune keys 14 / 15 = 1 (the f32 A/B switch bench.py's second leg uses) in an INFERENCE pass: the unmasked wide projections then
+    run the f32 kernel over all features (round 4 raised there: no mask and no f16).  Both paths against each other."""
+    from mgr_amd.configs import fusion_spec
+    from mgr_amd.engine import Engine
+    from mgr_amd.synthetic import synthetic_weights
+    spec = fusion_spec()
+    B, T, Lmax = 16, 72, 6
+    eng = Engine(spec, B, T, Lmax, device=device, seed=5, inference_only=True)
+    eng.set_weights(synthetic_weights(spec, 11))
+    data = [b[0] for b in _batches(spec, B, T, Lmax, 3)]
+    split = [eng.predict(x) for x in data]
+    device.call("mgr_tune", 14, 1)
+    device.call("mgr_tune", 15, 1)
+    try:
+        f32 = [eng.predict(x) for x in data]
+        pipe = list(eng.predict_stream(iter(data), output="posteriors"))
+    finally:
+        device.call("mgr_tune", 14, 0)
+        device.call("mgr_tune", 15, 0)
+    for a, b, c in zip(split, f32, pipe):
+        assert np.array_equal(b, c)
+        assert np.abs(a - b).max() < 2e-5           # posteriors in [0, 1]
+    eng.close()

@@ -15,13 +15,13 @@ cd $R && timeout 900 python bench.py > gpurun_out/${TAG}_bench.log 2>&1
 tail -1 gpurun_out/${TAG}_bench.log > gpurun_out/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/${TAG}_prof
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -- python3 $R/bench.py --no-cpu --no-parity > $R/gpurun_out/${TAG}_prof.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -- python3 $R/bench.py --no-cpu --no-parity --no-f32-leg > $R/gpurun_out/${TAG}_prof.log 2>&1
 cp $R/gpurun_out/${TAG}_prof/*/*_kernel_stats.csv $R/gpurun_out/${TAG}_kernel_stats.csv
 cp $R/gpurun_out/${TAG}_prof/*/*_kernel_trace.csv $R/gpurun_out/${TAG}_kernel_trace.csv
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT"; do
   name=$(echo $pass | cut -d' ' -f1)
   rm -rf $R/gpurun_out/${TAG}_pmc_$name
-  timeout 400 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $R/gpurun_out/${TAG}_pmc_$name -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-parity > $R/gpurun_out/${TAG}_pmc_$name.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $R/gpurun_out/${TAG}_pmc_$name -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-parity --no-f32-leg > $R/gpurun_out/${TAG}_pmc_$name.log 2>&1
   cp $R/gpurun_out/${TAG}_pmc_$name/*/*_counter_collection.csv $R/gpurun_out/${TAG}_pmc_$name.csv
 done
 if [ "$2" != "quick" ]; then
@@ -29,7 +29,7 @@ if [ "$2" != "quick" ]; then
     cd $R && timeout 300 python bench.py --config $C --steps 10 --no-cpu > gpurun_out/${TAG}_cfg_${C}_bench.log 2>&1
     tail -1 gpurun_out/${TAG}_cfg_${C}_bench.log > gpurun_out/${TAG}_cfg_${C}_bench.json
     cd /tmp; rm -rf $R/gpurun_out/${TAG}_cfgprof
-    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_cfgprof -- python3 $R/bench.py --config $C --steps 5 --warmup 2 --no-cpu --no-parity > /dev/null 2>&1
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_cfgprof -- python3 $R/bench.py --config $C --steps 5 --warmup 2 --no-cpu --no-parity --no-f32-leg > /dev/null 2>&1
     cp $R/gpurun_out/${TAG}_cfgprof/*/*_kernel_stats.csv $R/gpurun_out/${TAG}_cfg_${C}_kernel_stats.csv
   done
   cd $R && timeout 600 python tools/decode_bench.py > gpurun_out/${TAG}_decode.json 2> gpurun_out/${TAG}_decode.err
@@ -38,7 +38,7 @@ if [ "$2" != "quick" ]; then
   cp $R/gpurun_out/${TAG}_cfgprof/*/*_kernel_stats.csv $R/gpurun_out/${TAG}_decode_kernel_stats.csv
   rm -rf $R/gpurun_out/${TAG}_cfgprof
   cd $R && timeout 600 python tools/fit_bench.py > gpurun_out/${TAG}_fit.txt 2>&1
-  cd $R && timeout 600 python bench.py --gpus 2 --comm host --no-cpu --no-parity 2> gpurun_out/${TAG}_dp2_host.err | tail -1 > gpurun_out/${TAG}_dp2_host.json
+  cd $R && timeout 600 python bench.py --gpus 2 --comm host --no-cpu --no-parity --no-f32-leg 2> gpurun_out/${TAG}_dp2_host.err | tail -1 > gpurun_out/${TAG}_dp2_host.json
 fi
 ls $R/gpurun_out | grep "^${TAG}_" | tr '\n' ' '
 cut -c1-400 $R/gpurun_out/${TAG}_bench.json
