@@ -131,6 +131,23 @@ int mgr_lstm_input_proj_dropout_t(mgr_ctx* ctx, const float* XT, int ldt, const 
                                   const float* Wp, const float* bp, float* Z, int B, int T, int F, int H, void* ws,
                                   size_t ws_bytes, float x_absmax);
 int mgr_transpose_bt(mgr_ctx* ctx, const float* X, int ldx, float* XT, int ldt, int B, int T, int F);
+/* The same projection from a PRE-SPLIT transposed copy (round 5; gemm_split.hip).  XS has the shape and strides of XT - [B][F][ldt]
+ * floats' worth of bytes - but the 4 ldt bytes of row (b, f) hold ldt f16 values hi(t) followed by ldt f16 values lo(t) with
+ * x 2^13 = hi + lo, hi = rn_f16(x 2^13), lo = rn_f16(x 2^13 - hi): the split-f16 operand pair of the f16 matrix pipe, made ONCE by
+ * whoever produces the activations instead of by every product that reads them.  Producers: the scans (mgr_scan_job.yt_split - their
+ * outputs are bounded by construction: |h| <= 1, with a residual sum <= 2) and mgr_transpose_bt_split (any row-major tensor with
+ * |x| < 7.99; a larger value overflows the f16 range and shows as Inf / NaN).  ldt % 128 == 0, zero behind T.
+ * The kernel is a loader + matrix pipeline: both operands travel HBM -> LDS by LDS-DMA through a three-stage ring (no register
+ * staging, no conversion), fragments come out of LDS with transposed reads, the waves issue nothing but those and MFMAs.
+ * mask4: entries 0 or ONE common factor c (what mgr_dropout_mask and Keras' Dropout produce: c = 1 / (1 - rate)); checked on the
+ * device - two different factors in one call make Z NaN (the factor is applied once, in the epilogue).  NULL: no dropout.
+ * drop_rate is informative only.  16 <= F <= 2048. */
+size_t mgr_lstm_input_proj_dropout_ts_ws_bytes(int B, int F, int H);
+int mgr_lstm_input_proj_dropout_ts(mgr_ctx* ctx, const float* XS, int ldt, const float* mask4, float drop_rate,
+                                   const float* Wp, const float* bp, float* Z, int B, int T, int F, int H, void* ws,
+                                   size_t ws_bytes);
+/* XS[b][f] = the split row (above) of X[b][0..T)[f], zero for t in [T, ldt); ldt % 8 == 0. */
+int mgr_transpose_bt_split(mgr_ctx* ctx, const float* X, int ldx, float* XS, int ldt, int B, int T, int F);
 /* Recurrence. reverse=1 walks t = T-1..0 and writes outputs at their original t (Bidirectional backward
  * sub-layer).  Y[b,t,0:H] with row stride ldy gets h_t (+ R[b,t,0:H] with stride ldr when R != NULL: the
  * residual add / concat fusion of multimodal.py:111,117,155).  gates [B,T,H,4] (i,f,g,o after activation) and
@@ -171,6 +188,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
  * key 8: 1 = the multi-CU BPTT keeps its 4-wave kernel instead of the split-role (4 compute + 4 gather waves) one, 2 = always split.
  * key 9: 1 = mgr_lstm_input_proj_dropout always takes the dense kernel.
  * key 10: 2 = mgr_lstm_input_proj_dropout_t with a bound on |XT| takes the dense-K split-f16 kernel with a mask as well.
+ * key 12: mgr_lstm_input_proj_dropout_ts tile: 0 = the library's choice, 1 = 128 x 64 (4 waves, two workgroups per CU), 2 = 128 x 128 (8 waves).
  * key 13: 1 = mgr_dense_softmax_fwd / mgr_dense_bwd keep their LDS-tiled vector-ALU kernels where the matrix-core forms would run.
  * key 14: K-split scan step: 0 = recurrent product on the f16 matrix pipe with every f32 operand split into an f16 (hi, lo) pair and
  *        f32 accumulation (22+ significant bits per operand; lstm_cluster.hip cluster_run_k16), 1 = v_mfma_f32_16x16x4_f32.

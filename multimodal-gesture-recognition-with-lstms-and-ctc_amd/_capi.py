@@ -49,6 +49,9 @@ SIGNATURES = {
     "mgr_lstm_input_proj_dropout_wants_transposed": (i32, [vp, C.c_float, i32]),
     "mgr_lstm_input_proj_dropout_t": (i32, [vp, vp, i32, vp, C.c_float, vp, vp, vp, i32, i32, i32, i32, vp, sz, C.c_float]),
     "mgr_transpose_bt": (i32, [vp, vp, i32, vp, i32, i32, i32, i32]),
+    "mgr_lstm_input_proj_dropout_ts_ws_bytes": (sz, [i32, i32, i32]),
+    "mgr_lstm_input_proj_dropout_ts": (i32, [vp, vp, i32, vp, C.c_float, vp, vp, vp, i32, i32, i32, i32, vp, sz]),
+    "mgr_transpose_bt_split": (i32, [vp, vp, i32, vp, i32, i32, i32, i32]),
     "mgr_lstm_input_proj_pair": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
     "mgr_lstm_scan_ws_bytes": (sz, [i32, i32, i32]),
     "mgr_lstm_scan_fwd": (i32, [vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, sz]),

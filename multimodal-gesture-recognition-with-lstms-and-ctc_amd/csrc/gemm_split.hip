@@ -1,0 +1,491 @@
+// K2 / K7 on PRE-SPLIT operands (round 5): the wide dropout-aware projection and weight-gradient products as loader + matrix
+// pipelines - the operands arrive in HBM already as f16 (hi, lo) pairs of their scaled values, travel to LDS by LDS-DMA
+// (global_load_lds_dwordx4: no register, no conversion, no ds_write) through a three-stage ring behind counted vmcnt waits, and the
+// waves of a workgroup do nothing but fragment reads (ds_read_b64_tr_b16 where the K index is the slow one) and
+// v_mfma_f32_32x32x16_f16.  gemm.hip's k_gemm_nn_sparse16 / k_gemm_tn_sparse16 did the f32 -> (hi, lo) conversion of every element
+// while staging (~70 vector instructions per stage beside 6 MFMAs: the kernels were bound by their staging, profiles/r04_scan_probes.txt).
+//
+// SPLIT ROW FORMAT ("XS"): a transposed activation copy XT[b][f][ldt] of f32 (mgr.h, mgr_scan_job.YT) keeps its shape and strides;
+// the 4 ldt bytes of row (b, f) hold ldt f16 values hi(t) followed by ldt f16 values lo(t) with  x 2^13 = hi + lo,  hi = rn_f16(x 2^13),
+// lo = rn_f16(x 2^13 - hi)  (|x| < 7.99; exact scaling, 22+ significant bits - gemm.hip, mgr_split_f16).  The scans write it
+// themselves (lstm_cluster.hip, mgr_scan_job.yt_split), mgr_transpose_bt_split makes it from a row-major tensor.
+// Arithmetic: as everywhere on the split path, A B ~ (Ahi Bhi + Alo Bhi + Ahi Blo) / (sA sB) in ONE f32 accumulator.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short tr4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short tr8 __attribute__((__vector_size__(8 * sizeof(short))));
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) tr4 lds_tr4;
+
+constexpr float XS_SCALE = 8192.f;       // 2^13: the scale of a split row
+constexpr int PS_TM = 128, PS_SK = 32;   // rows (time steps) of a tile, kept features per stage
+constexpr int PS_HP = 128;               // the weight planes are padded to whole unit tiles of the widest kernel
+
+// LDS-DMA: 64 lanes x 16 B from global [gbase + voff] (voff per lane) to LDS [lds_addr + 16 lane]; M0 carries the LDS address
+__device__ __forceinline__ void ps_dma_b128(const void* gbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(gbase), "s"(lds_addr)
+               : "memory");
+}
+// chunk swizzle of a [rows][256 B] image (16 chunks of 16 B per row): conflict-free for ds_read_b64_tr_b16 blocks of 4 rows x 16
+// columns taken pairwise by a 32-lane half (the CDNA guide's image (b), T10)
+__device__ __forceinline__ int ps_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// ---- lists of a call: per (gate, sample) the kept features, padded to whole stages of 32.  Entry = a | w << 16: a = feature whose
+// activation row the position reads, w = row of the weight planes it meets - the feature itself, or (padding) a = the first kept
+// feature, w = F, the planes' all-zero row.  cword: the ONE mask factor of the call as float bits (0: nothing kept anywhere);
+// two different non-zero factors turn it into a NaN pattern - the products cannot carry a factor per (gate, sample, feature), and
+// an input the kernel was not written for shows as NaN in Z, never as a plausible number.
+__global__ __launch_bounds__(64) void k_lists32(const float* __restrict__ mask4, int F, int Fp32, int* __restrict__ lists, int* __restrict__ kcnt,
+                                                int* __restrict__ kpos /* [4B][F] list position of a kept feature, -1 if dropped; may be null */,
+                                                unsigned* __restrict__ cword) {
+  const int gb = blockIdx.x, lane = threadIdx.x;
+  int* out = lists + (size_t)gb * Fp32;
+  int n = 0;
+  unsigned seen = 0u;
+  bool mixed = false;
+  if (mask4) {
+    const float* m = mask4 + (size_t)gb * F;
+    for (int f0 = 0; f0 < F; f0 += 64) {
+      const int f = f0 + lane;
+      const float v = f < F ? m[f] : 0.f;
+      const bool take = f < F && v != 0.f;
+      const unsigned long long bal = __ballot(take);
+      if (take) {
+        out[n + __popcll(bal & ((1ull << lane) - 1ull))] = f | (f << 16);
+        const unsigned vb = __float_as_uint(v);
+        mixed = mixed || (seen != 0u && seen != vb);
+        seen = vb;
+      }
+      if (kpos && f < F) kpos[(size_t)gb * F + f] = take ? n + __popcll(bal & ((1ull << lane) - 1ull)) : -1;
+      n += __popcll(bal);
+    }
+  } else {   // no mask: every feature kept, factor 1
+    for (int f = lane; f < F; f += 64) out[f] = f | (f << 16);
+    n = F;
+    seen = __float_as_uint(1.f);
+  }
+  // one factor per wave: lanes that kept something must agree
+  const unsigned long long have = __ballot(seen != 0u);
+  if (have) {
+    const unsigned first = __shfl(seen, __ffsll((long long)have) - 1);
+    mixed = __any(mixed || (seen != 0u && seen != first));
+    if (lane == 0) {
+      const unsigned old = atomicCAS(cword, 0u, first);
+      if (mixed || (old != 0u && old != first)) atomicExch(cword, 0x7FC00000u);
+    }
+  }
+  if (lane == 0) kcnt[gb] = n;
+  __syncthreads();   // (one wave: orders the list writes above with the read of out[0] below)
+  const int first_kept = n > 0 ? (out[0] & 0xFFFF) : 0;
+  for (int i = n + lane; i < (n + 31) / 32 * 32; i += 64) out[i] = first_kept | (F << 16);
+}
+
+// largest |W| of the packed kernel, as float bits by atomic max (the word is zeroed by the caller)
+__global__ __launch_bounds__(256) void k_wmax(const float* __restrict__ Wp, size_t n4, unsigned* __restrict__ wmax) {
+  __shared__ float part[4];
+  float m = 0.f;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 w = reinterpret_cast<const float4*>(Wp)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(w.x), fabsf(w.y))), fmaxf(fabsf(w.z), fabsf(w.w)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  // ONE atomic per workgroup, 256 workgroups: 4096 atomics on one word (one per wave of 1024 workgroups) took 49 us of a 1.3 ms call
+  if (threadIdx.x == 0) atomicMax(wmax, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
+}
+__device__ __forceinline__ float ps_wscale(const unsigned* wmax) {   // the power of two that puts the largest |W| in [2^14, 2^15)
+  const float m = __uint_as_float(*wmax);
+  int ex = 0;
+  if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &ex);
+  ex = ex < -60 ? -60 : ex;
+  return m < 3.0e38f ? ldexpf(1.f, 15 - ex) : 0.f;    // (an Inf weight: scale 0, the output is NaN - visible)
+}
+__device__ __forceinline__ void ps_split(float x, _Float16& hi, _Float16& lo) {   // (gemm.hip, mgr_split_f16)
+  asm volatile("" : "+v"(x));
+  hi = (_Float16)x;
+  lo = (_Float16)(x - (float)hi);
+}
+// weight planes WS[g][f][hi Hp | lo Hp] f16 of W sw (gate-major, Hp = H rounded up to 64, zero beyond H, row F all zero):
+// Wp[f][4u + g] is the packed kernel
+__global__ __launch_bounds__(256) void k_wplanes(const float* __restrict__ Wp, _Float16* __restrict__ WS, int F, int H, int Hp,
+                                                 const unsigned* __restrict__ wmax) {
+  const float sw = ps_wscale(wmax);
+  const size_t n = (size_t)(F + 1) * Hp;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int u = (int)(i % Hp), f = (int)(i / Hp);
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < F && u < H) w = *reinterpret_cast<const float4*>(Wp + ((size_t)f * H + u) * 4);
+    const float g4[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      _Float16 hi, lo;
+      ps_split(g4[g] * sw, hi, lo);
+      _Float16* row = WS + ((size_t)g * (F + 1) + f) * 2 * Hp;
+      row[u] = hi;
+      row[Hp + u] = lo;
+    }
+  }
+}
+
+// XS[b][f] = split row of X[b][0..T)[f] (zero for t >= T): the generic producer of the split row format
+__global__ __launch_bounds__(256) void k_transpose_split(const float* __restrict__ X, int ldx, float* __restrict__ XS, int ldt, int T, int F,
+                                                         long long xsb /* batch stride of XS in floats; 0: F * ldt */, int fill) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, t0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const float* Xb = X + (size_t)b * T * ldx;
+  float* XSb = XS + (size_t)b * (xsb ? (size_t)xsb : (size_t)F * ldt);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int t = t0 + ty + 4 * i, f = f0 + tx;
+    tile[ty + 4 * i][tx] = (t < T && f < F) ? Xb[(size_t)t * ldx + f] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int f = f0 + ty + 4 * i, t = t0 + tx;
+    if (f < F && t < fill) {
+      _Float16 hi, lo;
+      ps_split(tile[tx][ty + 4 * i] * XS_SCALE, hi, lo);
+      _Float16* row = reinterpret_cast<_Float16*>(XSb + (size_t)f * ldt);
+      row[t] = hi;
+      row[ldt + t] = lo;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ nn on pre-split operands
+// Z[b, t, 4u + g] = bias + c sum_{f kept by (g, b)} X[b, t, f] W[f, 4u + g]      (c = the mask factor of the call)
+// Tile: 128 time steps x TU = 32 WC units x 4 gates per workgroup of NW = 2 WC waves, wave (wr, wc) = 64 steps x 32 units; ONE continuous
+// sequence of stages of 32 kept features through the four gates (the accumulator set changes, the pipeline does not drain).
+//   WC = 2: 128 x 64, 4 waves, 3-stage ring of 24 KiB, two workgroups per CU
+//   WC = 4: 128 x 128, 8 waves, 4-stage ring of 32 KiB, one workgroup per CU: half the A traffic per FLOP and three stages in flight
+//           (the first version of this kernel - WC = 2 only - moved 11.8 GB from L2 / MALL into LDS per audio depth-2 call and was
+//           bound by exactly that: profiles/r05_gemm_split_probes.txt)
+// Per stage every wave issues its share of the LDS-DMA instructions (1 KiB each: two feature rows of the A image [k][hi 128 t | lo
+// 128 t]; two or four feature rows of the B image [k][hi TU u | lo TU u]) NBUF - 1 stages ahead, waits for its OWN DMAs of the
+// current stage with a counted vmcnt, meets the others at ONE barrier, and runs 24 transposed fragment reads + 12 MFMAs.  The kept-feature
+// indices of a stage are wave-uniform: scalar loads, issued one iteration before the DMAs that use them and unpacked where they are used.
+template <int WC>
+struct PsCfg {
+  static constexpr int NW = 2 * WC, TU = 32 * WC, NBUF = WC == 2 ? 3 : 4;
+  static constexpr int B_ROW = 4 * TU;                     // bytes of one B image row: hi | lo
+  static constexpr int A_BYTES = 2 * PS_SK * 256, B_BYTES = PS_SK * B_ROW, STAGE = A_BYTES + B_BYTES, LDS = NBUF * STAGE;
+  static constexpr int NI = PS_SK / NW;                    // list entries per wave and stage (its A features = its B rows)
+  static constexpr int AI = 16 / NW;                       // A instructions per wave and stage
+  static constexpr int BI = B_BYTES / 1024 / NW;           // B instructions per wave and stage
+  static constexpr int RB = 1024 / B_ROW;                  // B rows per instruction
+};
+
+template <int WC>
+__global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_proj_split(const char* __restrict__ XS, int ldt, const int* __restrict__ lists,
+                                                                          const int* __restrict__ kcnt, const unsigned* __restrict__ cword,
+                                                                          const char* __restrict__ WS, int Hp, const unsigned* __restrict__ wmax,
+                                                                          const float* __restrict__ bp, float* __restrict__ Z, int B, int T,
+                                                                          int Fp32, int F, int H) {
+  typedef PsCfg<WC> C;
+  extern __shared__ __attribute__((aligned(16))) char ps_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave / WC, wc = wave % WC;
+  const int N = 4 * H;
+  const int ncol = (H + C::TU - 1) / C::TU, nrow = (T + PS_TM - 1) / PS_TM;
+  const int x = blockIdx.x & 7, jj = blockIdx.x >> 3;   // XCD-aware tile order (gemm.hip, k_gemm_nn_sparse): the column tiles of one
+  const int rt = (jj / ncol) * 8 + x;                   // (sample, row tile) meet in one L2
+  if (rt >= nrow * B) return;
+  const int u0 = (jj % ncol) * C::TU, r0 = (rt % nrow) * PS_TM, b = rt / nrow;
+  const char* XSb = XS + (size_t)b * F * ldt * 4;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)ps_smem;
+
+  // ---- stage sequence: gate g has its own number of stages (scalars, not an array: a private array indexed by a run-time gate
+  // would live in scratch memory)
+  const int c1 = (__builtin_amdgcn_readfirstlane(kcnt[0 * B + b]) + PS_SK - 1) / PS_SK;
+  const int c2 = c1 + (__builtin_amdgcn_readfirstlane(kcnt[1 * B + b]) + PS_SK - 1) / PS_SK;
+  const int c3 = c2 + (__builtin_amdgcn_readfirstlane(kcnt[2 * B + b]) + PS_SK - 1) / PS_SK;
+  const int NT = c3 + (__builtin_amdgcn_readfirstlane(kcnt[3 * B + b]) + PS_SK - 1) / PS_SK;
+
+  // ---- loader role of this lane.  One DMA instruction moves 1 KiB of an image; the feature a lane reads is picked from wave-uniform
+  // list entries (scalar registers) by masks, never by a branch.
+  //   A: instruction id = AI wave + i carries features k = 2 id + (lane >> 5), part (lane >> 4) & 1, chunk position lane & 15
+  //   B: instruction id = BI wave + j carries rows k = RB id + lane / (64 / RB), chunk position lane % (64 / RB) of [hi | lo]
+  const int dch = lane & 15;
+  const int hsel = -(lane >> 5);                         // all ones in the upper half of the wave
+  const int drow = lane >> 4;
+  const int m1 = -(int)(drow == 1), m2 = -(int)(drow == 2), m3 = -(int)(drow == 3);
+  unsigned a_src[C::AI], b_src[C::BI];
+#pragma unroll
+  for (int i = 0; i < C::AI; ++i) {
+    const int k = 2 * (C::AI * wave + i) + (lane >> 5);
+    const int ch = dch ^ ps_swz(k);                       // the logical chunk that lands at this lane's position
+    a_src[i] = (unsigned)((drow & 1) * 2 * ldt + (r0 + 8 * ch) * 2);
+  }
+#pragma unroll
+  for (int j = 0; j < C::BI; ++j) {
+    if constexpr (WC == 2) {     // 256-byte rows [hi 64 u | lo 64 u]: the swizzle runs over the 16 chunks of the row
+      const int k = 4 * (C::BI * wave + j) + drow;
+      const int ch = dch ^ ps_swz(k);
+      b_src[j] = (unsigned)((ch >> 3) * 2 * Hp + (u0 + 8 * (ch & 7)) * 2);
+    } else {                     // 512-byte rows [hi 128 u | lo 128 u]: over the 16 chunks of each half
+      const int k = 2 * (C::BI * wave + j) + (lane >> 5);
+      const int ch = dch ^ ps_swz(k);
+      b_src[j] = (unsigned)((drow & 1) * 2 * Hp + (u0 + 8 * ch) * 2);
+    }
+  }
+  struct Idx {
+    int e[C::NI];
+  };
+  auto stage_gate = [&](int n) { return (n >= c1) + (n >= c2) + (n >= c3); };
+  auto load_idx = [&](Idx& I, int n) {     // (n clamped: a stage beyond the last re-issues the last one into a free buffer)
+    n = n < NT ? n : NT - 1;
+    const int g = stage_gate(n);
+    const int first = n >= c3 ? c3 : n >= c2 ? c2 : n >= c1 ? c1 : 0;
+    const int* lp = lists + ((size_t)g * B + b) * Fp32 + (n - first) * PS_SK + C::NI * wave;
+#pragma unroll
+    for (int r = 0; r < C::NI; ++r) I.e[r] = lp[r];   // raw: unpacked in issue(), an iteration later (no wait for the scalar load here)
+  };
+  auto issue = [&](const Idx& I, int n) {
+    const unsigned buf = lds0 + (unsigned)(n % C::NBUF) * C::STAGE;
+    const int wbase = stage_gate(n < NT ? n : NT - 1) * (F + 1);
+#pragma unroll
+    for (int i = 0; i < C::AI; ++i) {
+      const int f0 = I.e[2 * i] & 0xFFFF, f1 = I.e[2 * i + 1] & 0xFFFF;
+      const int f = f0 + ((f1 - f0) & hsel);
+      ps_dma_b128(XSb, (unsigned)f * (unsigned)(4 * ldt) + a_src[i], buf + (unsigned)((C::AI * wave + i) * 1024));
+    }
+#pragma unroll
+    for (int j = 0; j < C::BI; ++j) {
+      int wrow;
+      if constexpr (WC == 2) {
+        const int w0 = I.e[4 * j] >> 16;
+        wrow = w0 + (((I.e[4 * j + 1] >> 16) - w0) & m1) + (((I.e[4 * j + 2] >> 16) - w0) & m2) + (((I.e[4 * j + 3] >> 16) - w0) & m3);
+      } else {
+        const int w0 = I.e[2 * j] >> 16;
+        wrow = w0 + (((I.e[2 * j + 1] >> 16) - w0) & hsel);
+      }
+      ps_dma_b128(WS, (unsigned)(wbase + wrow) * (unsigned)(4 * Hp) + b_src[j], buf + (unsigned)(C::A_BYTES + (C::BI * wave + j) * 1024));
+    }
+  };
+
+  // ---- matrix role: operand lane (column = lane & 31 of its block, k half = lane >> 5); a transposed read serves 16 lanes: lane
+  // 4 q + p of the group supplies the address of row q, columns 4 p .. 4 p + 3 of a 4 x 16 block and receives its column
+  const int kh = lane >> 5, mhalf = (lane >> 4) & 1, l16 = lane & 15, q = l16 >> 2, p = l16 & 3;
+  unsigned offA[2][2], offB[2][2];   // [read j][row block / plane]: byte offsets inside one k-step (16 rows) of the image
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 8 * kh + 4 * j + q;                    // (+ 16 per k-step: the swizzle does not see it)
+    const int sw = ps_swz(row);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) offA[j][mb] = (unsigned)(512 * row + 16 * ((wr * 8 + mb * 4 + 2 * mhalf + (p >> 1)) ^ sw) + 8 * (p & 1));
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+      offB[j][pl] = WC == 2 ? (unsigned)(256 * row + 16 * ((pl * 8 + wc * 4 + 2 * mhalf + (p >> 1)) ^ sw) + 8 * (p & 1))
+                            : (unsigned)(512 * row + 256 * pl + 16 * ((wc * 4 + 2 * mhalf + (p >> 1)) ^ sw) + 8 * (p & 1));
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[g][mb][e] = 0.f;
+
+  if (NT > 0) {
+    constexpr int PD = C::NBUF - 1;   // stages in flight
+    Idx I0;
+#pragma unroll
+    for (int s0 = 0; s0 < PD; ++s0) {
+      load_idx(I0, s0);
+      issue(I0, s0);
+    }
+    load_idx(I0, PD);
+    int n = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nst = g == 0 ? c1 : g == 1 ? c2 - c1 : g == 2 ? c3 - c2 : NT - c3;
+      for (int ls = 0; ls < nst; ++ls, ++n) {
+        // this wave's DMAs of stage n have landed (stages n .. n + PD - 1 are in flight); the barrier makes that true of every wave's,
+        // and says everybody is done reading stage n - 1, whose buffer the DMAs of stage n + PD overwrite
+        if constexpr (WC == 2)
+          asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // 6 per stage x (PD - 1)
+        else
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // 4 per stage x (PD - 1)
+        __syncthreads();
+        issue(I0, n + PD);
+        load_idx(I0, n + PD + 1);
+        // Fragment reads as inline asm: hipcc does not fold the constant part of an LDS address into the instruction's offset field here
+        // (it kept 24 address registers and re-added the ring position to each: ~120 vector instructions per stage beside 12 MFMAs).
+        // The ring position is added ONCE per base register (8 adds); k-step and plane are immediates.  The waits are explicit and
+        // carry the fragments as operands, so that no MFMA can be scheduled in front of the wait that covers its operands.
+        const unsigned sb = lds0 + (unsigned)(n % C::NBUF) * C::STAGE;
+        unsigned cA[2][2], cB[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int x2 = 0; x2 < 2; ++x2) {
+            cA[j][x2] = sb + offA[j][x2];
+            cB[j][x2] = sb + C::A_BYTES + offB[j][x2];
+          }
+        tr4 fa[2][2][2][2], fb[2][2][2];   // A: [k-step][row block][plane][read], B: [k-step][plane][read]
+#define PS_TR(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr) : "memory")
+#define PS_READS(KS, AOFF0, AOFF1, BOFF)                    \
+  PS_TR(fa[KS][0][0][0], cA[0][0], AOFF0);                  \
+  PS_TR(fa[KS][0][0][1], cA[1][0], AOFF0);                  \
+  PS_TR(fb[KS][0][0], cB[0][0], BOFF);                      \
+  PS_TR(fb[KS][0][1], cB[1][0], BOFF);                      \
+  PS_TR(fa[KS][1][0][0], cA[0][1], AOFF0);                  \
+  PS_TR(fa[KS][1][0][1], cA[1][1], AOFF0);                  \
+  PS_TR(fa[KS][0][1][0], cA[0][0], AOFF1);                  \
+  PS_TR(fa[KS][0][1][1], cA[1][0], AOFF1);                  \
+  PS_TR(fa[KS][1][1][0], cA[0][1], AOFF1);                  \
+  PS_TR(fa[KS][1][1][1], cA[1][1], AOFF1);                  \
+  PS_TR(fb[KS][1][0], cB[0][1], BOFF);                      \
+  PS_TR(fb[KS][1][1], cB[1][1], BOFF);
+        PS_READS(0, 0, 256, 0)
+        if constexpr (WC == 2) {
+          PS_READS(1, 8192, 8448, 4096)
+        } else {
+          PS_READS(1, 8192, 8448, 8192)
+        }
+#undef PS_READS
+#undef PS_TR
+#define PS_WAIT(KS, CNT)                                                                                                          \
+  asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                                      \
+               : "+v"(fa[KS][0][0][0]), "+v"(fa[KS][0][0][1]), "+v"(fa[KS][0][1][0]), "+v"(fa[KS][0][1][1]), "+v"(fa[KS][1][0][0]), \
+                 "+v"(fa[KS][1][0][1]), "+v"(fa[KS][1][1][0]), "+v"(fa[KS][1][1][1]), "+v"(fb[KS][0][0]), "+v"(fb[KS][0][1]),       \
+                 "+v"(fb[KS][1][0]), "+v"(fb[KS][1][1])                                                                            \
+               :                                                                                                                   \
+               : "memory")
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          // (LDS operations return in order; a scalar load that may be outstanding beside them only makes a counted wait longer)
+          if (ks == 0)
+            PS_WAIT(0, 12);
+          else
+            PS_WAIT(1, 0);
+          auto frag = [](tr4 a, tr4 b2) {
+            const tr8 v = __builtin_shufflevector(a, b2, 0, 1, 2, 3, 4, 5, 6, 7);
+            return __builtin_bit_cast(f16x8, v);
+          };
+          const f16x8 bh = frag(fb[ks][0][0], fb[ks][0][1]), bl = frag(fb[ks][1][0], fb[ks][1][1]);
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb) {
+            const f16x8 ah = frag(fa[ks][mb][0][0], fa[ks][mb][0][1]), al = frag(fa[ks][mb][1][0], fa[ks][mb][1][1]);
+            acc[g][mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[g][mb], 0, 0, 0);
+            acc[g][mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[g][mb], 0, 0, 0);
+            acc[g][mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[g][mb], 0, 0, 0);
+          }
+        }
+#undef PS_WAIT
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the re-issued last stages: nothing of this workgroup's LDS is in flight at exit)
+  }
+  const float sw = ps_wscale(wmax);
+  const float cf = __uint_as_float(*cword);
+  const float inv = sw > 0.f ? cf / (sw * XS_SCALE) : __uint_as_float(0x7FC00000u);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int unit = u0 + wc * 32 + l31;
+  if (unit < H) {
+    const float4 bias = *reinterpret_cast<const float4*>(bp + unit * 4);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = r0 + wr * 64 + mb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        if (row < T)
+          *reinterpret_cast<float4*>(Z + ((size_t)b * T + row) * N + unit * 4) =
+              make_float4(fmaf(acc[0][mb][reg], inv, bias.x), fmaf(acc[1][mb][reg], inv, bias.y), fmaf(acc[2][mb][reg], inv, bias.z),
+                          fmaf(acc[3][mb][reg], inv, bias.w));
+      }
+  }
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static int hp_of(int H) { return (H + PS_HP - 1) / PS_HP * PS_HP; }
+static int fp32_of(int F) { return (F + PS_SK - 1) / PS_SK * PS_SK; }
+
+}  // namespace
+
+extern "C" {
+
+size_t mgr_lstm_input_proj_dropout_ts_ws_bytes(int B, int F, int H) {
+  return mgr_align_up((size_t)4 * B * fp32_of(F) * sizeof(int), 256) + mgr_align_up((size_t)4 * B * sizeof(int), 256) + 256 +
+         mgr_align_up((size_t)4 * (F + 1) * 2 * hp_of(H) * sizeof(_Float16), 256);
+}
+
+int mgr_lstm_input_proj_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const float* mask4, float drop_rate, const float* Wp,
+                                   const float* bp, float* Z, int B, int T, int F, int H, void* ws, size_t ws_bytes) {
+  MGR_REQUIRE(c && XS && Wp && bp && Z, "null argument");
+  MGR_REQUIRE(B > 0 && T > 0 && H > 0 && F >= 16 && F <= 2048, "bad shape (16 <= F <= 2048)");
+  MGR_REQUIRE(ldt % PS_TM == 0 && ldt >= T, "the split copy must be padded to whole row tiles of %d (ldt %d, T %d)", PS_TM, ldt, T);
+  MGR_REQUIRE(aligned16(XS) && aligned16(bp) && aligned16(Z) && aligned16(Wp), "XS / bp / Z / Wp must be 16-byte aligned");
+  MGR_REQUIRE((size_t)F * ldt * 4 < (1ull << 32), "sample block too large");
+  MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_input_proj_dropout_ts_ws_bytes(B, F, H), "workspace too small");
+  (void)drop_rate;
+  const int Fp32 = fp32_of(F), Hp = hp_of(H);
+  char* w = reinterpret_cast<char*>(ws);
+  int* lists = reinterpret_cast<int*>(w);
+  w += mgr_align_up((size_t)4 * B * Fp32 * sizeof(int), 256);
+  int* kcnt = reinterpret_cast<int*>(w);
+  w += mgr_align_up((size_t)4 * B * sizeof(int), 256);
+  unsigned* words = reinterpret_cast<unsigned*>(w);   // [0] largest |W|, [1] the mask factor
+  w += 256;
+  _Float16* WSp = reinterpret_cast<_Float16*>(w);
+  hipStream_t s = mgr_stream(c);
+  if (!(c->attr_done & 16u)) {
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_split<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PsCfg<2>::LDS));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_split<4>), hipFuncAttributeMaxDynamicSharedMemorySize, PsCfg<4>::LDS));
+    c->attr_done |= 16u;
+  }
+  mgr_prof_begin(c, MGR_K_GEMM_NN);
+  MGR_HIP(hipMemsetAsync(words, 0, 2 * sizeof(unsigned), s));
+  hipLaunchKernelGGL(k_lists32, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp32, lists, kcnt, (int*)nullptr, words + 1);
+  {
+    const size_t n4 = (size_t)F * H;
+    hipLaunchKernelGGL(k_wmax, dim3((int)((n4 + 255) / 256 < 256 ? (n4 + 255) / 256 : 256)), dim3(256), 0, s, Wp, n4, words);
+    const size_t n = (size_t)(F + 1) * Hp;
+    hipLaunchKernelGGL(k_wplanes, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, Wp, WSp, F, H, Hp, words);
+  }
+  // 128-unit tiles (8 waves, one workgroup per CU) where they waste little of their width; tune key 12: 1 = always 64, 2 = always 128
+  const int waste128 = (H + 127) / 128 * 128 - H, waste64 = (H + 63) / 64 * 64 - H;
+  const bool wide = c->tune[12] == 2 || (c->tune[12] == 0 && waste128 - waste64 <= H / 8);
+  const int tu = wide ? 128 : 64;
+  const int ntiles = ((H + tu - 1) / tu) * ((((T + PS_TM - 1) / PS_TM) * B + 7) / 8) * 8;
+  if (wide)
+    hipLaunchKernelGGL(k_proj_split<4>, dim3(ntiles), dim3(512), PsCfg<4>::LDS, s, reinterpret_cast<const char*>(XS), ldt, lists, kcnt, words + 1,
+                       reinterpret_cast<const char*>(WSp), Hp, words, bp, Z, B, T, Fp32, F, H);
+  else
+    hipLaunchKernelGGL(k_proj_split<2>, dim3(ntiles), dim3(256), PsCfg<2>::LDS, s, reinterpret_cast<const char*>(XS), ldt, lists, kcnt, words + 1,
+                       reinterpret_cast<const char*>(WSp), Hp, words, bp, Z, B, T, Fp32, F, H);
+  MGR_LAUNCH_CHECK();
+  mgr_prof_end(c, MGR_K_GEMM_NN);
+  return 0;
+}
+
+int mgr_transpose_bt_split(mgr_ctx* c, const float* X, int ldx, float* XS, int ldt, int B, int T, int F) {
+  MGR_REQUIRE(c && X && XS, "null argument");
+  MGR_REQUIRE(B > 0 && T > 0 && F > 0 && ldx >= F && ldt >= T && ldt % 8 == 0, "bad shape");
+  mgr_prof_begin(c, MGR_K_MISC);
+  hipLaunchKernelGGL(k_transpose_split, dim3((ldt + 63) / 64, (F + 63) / 64, B), dim3(256), 0, mgr_stream(c), X, ldx, XS, ldt, T, F, 0LL, ldt);
+  MGR_LAUNCH_CHECK();
+  mgr_prof_end(c, MGR_K_MISC);
+  return 0;
+}
+
+}  // extern "C"
+
+int mgr_transpose_bt_split_strided(mgr_ctx* c, const float* X, int ldx, float* XS, int ldt, long long xsb, int ldt_fill, int B, int T, int F) {
+  hipLaunchKernelGGL(k_transpose_split, dim3((ldt_fill + 63) / 64, (F + 63) / 64, B), dim3(256), 0, mgr_stream(c), X, ldx, XS, ldt, T, F, xsb, ldt_fill);
+  MGR_LAUNCH_CHECK();
+  return 0;
+}

@@ -9,6 +9,12 @@ i.e. the split path may be no worse than the f32 path plus the representation er
 Cases (Next 1c): heavy-tailed trained-like weights (max / median 1e4, a few at 50), cancellation-heavy dot products
 (sum ~ 0 of large terms), activations exactly at +-x_absmax, and recurrent states whose hi half has an odd last mantissa bit
 under both epoch parities (the exchange steals that bit, lstm_cluster.hip).
+
+The recurrence's own constant is 2^-20, not 2^-22, and the test says why: the h operand carries one flag bit per published word,
+which costs it up to one bit (|h s - hi - lo| <= 2^-21 |h s| instead of 2^-22; U adds 2^-22, the dropped lo lo term 2^-22).  This
+file is what measured it: round 4's form (bit 0 of BOTH halves of the even unit forced to the parity) reached 8.4e-7 = 2^-20.2
+relative on a single product here and 2^-18.8 in the worst case; since round 5 the value moves to the NEAREST f16 with the flag
+bit, and the two flag bits of a unit pair sit on different units.
 """
 import numpy as np
 import pytest
@@ -62,7 +68,7 @@ def test_projection_split_vs_f32_vs_fp64(device, kind, B, T, F, H, p):
     """mgr_lstm_input_proj_dropout_t with a bound on |X| (k_gemm_nn_sparse16; tune key 10 = 2: k_gemm_nn_dense16; no mask: the
     inference projection) against the same call without a bound (the f32 MFMA kernel) and fp64."""
     dev = device
-    rng = np.random.default_rng(hash(kind) % 1000 + F)
+    rng = np.random.default_rng(sum(map(ord, kind)) + F)
     N, bound = 4 * H, 2.0
     X, W = _proj_inputs(kind, rng, B, T, F, N, bound)
     if kind == "cancellation":
@@ -211,7 +217,7 @@ def test_recurrence_one_step_operand_fidelity(device, H, kind):
         frac = float(hi[:, steps][:, :, 0::2].mean())
         assert 0.2 < frac < 0.8, (par, frac)           # both kinds of last bit meet both parities on the parity-carrying units
     e_s, e_m = errs[0], errs[1]
-    bound = 2.0 * e_m.max() + EPS22 * absdot + 2.0 ** -23       # (+ half an ulp of a gate value in [0.5, 1]: G is stored as f32)
+    bound = 2.0 * e_m.max() + 2.0 ** -20 * absdot + 2.0 ** -23  # (+ half an ulp of a gate value in [0.5, 1]: G is stored as f32)
     worst = (e_s / bound).max()
     print("   H=%d %-14s split %.3e  f32-mfma %.3e  worst / bound %.3f" % (H, kind, e_s.max(), e_m.max(), worst))
     assert np.all(e_s <= bound), (float(e_s.max()), float(e_m.max()), float(worst))

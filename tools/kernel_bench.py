@@ -50,6 +50,22 @@ def gemm(dev, B, T, F, H, mask=True):
         print("  split f16, dense K, mask as a factor    : %7.3f ms  %6.1f TF (f32-equivalent, dense)" % (ms, fl / ms / 1e9))
         ms = timeit(dev, lambda: dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, 0, 0.0, Wp, bp, Z, B, T, F, H, wsd, wsd.nbytes, 8.0))
         print("  split f16, dense K, no mask (inference) : %7.3f ms  %6.1f TF (f32-equivalent)" % (ms, fl / ms / 1e9))
+        # pre-split rows + loader / matrix pipeline (gemm_split.hip); the bench mask has the factor 2 = 1 / (1 - 0.5)
+        XS = dev.zeros((B, F, ldt))
+        Xb = dev.array((np.clip(X.download(), -7.9, 7.9)).astype(np.float32))
+        st = timeit(dev, lambda: dev.call("mgr_transpose_bt_split", Xb, F, XS, ldt, B, T, F))
+        wss = dev.bytes(dev.lib.mgr_lstm_input_proj_dropout_ts_ws_bytes(B, F, H))
+        for tile in (1, 2):
+            dev.call("mgr_tune", 12, tile)
+            ms = timeit(dev, lambda: dev.call("mgr_lstm_input_proj_dropout_ts", XS, ldt, m, 0.5, Wp, bp, Z, B, T, F, H, wss, wss.nbytes))
+            print("  PRE-SPLIT rows, DMA ring, 128 x %3d tile : %7.3f ms  %6.1f TF executed (f32-equivalent)  (+ split transpose %.3f ms)"
+                  % (64 * tile, ms, 0.5 * fl / ms / 1e9, st))
+            ms = timeit(dev, lambda: dev.call("mgr_lstm_input_proj_dropout_ts", XS, ldt, 0, 0.0, Wp, bp, Z, B, T, F, H, wss, wss.nbytes))
+            print("  ... no mask                             : %7.3f ms  %6.1f TF (f32-equivalent)" % (ms, fl / ms / 1e9))
+        dev.call("mgr_tune", 12, 0)
+        ms = timeit(dev, lambda: dev.call("mgr_lstm_input_proj_dropout_ts", XS, ldt, 0, 0.0, Wp, bp, Z, B, T, F, H, wss, wss.nbytes))
+        print("  PRE-SPLIT rows, DMA ring, no mask       : %7.3f ms  %6.1f TF (f32-equivalent)" % (ms, fl / ms / 1e9))
+        XS.free(); Xb.free(); wss.free()
         XT.free(); wsd.free()
     dZ = Z
     gW, gU, gb = dev.empty((F, 4 * H)), dev.empty((H, 4 * H)), dev.empty((4 * H,))
