@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the second timed leg on the f32 MFMA kernels (tune 14 = 15 = 1)")
     ap.add_argument("--tune", action="append", default=[], help="KEY=VALUE for mgr_tune (A/B of kernel variants; may be repeated)")
     ap.add_argument("--no-transposed", action="store_true", help="dropout-aware projections gather columns of the row-major input")
+    ap.add_argument("--no-two-ahead", action="store_true", help="the encoder stream is handed a batch's pass one call ahead only (round 4)")
+    ap.add_argument("--no-split-rows", action="store_true", help="transposed copies as f32 rows, converted by every product (round 4's kernels)")
     ap.add_argument("--cpu-T", type=int, default=0, help="T of the CPU leg's sample; 0 (default) = the configuration's own T: the full step")
     ap.add_argument("--cpu-B", type=int, default=0, help="batch of the CPU leg's sample; 0 (default) = the configuration's own")
     ap.add_argument("--comm", choices=("rccl", "host"), default="rccl",
@@ -202,7 +204,7 @@ def main():
 
     from mgr_amd.engine import Schedule
     eng = Engine(spec, B, T, Lmax, device=dev, seed=1000 + rank, comm=comm, world=world,
-                 schedule=Schedule(transposed_inputs=not args.no_transposed))
+                 schedule=Schedule(transposed_inputs=not args.no_transposed, split_rows=not args.no_split_rows))
     eng.set_weights(synthetic_weights(spec, 20131900 + 3))
     xs, labels, il, ll = synthetic_arrays(spec, B, T, Lmax, 20131900 + 3 + 17 * rank)
     eng._upload_inputs(xs, None, True)
@@ -210,12 +212,13 @@ def main():
     dev.sync()
     dog.beat("engine")
 
-    def step(prefetch):
+    def step(prefetch, prefetch2=False):
         # frozen encoders: the encoder pass of the NEXT step runs concurrently with this step's fusion / CTC / BPTT /
         # Adam (Engine.can_pipeline).  Never across the timing boundary: the last warm-up and the last timed step do
         # not prefetch, so exactly K complete steps - K encoder passes, K fusion passes - lie inside the timed region.
         eng.enqueue_train_step(None, None, None, None, rand=None, apply_update=True, upload=False,
-                               prefetch_next=prefetch and not args.no_pipeline)
+                               prefetch_next=prefetch and not args.no_pipeline,
+                               prefetch_after_next=prefetch2 and not args.no_pipeline and not args.no_two_ahead)
         # (world > 1: the global loss arrives with the gradient all-reduce at the end of the step; the loop paces itself on the
         # rank's own loss - one read-back per step, like N = 1 - and the line reports the global loss of the last step)
         loss = eng.read_loss(local=True)
@@ -227,7 +230,7 @@ def main():
     def timed_region():
         """W untimed warm-up steps, then exactly K steps between barrier + device-sync pairs."""
         for i in range(args.warmup):
-            step(i + 1 < args.warmup)
+            step(i + 1 < args.warmup, i + 2 < args.warmup)
         dev.prof_enable((1 << len(_capi.KERNEL_FAMILIES)) - 1)
         dev.prof_reset()
         if isinstance(comm, HostComm):
@@ -238,7 +241,9 @@ def main():
         t0 = time.perf_counter()
         losses, marks = [], [t0]
         for i in range(args.steps):
-            losses.append(step(i + 1 < args.steps))
+            # (prefetch2: the step after the next one is inside the timed region as well - the encoder stream may be handed the
+            # first part of its pass a call early; nothing crosses the boundary of the region)
+            losses.append(step(i + 1 < args.steps, i + 2 < args.steps))
             marks.append(time.perf_counter())     # (the moment the host has step i's loss: diagnostic only, `value` is frames / dt)
         dev.sync()
         if comm:

@@ -175,7 +175,11 @@ typedef struct mgr_scan_job {
    * read; with ytb > H * ldt several jobs fill column ranges of one wider [B][F][ldt] copy. */
   float* YT;
   long long ytb;
-  int ldt, reserved_;
+  int ldt;
+  /* yt_split != 0: the rows of YT are written in the SPLIT ROW FORMAT of mgr_lstm_input_proj_dropout_ts - row (b, u) holds ldt f16
+   * values hi(t) followed by ldt f16 values lo(t) of y 2^13 - instead of ldt floats: what the pre-split products read without
+   * converting anything (the scan's outputs are bounded by construction: |h| <= 1, with a residual input <= 2).  ldt % 8 == 0. */
+  int yt_split;
 } mgr_scan_job;
 size_t mgr_lstm_scan_multi_ws_bytes(int njobs, const mgr_scan_job* jobs);
 int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, void* ws, size_t ws_bytes);
@@ -184,6 +188,8 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
  * workgroup, 4 same with 8 tiles per workgroup.  key 1: !=0 makes scan_fwd check the give-up word synchronously.
  * key 2: print the scan plan.  key 3: 1 = K-split scan launches keep contiguous cluster ids and write-through publishes (no
  *        XCD-local exchange).
+ * key 4: 2 = split-f16 K-split scan launches take the PAIR form (two 16-sample groups per workgroup, one workgroup per CU) whenever
+ *        they qualify; bit-identical to the default (two workgroups per CU) and slower: kept as a measured alternative.
  * key 7: one-tile-per-wave clusters: 0 = K-split step (register-direct gather), 1 = LDS-image step.
  * key 8: 1 = the multi-CU BPTT keeps its 4-wave kernel instead of the split-role (4 compute + 4 gather waves) one, 2 = always split.
  * key 9: 1 = mgr_lstm_input_proj_dropout always takes the dense kernel.
@@ -195,6 +201,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
  * key 15: 1 = the transposed-input projection / parameter-gradient GEMMs keep their f32 MFMA kernels whatever bound the caller states. */
 enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 16 };
 int mgr_tune(mgr_ctx* ctx, int key, int value);
+int mgr_tune_get(mgr_ctx* ctx, int key, int* value);   /* what a key is set to (a host of the library that lays out buffers by it) */
 /* Health of the persistent multi-CU scans launched on this context since the last mgr_scan_status_clear: *out receives the OR
  * of their status bits.  MGR_SCAN_GAVE_UP: a bounded spin expired (a dead-locked or lost peer) - the launch returned promptly
  * but its outputs are garbage; the call FAILS (mgr_last_error).  MGR_SCAN_NONFINITE: a hidden state became NaN / Inf (diverged
@@ -294,6 +301,14 @@ size_t mgr_lstm_param_grads_dropout_t_ws_bytes(int B, int T, int F, int H, int l
 int mgr_lstm_param_grads_dropout_t(mgr_ctx* ctx, const float* XT, int ldt, const float* mask4, float drop_rate,
                                    const float* Hs, int ldh, const float* dZ, float* dWp, float* dUp, float* dbp, int B,
                                    int T, int F, int H, int reverse, void* ws, size_t ws_bytes, float x_absmax);
+/* The same from a PRE-SPLIT transposed copy XS (the format of mgr_lstm_input_proj_dropout_ts, ldt % 32 == 0): dW on the f16 matrix pipe
+ * as a loader + matrix pipeline (gemm_split.hip, k_dw_split) - dZ is transposed into the workspace as split rows scaled per (sample,
+ * gate column) by that row's own largest magnitude.  mask4: entries 0 or ONE common factor (checked on the device; else dW is NaN).
+ * 16 <= F <= 2048.  dU / db as in mgr_lstm_param_grads. */
+size_t mgr_lstm_param_grads_dropout_ts_ws_bytes(int B, int T, int F, int H, int ldt);
+int mgr_lstm_param_grads_dropout_ts(mgr_ctx* ctx, const float* XS, int ldt, const float* mask4, float drop_rate,
+                                    const float* Hs, int ldh, const float* dZ, float* dWp, float* dUp, float* dbp, int B,
+                                    int T, int F, int H, int reverse, void* ws, size_t ws_bytes);
 /* dX[b,t,0:F] (stride lddx) (+)= sum_g mask4[g] (.) (dZ_g . W_g^T); accumulate=1 adds into dX. */
 int mgr_lstm_input_grad(mgr_ctx* ctx, const float* dZ, const float* Wp, const float* mask4, float* dX,
                         int lddx, int accumulate, int B, int T, int F, int H);

@@ -58,6 +58,7 @@ SIGNATURES = {
     "mgr_lstm_scan_multi_ws_bytes": (sz, [i32, vp]),
     "mgr_lstm_scan_fwd_multi": (i32, [vp, i32, vp, vp, sz]),
     "mgr_tune": (i32, [vp, i32, i32]),
+    "mgr_tune_get": (i32, [vp, i32, C.POINTER(i32)]),
     "mgr_probe_xcc": (i32, [vp, i32, i32, i32, vp]),
     "mgr_stream_delay": (i32, [vp, i32]),
     "mgr_probe_guest": (i32, [vp, i32, i32, i32, i32, vp]),
@@ -85,6 +86,8 @@ SIGNATURES = {
     "mgr_lstm_param_grads_dropout_wants_transposed": (i32, [vp, C.c_float, i32]),
     "mgr_lstm_param_grads_dropout_t_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
     "mgr_lstm_param_grads_dropout_t": (i32, [vp, vp, i32, vp, C.c_float, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, C.c_float]),
+    "mgr_lstm_param_grads_dropout_ts_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "mgr_lstm_param_grads_dropout_ts": (i32, [vp, vp, i32, vp, C.c_float, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz]),
     "mgr_lstm_input_grad": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32]),
     "mgr_dense_softmax_fwd": (i32, [vp, vp, i32, vp, C.c_float, u64, vp, vp, vp, i32, i32, i32, i32]),
     "mgr_dense_bwd_ws_bytes": (sz, [i32, i32, i32, i32]),
@@ -120,7 +123,7 @@ class ScanJob(C.Structure):
     """struct mgr_scan_job"""
     _fields_ = [("Z", vp), ("Up", vp), ("Y", vp), ("R", vp), ("gates", vp), ("cs", vp),
                 ("ldy", i32), ("ldr", i32), ("B", i32), ("T", i32), ("H", i32), ("reverse", i32),
-                ("YT", vp), ("ytb", C.c_longlong), ("ldt", i32), ("reserved_", i32)]
+                ("YT", vp), ("ytb", C.c_longlong), ("ldt", i32), ("yt_split", i32)]
 
 
 class ScanBwdJob(C.Structure):
@@ -147,7 +150,7 @@ def make_scan_jobs(jobs):
         for k in ("Z", "Up", "Y", "R", "gates", "cs", "YT"):
             v = j.get(k, 0)
             setattr(a, k, v.ptr if isinstance(v, DeviceArray) else (v or 0))
-        for k in ("ldy", "ldr", "B", "T", "H", "reverse", "ytb", "ldt"):
+        for k in ("ldy", "ldr", "B", "T", "H", "reverse", "ytb", "ldt", "yt_split"):
             setattr(a, k, int(j.get(k, 0)))
     return arr
 

@@ -1771,6 +1771,13 @@ int mgr_lstm_input_grad(mgr_ctx* c, const float* dZ, const float* Wp, const floa
 
 }  // extern "C"
 
+// dU / db of one direction (the part of the parameter gradients that does not read the layer input): for gemm_split.hip.  ws: the
+// first mgr_lstm_param_grads_ws_bytes(B, T, F, H) bytes of the caller's workspace
+int mgr_param_grads_du_db(mgr_ctx* c, const float* Hs, int ldh, const float* dZ, float* dUp, float* dbp, int B, int T, int F, int H, int reverse,
+                          void* ws) {
+  return param_grads_impl(c, nullptr, 0, nullptr, Hs, ldh, dZ, nullptr, dUp, dbp, B, T, F, H, reverse, ws, false);
+}
+
 int mgr_transpose_bt_strided(mgr_ctx* c, const float* X, int ldx, float* XT, int ldt, long long xtb, int ldt_fill, int B, int T, int F) {
   hipLaunchKernelGGL(k_transpose_bt, dim3((ldt_fill + 63) / 64, (F + 63) / 64, B), dim3(256), 0, mgr_stream(c), X, ldx, XT, ldt, T, F, xtb, ldt_fill, (unsigned*)nullptr);
   MGR_LAUNCH_CHECK();

@@ -410,6 +410,239 @@ __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_proj_split(const 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ tn on pre-split operands
+// Dropout-aware dW: P[(g, b)][q][u] = c sum_t X[b, t, f_q] dZ[b, t, 4u + g] for the kept features f_q of (gate, sample) - K is TIME, so
+// both operands are read along their rows: A = rows of the split activation copy XS (gathered by the kept list: fixed for the whole K
+// loop, the per-lane source offsets are computed once), B = rows of dZS, the split transposed gate gradients.  dZS[b][4u + g] is a split
+// row of dZ sz(row) with sz the power of two that puts the ROW's largest |dZ| in [2^14, 2^15) (k_rowmax_bt finds it, k_transpose_split
+// applies it): a row's scale leaves the sum over time exactly and is divided out of its output column, so the gradient's dynamic range
+// across units, samples and gates costs nothing (gemm.hip, k_gemm_tn_sparse16).
+// Tile 128 kept features x 128 units, stages of 32 time steps: per operand and part a [128 rows][64 B] image, 16-byte chunk c of row r at
+// position c ^ ((r >> 2) & 3) (ds_read_b128 of 32 consecutive rows at one chunk: conflict-free); 32 KiB per stage.
+constexpr int DW_BM = 128, DW_BN = 128, DW_TK = 32, DW_STAGE = 4 * 128 * 64;
+
+// zmax[b][col] = largest |dZ[b, t, col]| over t, as float bits
+__global__ __launch_bounds__(256) void k_rowmax_bt(const float* __restrict__ dZ, int N, int T, unsigned* __restrict__ zmax) {
+  __shared__ float part[4][64];
+  const int b = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  float m = 0.f;
+  if (col < N) {
+    const float* p = dZ + (size_t)b * T * N + col;
+    for (int t = w; t < T; t += 4) m = fmaxf(m, fabsf(p[(size_t)t * N]));
+  }
+  part[w][threadIdx.x & 63] = m;
+  __syncthreads();
+  if (w == 0 && col < N) zmax[(size_t)b * N + col] = __float_as_uint(fmaxf(fmaxf(part[0][threadIdx.x], part[1][threadIdx.x]), fmaxf(part[2][threadIdx.x], part[3][threadIdx.x])));
+}
+__device__ __forceinline__ float dw_zscale(unsigned zm_bits) {   // the power of two that puts the row's largest |dZ| in [2^14, 2^15)
+  const float zm = __uint_as_float(zm_bits);
+  int ex = 0;
+  if (zm > 0.f && zm < 3.0e38f) (void)frexpf(zm, &ex);
+  ex = ex < -100 ? -100 : ex;
+  return zm < 3.0e38f ? ldexpf(1.f, 15 - ex) : __uint_as_float(0x7FC00000u);   // (an Inf / NaN gradient stays visible)
+}
+// dZS[b][col] = split row of dZ[b][0..T)[col] * sz(b, col), zero for t >= T
+__global__ __launch_bounds__(256) void k_transpose_split_scaled(const float* __restrict__ dZ, int N, float* __restrict__ dZS, int ldt, int T,
+                                                                const unsigned* __restrict__ zmax) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const float* Zb = dZ + (size_t)b * T * N;
+  float* Sb = dZS + (size_t)b * N * ldt;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int t = t0 + ty + 4 * i, cc = c0 + tx;
+    tile[ty + 4 * i][tx] = (t < T && cc < N) ? Zb[(size_t)t * N + cc] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int cc = c0 + ty + 4 * i, t = t0 + tx;
+    if (cc < N && t < ldt) {
+      const float sz = dw_zscale(zmax[(size_t)b * N + cc]);
+      _Float16 hi, lo;
+      ps_split(tile[tx][ty + 4 * i] * sz, hi, lo);
+      _Float16* row = reinterpret_cast<_Float16*>(Sb + (size_t)cc * ldt);
+      row[t] = hi;
+      row[ldt + t] = lo;
+    }
+  }
+}
+
+typedef float dw_f4 __attribute__((ext_vector_type(4)));
+
+// NW = 8 waves (wave = 32 features x 64 units), four-stage ring (128 KiB: a CU of its own), or NW = 4 waves (wave = 64 x 64), three-stage
+// ring (96 KiB, < 160 registers: fits on a CU beside ONE workgroup of a persistent scan - in the training step this kernel runs while
+// the next batch's encoder scans hold the chip, where the 8-wave form cannot be placed at all until they end)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 1) void k_dw_split(const char* __restrict__ XS, int ldt, const int* __restrict__ lists,
+                                                         const int* __restrict__ kcnt, const unsigned* __restrict__ cword,
+                                                         const char* __restrict__ dZS, const unsigned* __restrict__ zmax, float* __restrict__ P,
+                                                         int B, int T, int Fp32, int F, int H) {
+  constexpr int MB = 8 / NW;                  // 32-row blocks of A per wave
+  constexpr int NBUF = NW == 8 ? 4 : 3;
+  constexpr int DPW = 16 / NW;                // DMA instructions per wave, stage and operand
+  extern __shared__ __attribute__((aligned(16))) char dw_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 1, wc = wave & 1;
+  const int N = 4 * H;
+  // XCD-aware decode (gemm.hip, k_gemm_tn_sparse): all workgroups of a sample - which share its X rows and dZ rows - in one L2
+  const int nft = (Fp32 + DW_BM - 1) / DW_BM, nut = (H + DW_BN - 1) / DW_BN, wps = 4 * nft * nut;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int b = (jj / wps) * 8 + xcd;
+  if (b >= B) return;
+  const int w_ = jj % wps, g = w_ / (nft * nut), gb = g * B + b;
+  const int q0 = ((w_ / nut) % nft) * DW_BM, u0 = (w_ % nut) * DW_BN;
+  const int cnt = kcnt[gb];
+  if (q0 >= cnt) return;   // (uniform) no kept feature in this row tile
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)dw_smem;
+  const char* XSb = XS + (size_t)b * F * ldt * 4;
+  const char* ZSb = dZS + (size_t)b * N * ldt * 4;
+
+  // ---- loader role: instruction id = DPW wave + i of each operand: part = id >> 3, rows 16 (id & 7) + (lane >> 2), chunk position
+  // lane & 3.  The rows of a tile do not change over the K loop: the per-lane source offsets are computed once.
+  unsigned a_off[DPW], b_off[DPW];
+#pragma unroll
+  for (int i = 0; i < DPW; ++i) {
+    const int id = DPW * wave + i, part = id >> 3, r = 16 * (id & 7) + (lane >> 2);
+    const int ch = (lane & 3) ^ ((r >> 2) & 3);            // the logical chunk that lands at this lane's position
+    int q = q0 + r;
+    q = q < cnt ? q : cnt - 1;                             // (rows beyond the list are computed from a valid row and never stored)
+    const int f = lists[(size_t)gb * Fp32 + q] & 0xFFFF;
+    a_off[i] = (unsigned)f * (unsigned)(4 * ldt) + (unsigned)(part * 2 * ldt + ch * 16);
+    int u = u0 + r;
+    u = u < H ? u : H - 1;
+    b_off[i] = (unsigned)(4 * u + g) * (unsigned)(4 * ldt) + (unsigned)(part * 2 * ldt + ch * 16);
+  }
+  const int nst = (T + DW_TK - 1) / DW_TK;     // (the padded rows are zero behind T; ldt >= nst * 32)
+  auto issue = [&](int n) {                    // (a stage beyond the last re-reads the last one into a free buffer)
+    const unsigned buf = lds0 + (unsigned)(n % NBUF) * DW_STAGE;
+    const int nn = (n < nst ? n : nst - 1) * DW_TK * 2;   // byte offset of the stage's first time step in a part
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+      ps_dma_b128(XSb + nn, a_off[i], buf + (unsigned)((DPW * wave + i) * 1024));
+      ps_dma_b128(ZSb + nn, b_off[i], buf + (unsigned)(16384 + (DPW * wave + i) * 1024));
+    }
+  };
+  // ---- matrix role
+  const int l31 = lane & 31, kh = lane >> 5;
+  unsigned oA[MB][2], oB[2][2];   // [row block][k-step] / [column block][k-step]: byte offsets of this lane's 16-byte operand in the hi image
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = 32 * MB * wr + 32 * mb + l31;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) oA[mb][ks] = (unsigned)(m * 64 + 16 * ((2 * ks + kh) ^ ((m >> 2) & 3)));
+  }
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int nn = 64 * wc + 32 * nb + l31;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) oB[nb][ks] = (unsigned)(16384 + nn * 64 + 16 * ((2 * ks + kh) ^ ((nn >> 2) & 3)));
+  }
+  f32x16 acc[MB][2];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mb][nb][e] = 0.f;
+  constexpr int PD = NBUF - 1;
+#pragma unroll
+  for (int s0 = 0; s0 < PD; ++s0) issue(s0);
+  for (int n = 0; n < nst; ++n) {
+    // 2 DPW DMAs per stage and wave, PD - 1 stages may stay in flight: this wave's DMAs of stage n have landed
+    if constexpr (NW == 8)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // (4 waves: 8 per stage x 1)
+    __syncthreads();
+    issue(n + PD);
+    const unsigned sb = lds0 + (unsigned)(n % NBUF) * DW_STAGE;
+    dw_f4 fa[2][MB][2], fb[2][2][2];   // [k-step][block][part]
+#define DW_RD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr) : "memory")
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {     // the reads of both k-steps first: the second set lands under the first set's MFMAs
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const unsigned ca = sb + oA[mb][ks];
+        DW_RD(fa[ks][mb][0], ca, 0);
+        DW_RD(fa[ks][mb][1], ca, 8192);
+      }
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const unsigned cb = sb + oB[nb][ks];
+        DW_RD(fb[ks][nb][0], cb, 0);
+        DW_RD(fb[ks][nb][1], cb, 8192);
+      }
+    }
+#undef DW_RD
+    // (explicit waits with the fragments as operands: no MFMA can be scheduled in front of the wait that covers its operands;
+    // LDS operations return in order: 2 MB + 4 reads of the second k-step may stay in flight at the first wait)
+#define DW_WAIT(KS, CNT)                                                                                                              \
+  asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                                          \
+               : "+v"(fa[KS][0][0]), "+v"(fa[KS][0][1]), "+v"(fa[KS][MB - 1][0]), "+v"(fa[KS][MB - 1][1]), "+v"(fb[KS][0][0]), "+v"(fb[KS][0][1]), \
+                 "+v"(fb[KS][1][0]), "+v"(fb[KS][1][1])                                                                                \
+               :                                                                                                                       \
+               : "memory")
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks == 0) {
+        if constexpr (MB == 1)
+          DW_WAIT(0, 6);
+        else
+          DW_WAIT(0, 8);
+      } else {
+        DW_WAIT(1, 0);
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const f16x8 ah = __builtin_bit_cast(f16x8, fa[ks][mb][0]), al = __builtin_bit_cast(f16x8, fa[ks][mb][1]);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const f16x8 bh = __builtin_bit_cast(f16x8, fb[ks][nb][0]), bl = __builtin_bit_cast(f16x8, fb[ks][nb][1]);
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[mb][nb], 0, 0, 0);
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[mb][nb], 0, 0, 0);
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[mb][nb], 0, 0, 0);
+        }
+      }
+    }
+#undef DW_WAIT
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const float cf = __uint_as_float(*cword) * (1.f / XS_SCALE);
+  float* out = P + (size_t)gb * Fp32 * H;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int u = u0 + 64 * wc + 32 * nb + l31;
+    // (the reciprocals apart from each other: sz reaches 2^115 for a row of tiny gradients; all powers of two, the products are exact)
+    const float cz = u < H ? 1.f / dw_zscale(zmax[(size_t)b * N + 4 * u + g]) : 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = 32 * MB * wr + 32 * mb + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+        if (q0 + r < cnt && u < H) out[(size_t)(q0 + r) * H + u] = acc[mb][nb][reg] * cf * cz;
+      }
+  }
+}
+
+// dWp[f][4u+g] = sum over the samples that kept feature f for gate g, in sample order
+__global__ __launch_bounds__(256) void k_dw_gather32(const float* __restrict__ P, const int* __restrict__ kpos, float* __restrict__ dWp, int B, int F,
+                                                     int Fp32, int H) {
+  const size_t n = (size_t)4 * F * H;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int u = (int)(i % H);
+    const int f = (int)((i / H) % F);
+    const int g = (int)(i / ((size_t)H * F));
+    float sacc = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const int pos = kpos[((size_t)g * B + b) * F + f];
+      if (pos >= 0) sacc += P[(((size_t)g * B + b) * Fp32 + pos) * H + u];
+    }
+    dWp[(size_t)f * 4 * H + 4 * u + g] = sacc;
+  }
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static int hp_of(int H) { return (H + PS_HP - 1) / PS_HP * PS_HP; }
 static int fp32_of(int F) { return (F + PS_SK - 1) / PS_SK * PS_SK; }
@@ -469,6 +702,71 @@ int mgr_lstm_input_proj_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const f
                        reinterpret_cast<const char*>(WSp), Hp, words, bp, Z, B, T, Fp32, F, H);
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_GEMM_NN);
+  return 0;
+}
+
+static size_t dw_ts_extra(int B, int F, int H, int ldt) {
+  const size_t Fp32 = (size_t)fp32_of(F);
+  return mgr_align_up((size_t)4 * B * Fp32 * sizeof(int), 256) + mgr_align_up((size_t)4 * B * sizeof(int), 256) + 256 +
+         mgr_align_up((size_t)4 * B * F * sizeof(int), 256) + mgr_align_up((size_t)4 * B * Fp32 * H * sizeof(float), 256) +
+         mgr_align_up((size_t)B * 4 * H * ldt * sizeof(float), 256) + mgr_align_up((size_t)B * 4 * H * sizeof(unsigned), 256);
+}
+
+size_t mgr_lstm_param_grads_dropout_ts_ws_bytes(int B, int T, int F, int H, int ldt) {
+  return mgr_lstm_param_grads_ws_bytes(B, T, F, H) + dw_ts_extra(B, F, H, ldt);
+}
+
+int mgr_lstm_param_grads_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const float* mask4, float drop_rate, const float* Hs, int ldh,
+                                    const float* dZ, float* dWp, float* dUp, float* dbp, int B, int T, int F, int H, int reverse,
+                                    void* ws, size_t ws_bytes) {
+  MGR_REQUIRE(c && XS && mask4 && Hs && dZ && dWp && dUp && dbp, "null argument");
+  MGR_REQUIRE(B > 0 && T > 0 && H > 0 && F >= 16 && F <= 2048 && ldh >= H, "bad shape (16 <= F <= 2048)");
+  MGR_REQUIRE(ldt % 32 == 0 && ldt >= (T + DW_TK - 1) / DW_TK * DW_TK, "the split copy must be padded to whole stages of %d time steps (ldt %d, T %d)", DW_TK, ldt, T);
+  MGR_REQUIRE(aligned16(dZ) && aligned16(XS), "dZ / XS must be 16-byte aligned");
+  MGR_REQUIRE((size_t)F * ldt * 4 < (1ull << 32) && (size_t)4 * H * ldt * 4 < (1ull << 32), "sample block too large");
+  MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_param_grads_dropout_ts_ws_bytes(B, T, F, H, ldt), "workspace too small");
+  (void)drop_rate;
+  mgr_prof_begin(c, MGR_K_GEMM_TN);
+  // dU / db first: they are short, and in the training step the long dW kernel then ends this direction's work (gemm.hip)
+  int r = mgr_param_grads_du_db(c, Hs, ldh, dZ, dUp, dbp, B, T, F, H, reverse, ws);
+  if (r) return r;
+  const int Fp32 = fp32_of(F), N = 4 * H;
+  char* w = reinterpret_cast<char*>(ws) + mgr_lstm_param_grads_ws_bytes(B, T, F, H);
+  int* lists = reinterpret_cast<int*>(w);
+  w += mgr_align_up((size_t)4 * B * Fp32 * sizeof(int), 256);
+  int* kcnt = reinterpret_cast<int*>(w);
+  w += mgr_align_up((size_t)4 * B * sizeof(int), 256);
+  unsigned* words = reinterpret_cast<unsigned*>(w);   // [1] the mask factor
+  w += 256;
+  int* kpos = reinterpret_cast<int*>(w);
+  w += mgr_align_up((size_t)4 * B * F * sizeof(int), 256);
+  float* P = reinterpret_cast<float*>(w);
+  w += mgr_align_up((size_t)4 * B * Fp32 * H * sizeof(float), 256);
+  float* dZS = reinterpret_cast<float*>(w);
+  w += mgr_align_up((size_t)B * N * ldt * sizeof(float), 256);
+  unsigned* zmax = reinterpret_cast<unsigned*>(w);
+  hipStream_t s = mgr_stream(c);
+  if (!(c->attr_done & 32u)) {
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dw_split<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * DW_STAGE));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dw_split<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * DW_STAGE));
+    c->attr_done |= 32u;
+  }
+  MGR_HIP(hipMemsetAsync(words, 0, 2 * sizeof(unsigned), s));
+  hipLaunchKernelGGL(k_lists32, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp32, lists, kcnt, kpos, words + 1);
+  hipLaunchKernelGGL(k_rowmax_bt, dim3((N + 63) / 64, B), dim3(256), 0, s, dZ, N, T, zmax);
+  hipLaunchKernelGGL(k_transpose_split_scaled, dim3((ldt + 63) / 64, (N + 63) / 64, B), dim3(256), 0, s, dZ, N, dZS, ldt, T, zmax);
+  const int grid = 8 * ((B + 7) / 8) * 4 * ((Fp32 + DW_BM - 1) / DW_BM) * ((H + DW_BN - 1) / DW_BN);
+  // tune key 12 (the tile switch of the projection): 1 = the 4-wave form, which fits on a CU beside a workgroup of a persistent scan
+  if (c->tune[12] == 1)
+    hipLaunchKernelGGL(k_dw_split<4>, dim3(grid), dim3(256), 3 * DW_STAGE, s, reinterpret_cast<const char*>(XS), ldt, lists, kcnt, words + 1,
+                       reinterpret_cast<const char*>(dZS), zmax, P, B, T, Fp32, F, H);
+  else
+    hipLaunchKernelGGL(k_dw_split<8>, dim3(grid), dim3(512), 4 * DW_STAGE, s, reinterpret_cast<const char*>(XS), ldt, lists, kcnt, words + 1,
+                       reinterpret_cast<const char*>(dZS), zmax, P, B, T, Fp32, F, H);
+  const size_t n = (size_t)4 * F * H;
+  hipLaunchKernelGGL(k_dw_gather32, dim3((int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, P, kpos, dWp, B, F, Fp32, H);
+  MGR_LAUNCH_CHECK();
+  mgr_prof_end(c, MGR_K_GEMM_TN);
   return 0;
 }
 

@@ -183,6 +183,12 @@ int mgr_tune(mgr_ctx* c, int key, int value) {
   return 0;
 }
 
+int mgr_tune_get(mgr_ctx* c, int key, int* value) {
+  MGR_REQUIRE(c && value && key >= 0 && key < MGR_TUNE_COUNT, "bad tune key");
+  *value = c->tune[key];
+  return 0;
+}
+
 static size_t bwd_job_ws(const mgr_scan_bwd_job& j) {
   int nbg = (j.B + 15) / 16;
   size_t cluster = mgr_align_up((size_t)nbg * 2 * mgr_cluster_bwd_img_floats(j.H) * sizeof(float), 256);
@@ -225,6 +231,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     MGR_REQUIRE(aligned16(j.Z) && aligned16(j.Up) && (!j.gates || aligned16(j.gates)), "job %d: Z/Up/gates must be 16-byte aligned", i);
     MGR_REQUIRE(!j.YT || (aligned16(j.YT) && j.ldt % 4 == 0 && j.ldt >= (j.T + 31) / 32 * 32 && j.ytb % 4 == 0 && j.ytb >= (long long)j.H * j.ldt),
                 "job %d: transposed output needs a 16-byte aligned YT, ldt %% 4 == 0, ldt >= T rounded up to 32, ytb >= H * ldt", i);
+    MGR_REQUIRE(!j.YT || !j.yt_split || j.ldt % 8 == 0, "job %d: split rows need ldt %% 8 == 0", i);
   }
   int r = mgr_prof_begin(c, MGR_K_SCAN_FWD);
   if (r) return r;
@@ -255,9 +262,31 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
       const size_t zb = (size_t)j.B * j.T * 4 * j.H * sizeof(float), rb = j.R ? (size_t)j.B * j.T * j.ldr * sizeof(float) : 0;
       ks_ok = zb < ((size_t)1 << 32) && rb < ((size_t)1 << 32);
     }
+    // Pair form of the split-f16 K-split step (lstm_cluster.hip, cluster_run_k16p): two 16-sample groups per workgroup, ONE workgroup
+    // per CU (config F's encoder depths: 204 workgroups instead of 408).  Bit-identical, tested - and NOT the default: measured 3.5 us
+    // per pair of steps against 2.2 for the two-workgroups-per-CU launch (one wave runs both groups' instruction streams one after the
+    // other; two waves per SIMD interleave them), 30.9 against 21.5 ms per training step (profiles/r05_scan_probes.txt).
+    // tune key 4: 2 = take it whenever the launch qualifies.
+    int nbg16[MGR_MAX_SCAN_JOBS];
+    for (int i = 0; i < njobs; ++i) nbg16[i] = P.cluster[i] ? P.nbg[i] : 0;
+    bool pair = ks_ok && P.exchange && c->tune[14] == 0 && c->tune[4] == 2;
+    {
+      int unpaired = 0, most = 0;
+      for (int i = 0; i < njobs && pair; ++i) {
+        if (!P.cluster[i]) continue;
+        pair = P.cfg[i].nw == 4 && P.cfg[i].tpw == 1 && P.G[i] > 1 && mgr_cluster_ks_supported(jobs[i].H / 4);
+        unpaired += P.G[i] * P.nbg[i];
+        most = P.nbg[i] > most ? P.nbg[i] : most;
+      }
+      pair = pair && most >= 2;
+      (void)unpaired;
+      if (pair)
+        for (int i = 0; i < njobs; ++i)
+          if (P.cluster[i]) P.nbg[i] = (P.nbg[i] + 1) / 2;     // clusters of the job from here on
+    }
     bool xcd = c->tune[3] == 0 && ks_ok && P.exchange;
     {
-      int tot = 0;
+      int tot = 0, live_x = 0;
       for (int i = 0; i < njobs && xcd; ++i) {
         if (!P.cluster[i]) continue;
         xcd = P.cfg[i].nw == 4 && P.cfg[i].tpw == 1 && P.G[i] > 1 && mgr_cluster_ks_supported(jobs[i].H / 4);
@@ -275,11 +304,17 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
           for (int k = i; k < njobs; ++k)
             if (P.cluster[k] && jobs[k].H == jobs[i].H) clusters += P.nbg[k];
           tot += P.G[i] * ((clusters + 7) / 8 * 8);
+          live_x += P.G[i] * clusters;
         }
-        xcd = tot <= 2 * c->cu_count && (size_t)tot * sizeof(unsigned) <= kScanHdrBytes - 256;
+        xcd = live_x <= (pair ? 1 : 2) * c->cu_count && tot <= 2 * c->cu_count && (size_t)tot * sizeof(unsigned) <= kScanHdrBytes - 256;
       }
     }
     int cb[MGR_MAX_SCAN_JOBS], cn[MGR_MAX_SCAN_JOBS], c0[MGR_MAX_SCAN_JOBS], cr[MGR_MAX_SCAN_JOBS];
+    // workgroups that really run (a class laid out in octets of clusters has empty ids when its cluster count is no multiple of 8:
+    // those workgroups count themselves in and return): what co-residency and the admission ledger are about
+    int live = 0;
+    for (int i = 0; i < njobs; ++i)
+      if (P.cluster[i]) live += P.G[i] * P.nbg[i];
     P.total = layout_classes(
         njobs, P.cluster,
         [&](int a, int b) { return jobs[a].H == jobs[b].H && P.cfg[a].nw == P.cfg[b].nw && P.cfg[a].tpw == P.cfg[b].tpw; },
@@ -294,11 +329,13 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
       cj.Z = j.Z; cj.Up = j.Up; cj.Y = j.Y; cj.R = j.R; cj.G = j.gates; cj.Cs = j.cs;
       cj.ldy = j.ldy; cj.ldr = j.ldr; cj.B = j.B; cj.T = j.T; cj.H = j.H; cj.reverse = j.reverse;
       cj.ks = ks; cj.tpw = P.cfg[i].tpw; cj.nw = P.cfg[i].nw;
-      cj.G_ = P.G[i]; cj.nbg = P.nbg[i];
+      cj.G_ = P.G[i]; cj.nbg = P.nbg[i]; cj.nbg16 = nbg16[i];
       cj.cls_begin = cb[i]; cj.cls_nclusters = cn[i]; cj.cls_cluster0 = c0[i]; cj.cls_rot = cr[i];
       cj.xbuf = reinterpret_cast<float*>(w);
-      w += mgr_align_up((size_t)P.nbg[i] * 2 * img * sizeof(float), 256);
+      w += mgr_align_up((size_t)nbg16[i] * 2 * img * sizeof(float), 256);
     }
+    L.pair = pair ? 1 : 0;
+    L.live_wgs = live;
     // tune key 7: 0 = K-split step for one-tile-per-wave clusters, 1 = LDS-image step for every cluster
     L.ksplit = ks_ok ? 1 : 0;
     L.split16 = c->tune[14] == 0;   // tune key 14: 1 = f32 MFMA in the K-split step
@@ -308,7 +345,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
       for (int i = 0; i < njobs; ++i) {
         if (!P.cluster[i]) continue;
         ClusterJob& cj = L.job[k++];
-        cj.YT = jobs[i].YT; cj.ytb = jobs[i].ytb; cj.ldt = jobs[i].ldt;
+        cj.YT = jobs[i].YT; cj.ytb = jobs[i].ytb; cj.ldt = jobs[i].ldt; cj.yt_split = jobs[i].yt_split;
         yt_done[i] = jobs[i].YT != nullptr;
       }
     }
@@ -326,7 +363,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     L.cm.total_wgs = P.total;
     // (a launch without an exchange spins on nobody: it needs no place in the ledger and is never ordered behind one)
     if (P.exchange) {
-      r = mgr_persist_admit(c, P.total, waves, per_cu, &L.cm.seq);
+      r = mgr_persist_admit(c, live, waves, per_cu, &L.cm.seq);
       if (r) return r;
     }
     // exchange slots + status must be zero at every launch (epochs count from 1 within the call)
@@ -334,7 +371,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     r = mgr_cluster_launch(c, L, P.total, P.exchange);
     if (r) return r;
     if (P.exchange) {
-      r = mgr_persist_commit(c, P.total, waves, per_cu);
+      r = mgr_persist_commit(c, live, waves, per_cu);
       if (r) return r;
     }
   }
@@ -347,7 +384,8 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
   for (int i = 0; i < njobs; ++i) {   // transposed outputs the scan kernel did not write itself
     const mgr_scan_job& j = jobs[i];
     if (!j.YT || yt_done[i]) continue;
-    r = mgr_transpose_bt_strided(c, j.Y, j.ldy, j.YT, j.ldt, j.ytb, j.ldt, j.B, j.T, j.H);
+    r = j.yt_split ? mgr_transpose_bt_split_strided(c, j.Y, j.ldy, j.YT, j.ldt, j.ytb, j.ldt, j.B, j.T, j.H)
+                   : mgr_transpose_bt_strided(c, j.Y, j.ldy, j.YT, j.ldt, j.ytb, j.ldt, j.B, j.T, j.H);
     if (r) return r;
   }
   r = mgr_prof_end(c, MGR_K_SCAN_FWD);

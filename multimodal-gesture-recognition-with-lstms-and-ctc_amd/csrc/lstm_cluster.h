@@ -40,10 +40,12 @@ struct ClusterJob {
   float* YT;        // optional transposed output: YT[b * ytb + unit * ldt + t] = what Y[b, t, unit] gets (K-split kernel; else null)
   long long ytb;    // ... its batch stride in floats
   int ldt;          // ... its row length (T padded; entries t in [T, ldt) are written as zero)
+  int yt_split;     // ... rows in the split row format (mgr.h): ldt f16 hi values, then ldt f16 lo values of y 2^13
   int ldy, ldr, B, T, H, reverse;
   int ks, tpw, nw;  // k-steps (H/4), tiles per wave, active waves per workgroup
   int G_;           // workgroups per cluster (one cluster = one 16-sample batch group)
-  int nbg;          // batch groups
+  int nbg;          // clusters of this job: 16-sample batch groups, or (ClusterLaunch::pair) pairs of them
+  int nbg16;        // 16-sample batch groups
   // jobs with identical geometry form a CLASS that shares one contiguous workgroup range: cluster `cl` of the class
   // owns workgroups [cls_begin + cl*G_, +G_); a job's batch group bg is cluster cls_cluster0 + bg
   int cls_begin, cls_nclusters, cls_cluster0;
@@ -55,6 +57,8 @@ struct ClusterLaunch {
   int njobs;
   int ksplit;        // one-tile-per-wave clusters use the K-split step (cluster_run_ks: register-direct gather); 0 = LDS-image step
   int split16;       // K-split launches: f16 (hi, lo) operands on the f16 matrix pipe (cluster_run_k16; tune key 14 = 1: f32 MFMA step)
+  int live_wgs;      // workgroups of the grid that run a cluster (the others are empty ids of the octet layout)
+  int pair;          // split16 K-split launches: every workgroup runs TWO 16-sample groups (cluster_run_k16p: one workgroup per CU)
   int xcd_local;     // K-split launches: clusters are laid out on workgroup ids congruent mod 8 (one XCD under the dispatcher's
                      // round-robin); a cluster that FINDS all its members on one XCD publishes with plain stores into that L2
   ClusterJob job[MGR_MAX_SCAN_JOBS];

@@ -303,6 +303,44 @@ __device__ __forceinline__ void cluster_run(const ClusterJob& jb, int bg, int ug
 // (4.1 / 5.3); a raised wave priority for the cell phase, or for the wider layer's waves (no change).
 typedef __attribute__((address_space(3))) float lds_float;
 constexpr int KS_STG = 8;                      // steps per staged chunk of the transposed output
+typedef _Float16 yt_f16x8 __attribute__((ext_vector_type(8)));
+// A finished chunk of 8 time steps of one (sample, unit) row of the transposed output leaves the staging tile: as 8 floats, or - split
+// row format, mgr.h - as 8 f16 hi values into the row's first half and 8 f16 lo values into its second half (16 + 16 bytes either way).
+// row: the row's first float; t8: first time step of the chunk; ldt: row length in floats.
+__device__ __forceinline__ void ks_flush_chunk(const float* stg, int lane, float* row, int t8, int ldt, bool split) {
+  float v[KS_STG];
+#pragma unroll
+  for (int i = 0; i < KS_STG; ++i) v[i] = stg[i * 64 + lane];
+  if (!split) {
+    *reinterpret_cast<f32x4*>(row + t8) = (f32x4){v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(row + t8 + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+  } else {
+    yt_f16x8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < KS_STG; ++i) {
+      float xs = v[i] * 8192.f;
+      asm volatile("" : "+v"(xs));   // (hi and the residual from ONE f32 value: gemm.hip, mgr_split_f16)
+      hi[i] = (_Float16)xs;
+      lo[i] = (_Float16)(xs - (float)hi[i]);
+    }
+    _Float16* r16 = reinterpret_cast<_Float16*>(row);
+    *reinterpret_cast<yt_f16x8*>(r16 + t8) = hi;
+    *reinterpret_cast<yt_f16x8*>(r16 + ldt + t8) = lo;
+  }
+}
+// zeros behind T up to the row length (both halves of a split row: 2 ldt f16 = ldt floats of zero bits)
+__device__ __forceinline__ void ks_zero_tail(float* row, int T, int ldt, bool split) {
+  const int t0 = (T + KS_STG - 1) / KS_STG * KS_STG;
+  if (!split) {
+    for (int t = t0; t + 4 <= ldt; t += 4) *reinterpret_cast<f32x4*>(row + t) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  } else {
+    _Float16* r16 = reinterpret_cast<_Float16*>(row);
+    for (int t = t0; t + 8 <= ldt; t += 8) {
+      *reinterpret_cast<f32x4*>(r16 + t) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(r16 + ldt + t) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
 constexpr unsigned KS_ROUND_LIMIT = 1u << 20;  // re-fetch rounds of one wave before it gives up (~1 s)
 
 // LDS-DMA: one wave-instruction copies 64 x 16 B (64 x 4 B) from global memory [gbase + voff] (gbase wave-uniform, voff per
@@ -378,6 +416,7 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
   const unsigned zring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)zring);
   const unsigned rring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)rring);
   float* ytrow = nullptr;
+  const bool yt_split = jb.yt_split != 0;
   if (jb.YT && cvalid && bvalid) {
     ytrow = jb.YT + (size_t)b * jb.ytb + (size_t)unit * jb.ldt;
 #pragma unroll
@@ -502,7 +541,6 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
         // NaN / Inf (diverged weights, bad checkpoint): what is published - and fed back - stays finite (0), Y of this (sample,
         // unit) is NaN from here on (latched) and the launch raises MGR_SCAN_NONFINITE (mgr.h)
         __hip_atomic_fetch_or(cm.sticky, MGR_ST_NONFINITE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        mgr_mark_sample(cm, b);
         nonfinite = true;
       }
       if (nonfinite) {
@@ -536,25 +574,15 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
         stg[(t & (KS_STG - 1)) * 64 + lane] = yo;
         // the chunk [t & ~7, +8) is complete when the walk leaves it (all lanes of the launch agree on t)
         if (reverse ? (t & (KS_STG - 1)) == 0 : ((t & (KS_STG - 1)) == KS_STG - 1 || t == T - 1)) {
-          float* dst = ytrow + (t & ~(KS_STG - 1));
-          f32x4 o0, o1;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            o0[i] = stg[i * 64 + lane];
-            o1[i] = stg[(4 + i) * 64 + lane];
-          }
-          *reinterpret_cast<f32x4*>(dst) = o0;
-          *reinterpret_cast<f32x4*>(dst + 4) = o1;
+          ks_flush_chunk(stg, lane, ytrow, t & ~(KS_STG - 1), jb.ldt, yt_split);
 #pragma unroll
           for (int i = 0; i < KS_STG; ++i) stg[i * 64 + lane] = 0.f;   // (a partial last chunk pads with zeros)
         }
       }
     }
   }
-  if (ytrow) {   // zeros behind T up to the row length (mgr.h: the transposed copy is zero in [T, ldt))
-    for (int t0 = (T + KS_STG - 1) / KS_STG * KS_STG; t0 + 4 <= jb.ldt; t0 += 4)
-      *reinterpret_cast<f32x4*>(ytrow + t0) = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
+  if (nonfinite) mgr_mark_sample(cm, b);   // (latched: marked once, behind the time loop - inside it the call cost the step 0.1 us)
+  if (ytrow) ks_zero_tail(ytrow, T, jb.ldt, yt_split);   // (mgr.h: the transposed copy is zero in [T, ldt))
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -581,9 +609,9 @@ __device__ __forceinline__ void cluster_run_ks(const ClusterJob& jb, const Clust
 //     lanes of a unit pair swap their packed (hi, lo) word by DPP, the even lane keeps (hi_even, hi_odd), the odd lane (lo_even,
 //     lo_odd), and ONE store instruction of the wave writes two whole 128-byte lines: the hi line and the lo line of its four samples.
 //     No ds_bpermute.  (Z / Y / gate / c rows of a sample are read and written as 16 consecutive units.)
-//   * every published word carries the epoch parity in one bit: a hi word in bit 0 (the last mantissa bit of the even unit's hi, moved
-//     to the nearest f16 with that bit BEFORE lo is taken, so lo absorbs it), a lo word in bit 16 (the last mantissa bit of the odd
-//     unit's lo, moved to the nearest such f16): every h keeps |h 2^15 - hi - lo| <= 2^-21 |h 2^15| (2^-22 without a flag bit).
+//   * every published word carries the epoch parity in bit 0: the last mantissa bit of the even unit's hi (moved to the nearest f16 with
+//     that bit BEFORE lo is taken, so lo absorbs it) resp. of the even unit's lo (moved likewise): an even unit keeps
+//     |h 2^15 - hi - lo| <= 2^-20 |h 2^15|, an odd unit 2^-22.
 //   * Y, the saved gates and c are the f32 values; the recurrence sees h rounded to 22+ bits (as every f32 consumer of Y would
 //     see it rounded to 24).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -677,6 +705,7 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
       }
 
   float* ytrow = nullptr;
+  const bool yt_split = jb.yt_split != 0;
   if (jb.YT && cvalid && bvalid) {
     ytrow = jb.YT + (size_t)b * jb.ytb + (size_t)unit * jb.ldt;
 #pragma unroll
@@ -745,16 +774,13 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
           v[2 * i] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i], sbase, 16);              // sc1
           v[2 * i + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i] + 1024u, sbase, 16);   // sc1
         }
-        // (the parity bit of a hi word is bit 0, of a lo word bit 16: see the publishing side)
-        unsigned h_and = 0xFFFFFFFFu, h_or = 0u, l_and = 0xFFFFFFFFu, l_or = 0u;
+        unsigned a_and = 0xFFFFFFFFu, a_or = 0u;
 #pragma unroll
-        for (int i = 0; i < NBW; ++i) {
-          h_and &= v[2 * i].x & v[2 * i].y & v[2 * i].z & v[2 * i].w;
-          h_or |= v[2 * i].x | v[2 * i].y | v[2 * i].z | v[2 * i].w;
-          l_and &= v[2 * i + 1].x & v[2 * i + 1].y & v[2 * i + 1].z & v[2 * i + 1].w;
-          l_or |= v[2 * i + 1].x | v[2 * i + 1].y | v[2 * i + 1].z | v[2 * i + 1].w;
+        for (int i = 0; i < 2 * NBW; ++i) {
+          a_and &= v[i].x & v[i].y & v[i].z & v[i].w;
+          a_or |= v[i].x | v[i].y | v[i].z | v[i].w;
         }
-        const bool lane_fresh = par ? (h_and & (l_and >> 16) & 1u) != 0u : ((h_or | (l_or >> 16)) & 1u) == 0u;
+        const bool lane_fresh = par ? (a_and & 1u) != 0u : (a_or & 1u) == 0u;
         if (__all(lane_fresh) || failed) break;
         tick();
         if (failed) break;
@@ -803,7 +829,6 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
       h = mgr_cell_fwd(tot[0], tot[1], tot[2], tot[3], c, g4);
       if (!(fabsf(h) < 2.f) && !nonfinite) {
         __hip_atomic_fetch_or(cm.sticky, MGR_ST_NONFINITE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        mgr_mark_sample(cm, b);
         nonfinite = true;
       }
       if (nonfinite) {
@@ -811,12 +836,13 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
         c = 0.f;
       }
       yv = nonfinite ? __uint_as_float(0x7FC00000u) : h;
-      // h 2^15 = hi + lo.  The epoch parity rides in ONE bit of each published word: bit 0 of the hi word (hi_even, hi_odd) = the
-      // last mantissa bit of the EVEN unit's hi, bit 16 of the lo word (lo_even, lo_odd) = the last mantissa bit of the ODD unit's
-      // lo.  The bit is not forced: the value moves to the NEAREST f16 whose last bit is the parity (k16_with_lsb) - for a hi
-      // BEFORE lo is taken, so that lo absorbs the move.  What it costs (round 5, found by tests/test_gpu_split_adversarial.py: round 4
-      // forced bit 0 of BOTH parts of the even unit, |h 2^15 - hi - lo| up to 2^-18.8 |h| there): even unit: |residual| <= 1 ulp(hi)
-      // instead of 1/2, lo rounds as usual: <= 2^-21 |h|; odd unit: lo moves by at most one ulp(lo) <= 2^-21 |h|.
+      // h 2^15 = hi + lo.  The epoch parity rides in bit 0 of each published word: the last mantissa bit of the EVEN unit's hi (word
+      // (hi_even, hi_odd)) and of the even unit's lo (word (lo_even, lo_odd)).  The bit is not forced: the value moves to the NEAREST
+      // f16 whose last bit is the parity (k16_with_lsb) - the hi BEFORE lo is taken, so that lo absorbs the move.  Cost (round 5, found
+      // by tests/test_gpu_split_adversarial.py: round 4 forced both bits, |h 2^15 - hi - lo| up to 2^-18.8 |h| on even units): even
+      // unit |residual| <= 1 ulp(hi), lo within 1 ulp(lo) of it: <= 2^-20 |h|, odd unit untouched (2^-22).  (Measured and not kept: the
+      // lo word's flag on the ODD unit's lo, bit 16 - every unit <= 2^-21 - but the two-mask check it needs in the gather cost the
+      // audio step 0.3 us of 1.6: profiles/r05_scan_probes.txt.)
       float hs = h * 32768.f;
       asm volatile("" : "+v"(hs));   // (as above)
       unsigned hib = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)hs);
@@ -825,7 +851,7 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
       float ls = hs - hif;
       asm volatile("" : "+v"(ls));
       unsigned lob = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)ls);
-      if (lane & 1) lob = k16_with_lsb(lob, par, ls);
+      if (!(lane & 1)) lob = k16_with_lsb(lob, par, ls);
       packed = hib | (lob << 16);
     }
     if (step + 1 < T) {
@@ -848,24 +874,310 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
       if (ytrow) {
         stg[(t & (KS_STG - 1)) * 64 + lane] = yo;
         if (reverse ? (t & (KS_STG - 1)) == 0 : ((t & (KS_STG - 1)) == KS_STG - 1 || t == T - 1)) {
-          float* dst = ytrow + (t & ~(KS_STG - 1));
-          f32x4 o0, o1;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            o0[i] = stg[i * 64 + lane];
-            o1[i] = stg[(4 + i) * 64 + lane];
-          }
-          *reinterpret_cast<f32x4*>(dst) = o0;
-          *reinterpret_cast<f32x4*>(dst + 4) = o1;
+          ks_flush_chunk(stg, lane, ytrow, t & ~(KS_STG - 1), jb.ldt, yt_split);
 #pragma unroll
           for (int i = 0; i < KS_STG; ++i) stg[i * 64 + lane] = 0.f;
         }
       }
     }
   }
-  if (ytrow) {
-    for (int t0 = (T + KS_STG - 1) / KS_STG * KS_STG; t0 + 4 <= jb.ldt; t0 += 4)
-      *reinterpret_cast<f32x4*>(ytrow + t0) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (nonfinite) mgr_mark_sample(cm, b);   // (latched: marked once, behind the time loop)
+  if (ytrow) ks_zero_tail(ytrow, T, jb.ldt, yt_split);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// PAIR form of the split-f16 K-split step (round 5): ONE workgroup per CU.  A workgroup holds its 16 hidden units' slice of U once and
+// runs TWO 16-sample batch groups through it (cluster `bg` of a paired job owns the groups 2 bg and 2 bg + 1; an odd group count
+// leaves the last cluster with one).  Same exchange images (one per 16-sample group), same layouts, same arithmetic and summation order
+// as cluster_run_k16 - bit-identical results - but per step ONE round of gathers for both groups (one L2 round trip), one barrier,
+// and half the workgroups: the encoder launch of config F is 204 workgroups instead of 408, no CU holds two of them (the pace of a
+// cluster was set by its members that shared their CU with a workgroup of another cluster - uneven by construction), 52 CUs stay free
+// and every scan CU keeps one wave slot per SIMD and ~50 KiB of LDS for the other stream's kernels.
+constexpr int K16P_PER_S = 4 * K16_TILE + 4 * KS_STG * 64 + 4 * 2 * 256 + 4 * 2 * 64;
+constexpr int K16P_LDS_FLOATS = 2 * K16P_PER_S + 16;
+
+template <int NBW>
+__device__ __forceinline__ void cluster_run_k16p(const ClusterJob& jb, const ClusterCommon& cm, int bg, int ug, float* smem, bool fast) {
+  static_assert(NBW >= 1 && NBW <= 4, "1..4 K-blocks per wave (H <= 512)");
+  unsigned* status = cm.status;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..3
+  const int H = jb.H, N = 4 * H, G = jb.G_;
+  const int NKB = (H + 31) >> 5;
+  const int IMGB = NKB * 2048;            // bytes of one exchange slot of one 16-sample group
+  const int B = jb.B, T = jb.T, reverse = jb.reverse;
+  const int om = lane & 15, okg = lane >> 4;
+  const int fn = 4 * wave + (lane >> 4), fu = lane & 15;
+  const int ns = (2 * bg + 1 < jb.nbg16) ? 2 : 1;     // 16-sample groups of this cluster (the same on every member)
+  int b[2];
+  bool bvalid[2];
+  int bc[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    b[s] = (2 * bg + s) * 16 + fn;
+    bvalid[s] = s < ns && b[s] < B;
+    bc[s] = bvalid[s] ? b[s] : B - 1;
+  }
+  const int unit = 16 * ug + fu;
+  const bool cvalid = unit < H;
+  const float* __restrict__ Z = jb.Z;
+  const float* __restrict__ Up = jb.Up;
+  const float* Rp = jb.R;
+  float *Yp = jb.Y, *Gp = jb.G, *Csp = jb.Cs;
+  int ldr = jb.ldr, ldy = jb.ldy;
+  asm volatile("" : "+s"(Rp), "+s"(Yp), "+s"(Gp), "+s"(Csp), "+s"(ldr), "+s"(ldy));   // (see cluster_run_ks)
+
+  const int qb = wave * NBW;
+  int nb = NKB - qb;
+  nb = nb < 0 ? 0 : (nb > NBW ? NBW : nb);
+  nb = __builtin_amdgcn_readfirstlane(nb);
+
+  // LDS of sample group s at smem + s K16P_PER_S: partial sums [tile] K16_TILE | staging [4 waves][KS_STG][64] | Z rings | R rings
+  float *red[2], *stg[2], *zring[2], *rring[2];
+  unsigned zring_lds[2], rring_lds[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    float* base = smem + s * K16P_PER_S;
+    red[s] = base;
+    stg[s] = base + 4 * K16_TILE + wave * (KS_STG * 64);
+    zring[s] = base + 4 * K16_TILE + 4 * KS_STG * 64 + wave * (2 * 256);
+    rring[s] = base + 4 * K16_TILE + 4 * KS_STG * 64 + 4 * 2 * 256 + wave * (2 * 64);
+    zring_lds[s] = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)zring[s]);
+    rring_lds[s] = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)rring[s]);
+  }
+  float* wmax = smem + 2 * K16P_PER_S;
+
+  // ---- weights (as cluster_run_k16)
+  auto uval = [&](int tt, int i, int e) -> float {
+    const int k = 32 * (qb + i) + 8 * okg + e, uu = 16 * ug + 4 * tt + (om >> 2);
+    return (k < H && uu < H) ? Up[(size_t)k * N + uu * 4 + (om & 3)] : 0.f;
+  };
+  float umax = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) umax = fmaxf(umax, fabsf(uval(tt, i, e)));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) umax = fmaxf(umax, __shfl_xor(umax, o));
+  if (lane == 0) wmax[wave] = umax;
+  __syncthreads();
+  umax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  int ex = 0;
+  if (umax > 0.f && umax < 3.0e38f) (void)frexpf(umax, &ex);
+  ex = ex < -60 ? -60 : ex;
+  const float sU = ldexpf(1.f, 15 - ex);
+  const float inv = ldexpf(1.f, ex - 30);
+  f16x8 ah[4][NBW], al[4][NBW];
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = uval(tt, i, e) * sU;
+        asm volatile("" : "+v"(x));
+        const _Float16 hi = (_Float16)x;
+        ah[tt][i][e] = hi;
+        al[tt][i][e] = (_Float16)(x - (float)hi);
+      }
+
+  float* ytrow[2] = {nullptr, nullptr};
+  const bool yt_split = jb.yt_split != 0;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+    if (jb.YT && cvalid && bvalid[s]) {
+      ytrow[s] = jb.YT + (size_t)b[s] * jb.ytb + (size_t)unit * jb.ldt;
+#pragma unroll
+      for (int i = 0; i < KS_STG; ++i) stg[s][i * 64 + lane] = 0.f;
+    }
+  // the exchange slots of the two groups are neighbours in the job's buffer: [group][slot][IMGB]
+  char* xb = reinterpret_cast<char*>(jb.xbuf) + (size_t)(2 * bg) * 2 * IMGB;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, ns * 2 * IMGB, 0x00020000);
+  unsigned goff[NBW];
+#pragma unroll
+  for (int i = 0; i < NBW; ++i) {
+    const int kb = qb + (i < nb ? i : 0);
+    const int half = (2 * kb + (okg >> 1) < G) ? (okg >> 1) : 0;
+    goff[i] = (unsigned)(kb * 2048 + half * 512 + (om >> 2) * 128 + (om & 3) * 32 + (okg & 1) * 16);
+  }
+  const unsigned poff = (unsigned)((ug >> 1) * 2048 + (lane & 1) * 1024 + (ug & 1) * 512 + wave * 128 + (lane >> 4) * 32 + (fu >> 1) * 4);
+
+  const int zunit = cvalid ? unit : 0;
+  unsigned zvoff[2], rvoff[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    zvoff[s] = (unsigned)(((size_t)bc[s] * T * N + (size_t)zunit * 4) * sizeof(float));
+    rvoff[s] = Rp ? (unsigned)(((size_t)bc[s] * T * ldr + zunit) * sizeof(float)) : 0u;
+  }
+  {   // Z / R of step 0 of both groups
+    const int t0 = reverse ? T - 1 : 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      if (s < ns) {
+        mgr_dma_b128(Z + (size_t)t0 * N, zvoff[s], zring_lds[s]);
+        if (Rp) mgr_dma_b32(Rp + (size_t)t0 * ldr, rvoff[s], rring_lds[s]);
+      }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the weight loads are retired before the time loop (see cluster_run_ks)
+
+  const int wslot = om * 4 + ((okg + (om >> 2)) & 3);
+  const int rslot = (fu >> 2) * 260 + fn * 4 + (((fu & 3) + (fn >> 2)) & 3);
+
+  float c[2] = {0.f, 0.f};
+  bool nonfinite[2] = {false, false};
+  bool failed = false;
+  unsigned rounds = 0;
+  auto tick = [&]() {
+    ++rounds;
+    if ((rounds & 255u) == 0) {
+      unsigned st;
+      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(st) : "v"(status) : "memory");
+      if (__builtin_amdgcn_readfirstlane(st) != 0u) failed = true;
+    }
+    if (rounds > KS_ROUND_LIMIT) {
+      failed = true;
+      if (lane == 0) __hip_atomic_store(status, MGR_ST_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+
+  // One time step of ONE group: gather its h_{t-1} blocks, the matrix products, partial sums through LDS, barrier, cell, publish.
+  // The two groups alternate: while the peers' publishes of group s travel (publish -> L2 -> visible: the hand-off latency that a
+  // single chain waits for), this workgroup works on the other group - two barriers per pair of steps, and the partial-sum buffer of
+  // a group needs no second copy (a wave re-writes it only behind the OTHER group's barrier, which every wave reaches after it has
+  // read this one).
+  auto half_step = [&](auto sc, int step) {
+    constexpr int s = decltype(sc)::value;
+    const int t = reverse ? T - 1 - step : step;
+    f32x4 acc[4];
+    u32x4 v[2 * NBW];
+    const bool gather = step > 0 && nb > 0 && !failed;
+    if (gather) {
+      const unsigned sbase = (unsigned)(s * 2 * IMGB + ((step - 1) & 1) * IMGB);
+      const unsigned par = ((((unsigned)(step - 1)) >> 1) & 1u) ^ 1u;
+      for (;;) {
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+          v[2 * i] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i], sbase, 16);              // sc1
+          v[2 * i + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i] + 1024u, sbase, 16);   // sc1
+        }
+        unsigned a_and = 0xFFFFFFFFu, a_or = 0u;
+#pragma unroll
+        for (int i = 0; i < 2 * NBW; ++i) {
+          a_and &= v[i].x & v[i].y & v[i].z & v[i].w;
+          a_or |= v[i].x | v[i].y | v[i].z | v[i].w;
+        }
+        const bool lane_fresh = par ? (a_and & 1u) != 0u : (a_or & 1u) == 0u;
+        if (__all(lane_fresh) || failed) break;
+        tick();
+        if (failed) break;
+      }
+    }
+    auto prefetch_s = [&](int st) {
+      if (st < T) {
+        const int tt2 = reverse ? T - 1 - st : st;
+        mgr_dma_b128(Z + (size_t)tt2 * N, zvoff[s], zring_lds[s] + (st & 1) * 1024);
+        if (Rp) mgr_dma_b32(Rp + (size_t)tt2 * ldr, rvoff[s], rring_lds[s] + (st & 1) * 256);
+      }
+    };
+    if (gather && !failed) {
+#pragma unroll
+      for (int i = 0; i < NBW; ++i) {
+        if (i == (NBW > 1 ? 1 : 0)) prefetch_s(step + 1);
+        const f16x8 bh = __builtin_bit_cast(f16x8, v[2 * i]), bl = __builtin_bit_cast(f16x8, v[2 * i + 1]);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tt][i], bh, i == 0 ? zero : acc[tt], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tt][i], bh, acc[tt], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tt][i], bl, acc[tt], 0, 0, 0);
+      }
+    } else {
+      prefetch_s(step + 1);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float* rbuf = red[s];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(rbuf + tt * K16_TILE + (wave * 64 + wslot) * 4) = acc[tt];
+    // (Z_t / R_t of this group were fetched a pair of steps ago; what this wave may still have in flight are the DMAs just issued)
+    if (Rp)
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    const f32x4 zt = *reinterpret_cast<const f32x4*>(zring[s] + (step & 1) * 256 + lane * 4);
+    const float rt = Rp ? rring[s][(step & 1) * 64 + lane] : 0.f;
+    __syncthreads();
+    const unsigned par = (((unsigned)step >> 1) & 1u) ^ 1u;
+    unsigned packed = par | (par << 16);
+    float h = 0.f, yv = 0.f;
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cvalid) {
+      const float* mine = rbuf + rslot * 4;
+      f32x4 sum = *reinterpret_cast<const f32x4*>(mine);
+#pragma unroll
+      for (int src = 1; src < 4; ++src) sum += *reinterpret_cast<const f32x4*>(mine + src * 64 * 4);
+      f32x4 tot;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) tot[g] = fmaf(sum[g], inv, zt[g]);
+      h = mgr_cell_fwd(tot[0], tot[1], tot[2], tot[3], c[s], g4);
+      if (!(fabsf(h) < 2.f) && !nonfinite[s]) {
+        __hip_atomic_fetch_or(cm.sticky, MGR_ST_NONFINITE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nonfinite[s] = true;
+      }
+      if (nonfinite[s]) {
+        h = 0.f;
+        c[s] = 0.f;
+      }
+      yv = nonfinite[s] ? __uint_as_float(0x7FC00000u) : h;
+      float hs = h * 32768.f;   // (the flag bits: cluster_run_k16)
+      asm volatile("" : "+v"(hs));
+      unsigned hib = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)hs);
+      if (!(lane & 1)) hib = k16_with_lsb(hib, par, hs);
+      const float hif = (float)__builtin_bit_cast(_Float16, (unsigned short)hib);
+      float ls = hs - hif;
+      asm volatile("" : "+v"(ls));
+      unsigned lob = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)ls);
+      if (!(lane & 1)) lob = k16_with_lsb(lob, par, ls);
+      packed = hib | (lob << 16);
+    }
+    if (step + 1 < T) {
+      const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)packed, 0xB1, 0xF, 0xF, true);
+      const unsigned w = (lane & 1) ? ((other >> 16) | (packed & 0xFFFF0000u)) : ((packed & 0xFFFFu) | (other << 16));
+      const unsigned so = (unsigned)(s * 2 * IMGB + (step & 1) * IMGB);
+      if (fast)
+        __builtin_amdgcn_raw_buffer_store_b32(w, rs, poff, so, 0);
+      else
+        __builtin_amdgcn_raw_buffer_store_b32(w, rs, poff, so, 16);  // sc1
+    }
+    if (cvalid && bvalid[s]) {
+      size_t row = (size_t)b[s] * T + t;
+      const float yo = yv + rt;
+      typedef __attribute__((address_space(1))) float gfloat;
+      typedef __attribute__((address_space(1))) f32x4 gf32x4;
+      ((gfloat*)Yp)[row * ldy + unit] = yo;
+      if (Gp) *(gf32x4*)(Gp + (row * H + unit) * 4) = (f32x4){g4.x, g4.y, g4.z, g4.w};
+      if (Csp) ((gfloat*)Csp)[row * H + unit] = c[s];
+      if (ytrow[s]) {
+        stg[s][(t & (KS_STG - 1)) * 64 + lane] = yo;
+        if (reverse ? (t & (KS_STG - 1)) == 0 : ((t & (KS_STG - 1)) == KS_STG - 1 || t == T - 1)) {
+          ks_flush_chunk(stg[s], lane, ytrow[s], t & ~(KS_STG - 1), jb.ldt, yt_split);
+#pragma unroll
+          for (int i = 0; i < KS_STG; ++i) stg[s][i * 64 + lane] = 0.f;
+        }
+      }
+    }
+  };
+  for (int step = 0; step < T; ++step) {
+    half_step(std::integral_constant<int, 0>{}, step);
+    if (ns == 2) half_step(std::integral_constant<int, 1>{}, step);   // (uniform over the cluster)
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    if (nonfinite[s]) mgr_mark_sample(cm, b[s]);
+    if (ytrow[s]) ks_zero_tail(ytrow[s], T, jb.ldt, yt_split);
   }
 }
 
@@ -996,6 +1308,39 @@ __global__ __launch_bounds__(256, 2) void k_scan_cluster_k16_s(ClusterLaunch L) 
   scan_cluster_k16_body<true>(L, smem);
 }
 
+// the pair form (cluster_run_k16p): one workgroup per CU, two 16-sample groups per workgroup; same launch layout, `bg` counts pairs
+__global__ __launch_bounds__(256, 1) void k_scan_cluster_k16p(ClusterLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  mgr_cluster_enter(L.cm);
+#define K16P_RUN(NBW) \
+  if (nbw == NBW) { cluster_run_k16p<NBW>(jb, L.cm, bg, ug, smem, same); return mgr_cluster_exit(L.cm); }
+#define K16P_DISPATCH                                    \
+  {                                                      \
+    const int nbw = (((jb.H + 31) >> 5) + 3) >> 2;       \
+    K16P_RUN(1) K16P_RUN(2) K16P_RUN(3) K16P_RUN(4)      \
+    return;                                              \
+  }
+  if (L.xcd_local) {
+    for (int k_ = 0; k_ < L.njobs; ++k_) {
+      const ClusterJob& jb = L.job[k_];
+      const int w_ = (int)blockIdx.x - jb.cls_begin, G = jb.G_;
+      if (w_ < 0 || w_ >= (jb.cls_nclusters + 7) / 8 * 8 * G) continue;
+      int cl, ug;
+      const bool same = mgr_cluster_octet(L.cm, jb.cls_begin, G, jb.cls_rot, w_, cl, ug);
+      const int bg = cl - jb.cls_cluster0;
+      if (cl >= jb.cls_nclusters || bg < 0 || bg >= jb.nbg) continue;
+      K16P_DISPATCH
+    }
+    return;
+  }
+  MGR_FOR_MY_JOB(L, jb, bg, ug) {
+    const bool same = false;
+    K16P_DISPATCH
+  }
+#undef K16P_DISPATCH
+#undef K16P_RUN
+}
+
 }  // namespace
 
 bool mgr_cluster_supported(int ks, int tpw) {
@@ -1043,6 +1388,7 @@ void mgr_cluster_geometry(const ClusterLaunch& L, bool any_exchange, int* waves,
   *waves = maxnw <= 4 ? 4 : CL_WAVES;
   // 4-wave workgroups with <= 80 KiB of LDS fit two per CU (8 waves, <= 256 VGPRs each); anything else sits alone on its CU
   *per_cu = (*waves == 4 && (ks_eligible(L, any_exchange, *waves) || image_lds(L) <= 80 * 1024)) ? 2 : 1;
+  if (L.pair && L.split16 && ks_eligible(L, any_exchange, *waves)) *per_cu = 1;   // (the pair form's 101 KiB of LDS: alone among scans on its CU)
 }
 
 bool mgr_cluster_uses_ks(const ClusterLaunch& L, bool any_exchange) {
@@ -1059,8 +1405,9 @@ int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool a
     // co-residency of every spinning workgroup is what makes the in-launch hand-off deadlock-free; a workgroup that must sit
     // alone on its CU says so through its LDS request
     if (per_cu == 1 && lds < 84 * 1024) lds = 84 * 1024;
-    MGR_REQUIRE(total_wgs <= per_cu * c->cu_count, "cluster scan needs %d co-resident workgroups but the device holds %d",
-                total_wgs, per_cu * c->cu_count);
+    const int live = L.live_wgs > 0 ? L.live_wgs : total_wgs;
+    MGR_REQUIRE(live <= per_cu * c->cu_count, "cluster scan needs %d co-resident workgroups but the device holds %d", live,
+                per_cu * c->cu_count);
   }
   if (!(c->attr_done & 1u)) {   // (function attributes are per device, hence per context)
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1068,6 +1415,7 @@ int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool a
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_ks_s), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_k16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_k16_s), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_k16p), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     c->attr_done |= 1u;
   }
   MGR_REQUIRE(!L.xcd_local || ks_eligible(L, any_exchange, waves), "XCD-local layout is only understood by the K-split kernel");
@@ -1075,7 +1423,9 @@ int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool a
     // partial-sum exchange, staging tiles of the transposed output, Z / R rings (no h image): 50 KiB, two workgroups per CU
     bool small = true;
     for (int i = 0; i < L.njobs; ++i) small = small && L.job[i].ks <= 32;
-    if (L.split16) {
+    if (L.split16 && L.pair) {
+      hipLaunchKernelGGL(k_scan_cluster_k16p, dim3(total_wgs), dim3(256), K16P_LDS_FLOATS * sizeof(float), mgr_stream(c), L);
+    } else if (L.split16) {
       if (small)
         hipLaunchKernelGGL(k_scan_cluster_k16_s, dim3(total_wgs), dim3(256), K16_LDS_FLOATS * sizeof(float), mgr_stream(c), L);
       else

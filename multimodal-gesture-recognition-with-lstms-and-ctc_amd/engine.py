@@ -81,6 +81,12 @@ class Schedule:
     transposed_inputs   keep a transposed copy of the inputs of the wide dropout layers for the dropout-aware projection GEMMs
     resident_wait_us    upper bound of the device-side wait that lets the deepest encoder scan become resident before the
                         deferred GEMMs are released (mgr_stream_wait_next_resident); 0 = no wait
+    encoders_two_ahead  (round 5; needs bptt_beside_deepest_scan) a caller that announces TWO batches ahead (enqueue_train_step's
+                        prefetch_after_next) gets the first part of the batch-after-next's encoder pass enqueued at the end of a
+                        step instead of at the start of the next call, which has to wait for the step's loss
+    split_rows          (round 5) the transposed copies are written in the split row format (f16 hi / lo pairs) and the wide products
+                        run as loader / matrix pipelines on pre-split operands (gemm_split.hip); False: f32 rows, converted by
+                        every product that reads them (round 4's kernels)
     bptt_beside_deepest_scan  (round 4; needs the three switches above) the trainable layer's BPTT is held back together with its
                         GEMMs: recurrence beside recurrence, GEMM beside GEMM.  The encoder stream then runs free - the next batch's
                         encoder pass up to its deepest projections is enqueued BEFORE this step's fusion work, and its depth-1
@@ -88,7 +94,9 @@ class Schedule:
     """
 
     def __init__(self, pipeline=True, defer_param_grads=True, encoders_run_ahead=True, resident_wait_us=2000,
-                 transposed_inputs=True, bptt_beside_deepest_scan=True):
+                 transposed_inputs=True, bptt_beside_deepest_scan=True, split_rows=True, encoders_two_ahead=True):
+        self.encoders_two_ahead = bool(encoders_two_ahead)
+        self.split_rows = bool(split_rows)
         self.bptt_beside_deepest_scan = bool(bptt_beside_deepest_scan)
         self.transposed_inputs = bool(transposed_inputs)
         self.pipeline = bool(pipeline)
@@ -181,10 +189,15 @@ class Engine:
                         # (+ the transposed dZ of the dropout-aware dW from the transposed activation copy: sized here, not by a
                         # hipMalloc in the middle of the first training step)
                         need = max(need, self.lib.mgr_lstm_param_grads_dropout_t_ws_bytes(B, T, fin, H, (T + 127) // 128 * 128))
+                        if self._ts_shape(fin):
+                            need = max(need, self.lib.mgr_lstm_param_grads_dropout_ts_ws_bytes(B, T, fin, H, (T + 127) // 128 * 128))
                     L.ws_pg = dev.bytes(need)
                 if p > 0:
                     L.mask = dev.empty((4, B, fin))
-                    L.ws_sp = dev.bytes(self.lib.mgr_lstm_input_proj_dropout_ws_bytes(B, fin, H))   # kept-feature lists
+                    need = self.lib.mgr_lstm_input_proj_dropout_ws_bytes(B, fin, H)                 # kept-feature lists, weight copies
+                    if self._ts_shape(fin):
+                        need = max(need, self.lib.mgr_lstm_input_proj_dropout_ts_ws_bytes(B, fin, H))
+                    L.ws_sp = dev.bytes(need)
                 L.p = p
                 self.dirs[base] = L
 
@@ -233,6 +246,7 @@ class Engine:
         self.Y1T = {}
         self._featT = {}
         self._featT_ready = {}   # FEAT buffer -> its transposed copy was written by the scans of the current pass
+        self._xt_split = {}      # transposed copy (device pointer) -> its rows are in the split row format (as last written)
         if self.schedule.transposed_inputs:   # (training: dropout-aware GEMMs; inference: the dense split-f16 projection reads it too)
             want = lambda p, F: bool(self.lib.mgr_lstm_input_proj_dropout_wants_transposed(self.dev.ctx, C.c_float(float(p)), int(F)))
             for s in sp.streams:
@@ -430,31 +444,49 @@ class Engine:
     # whether the scans wrote the copy themselves or mgr_transpose_bt made it from such a buffer.  A diverged state is NaN, not large.
     XT_BOUND = -2.0
 
+    @staticmethod
+    def _ts_shape(fin):
+        """Layer widths the pre-split products handle (mgr_lstm_input_proj_dropout_ts / mgr_lstm_param_grads_dropout_ts)."""
+        return 128 <= fin <= 2048
+
+    def _split_rows_wanted(self):
+        """The format new transposed activation copies are written in: split rows (f16 hi / lo pairs, mgr.h) for the pre-split
+        products on the f16 matrix pipe - unless tune key 15 keeps the GEMMs on their f32 MFMA kernels (bench.py's second leg)."""
+        if not self.schedule.split_rows:
+            return False
+        v = C.c_int()
+        self.dev.call("mgr_tune_get", 15, C.byref(v))
+        return v.value == 0
+
+    def _make_xt(self, X, ldx, XT, B, T, fin):
+        """Transposed copy of a row-major activation buffer the scans did not write themselves, in the format wanted now."""
+        split = self._split_rows_wanted() and self._ts_shape(fin)
+        self.dev.call("mgr_transpose_bt_split" if split else "mgr_transpose_bt", X, ldx, XT, self.ldt, B, T, fin)
+        self._xt_split[XT.ptr] = split
+
     def _project_pair(self, X, ldx, pair, Ls, B, T, fin, H, XT=None, xt_ready=False):
         """Input projections of the two directions of one Bidirectional layer (pair = [mask, Wp, bp, Z] x 2).  With input
         dropout active the library runs each direction's K loops over the kept features only (from p >= 0.3 on) - from the
-        transposed copy XT of the input where the engine keeps one; otherwise both directions go through one call that fuses
-        them into one GEMM where that saves tiles."""
-        if pair[0] and Ls[0].ws_sp is not None:
-            if XT is not None and not xt_ready:     # (xt_ready: the scans that produced X wrote XT themselves, mgr_scan_job.YT)
-                self.dev.call("mgr_transpose_bt", X, ldx, XT, self.ldt, B, T, fin)
+        transposed copy XT of the input where the engine keeps one (pre-split rows: the loader / matrix pipeline of gemm_split.hip;
+        f32 rows: the kernels of gemm.hip); otherwise both directions go through one call that fuses them into one GEMM where that
+        saves tiles."""
+        masked = bool(pair[0]) and Ls[0].ws_sp is not None
+        unmasked_wide = not pair[0] and XT is not None and 128 <= fin <= 2048 and Ls[0].ws_sp is not None
+        if XT is not None and (masked or unmasked_wide) and not xt_ready:   # (xt_ready: the scans that produced X wrote XT themselves, mgr_scan_job.YT)
+            self._make_xt(X, ldx, XT, B, T, fin)
+        split = XT is not None and self._xt_split.get(XT.ptr, False)
+        if masked or unmasked_wide:
+            # (no dropout - inference - on a wide layer whose input the engine keeps transposed: the same kernels without a mask)
             for d in range(2):
                 m, Wp, bp, Z = pair[4 * d:4 * d + 4]
                 ws = Ls[d].ws_sp
-                if XT is not None:
-                    self.dev.call("mgr_lstm_input_proj_dropout_t", XT, self.ldt, m, float(Ls[d].p), Wp, bp, Z, B, T, fin, H,
-                                  ws, ws.nbytes, self.XT_BOUND)
+                p = float(Ls[d].p) if masked else 0.0
+                if split:
+                    self.dev.call("mgr_lstm_input_proj_dropout_ts", XT, self.ldt, m, p, Wp, bp, Z, B, T, fin, H, ws, ws.nbytes)
+                elif XT is not None:
+                    self.dev.call("mgr_lstm_input_proj_dropout_t", XT, self.ldt, m, p, Wp, bp, Z, B, T, fin, H, ws, ws.nbytes, self.XT_BOUND)
                 else:
-                    self.dev.call("mgr_lstm_input_proj_dropout", X, ldx, m, float(Ls[d].p), Wp, bp, Z, B, T, fin, H, ws, ws.nbytes)
-        elif not pair[0] and XT is not None and 128 <= fin <= 2048 and Ls[0].ws_sp is not None:
-            # no dropout (inference) on a wide layer whose input the engine keeps transposed: the dense projection on the f16 matrix
-            # pipe (split-f16 operands; XT_BOUND) instead of the f32 MFMA pair kernel (tune key 15 = 1: the f32 kernel over all features)
-            if not xt_ready:
-                self.dev.call("mgr_transpose_bt", X, ldx, XT, self.ldt, B, T, fin)
-            for d in range(2):
-                m, Wp, bp, Z = pair[4 * d:4 * d + 4]
-                ws = Ls[d].ws_sp
-                self.dev.call("mgr_lstm_input_proj_dropout_t", XT, self.ldt, 0, 0.0, Wp, bp, Z, B, T, fin, H, ws, ws.nbytes, self.XT_BOUND)
+                    self.dev.call("mgr_lstm_input_proj_dropout", X, ldx, m, p, Wp, bp, Z, B, T, fin, H, ws, ws.nbytes)
         else:
             self.dev.call("mgr_lstm_input_proj_pair", X, ldx, *pair, B, T, fin, H)
 
@@ -526,6 +558,7 @@ class Engine:
             self._xcur[name] = X
         depth = max(len(s["layers"]) for s in sp.streams)
         feat_by_scans = True     # every stream's last layer writes FEAT (and its transposed copy) from its scan
+        split_now = self._split_rows_wanted()   # the format of the transposed copies this pass's scans write
         for k in range(depth):
             jobs = []
             for si, s in enumerate(sp.streams):
@@ -557,10 +590,13 @@ class Engine:
                     Z = (z_first[name] if (k == 0 and z_first is not None) else self.Zbuf[name])[di]
                     R, ldr = 0, 0
                     YT, ytb = 0, 0      # transposed copy written by the scan itself (what the next dropout layer's GEMMs read)
+                    yt_fmt = 0
                     if not last:
                         Y, ldy = self.Y1[name].view(di * H, (1,)), 2 * H
                         if name in self.Y1T:
                             YT, ytb = self.Y1T[name].ptr + di * H * self.ldt * 4, 2 * H * self.ldt
+                            yt_fmt = int(split_now and self._ts_shape(2 * H))
+                            self._xt_split[self.Y1T[name].ptr] = bool(yt_fmt)
                     elif nl == 2 and s["residual"] and name in self.Y2 and save:
                         Y, ldy = self.Y2[name].view(di * H, (1,)), 2 * H
                         feat_by_scans = False
@@ -570,10 +606,12 @@ class Engine:
                             R, ldr = self.Y1[name].view(di * H, (1,)), 2 * H
                         if feat_buf.ptr in self._featT:
                             YT, ytb = self._featT[feat_buf.ptr].ptr + (col + di * H) * self.ldt * 4, W * self.ldt
+                            yt_fmt = int(split_now and self._ts_shape(W))
+                            self._xt_split[self._featT[feat_buf.ptr].ptr] = bool(yt_fmt)
                     keep = save and L.trainable
                     jobs.append(dict(Z=Z, Up=L.Up, Y=Y, ldy=ldy, R=R, ldr=ldr, gates=L.gates if keep else 0,
                                      cs=L.cs if keep else 0, B=B, T=T, H=H, reverse=L.reverse, YT=YT, ytb=ytb,
-                                     ldt=self.ldt if YT else 0))
+                                     ldt=self.ldt if YT else 0, yt_split=yt_fmt))
             if k == 0:
                 dev.record(self.EV_IN[self._xin_slot])   # the inputs have been read (noise kernel / depth-1 projections)
             self.rng_step = saved_step
@@ -615,8 +653,11 @@ class Engine:
                 mptr = self._prep_mask(L, train, rand, 500 + di)
                 self._masks[(L.prefix, L.d)] = mptr
                 pair += [mptr, L.Wp, L.bp, self.ZF[di]]
-            self._project_pair(feat_buf, W, pair, Ls_pair, B, T, W, Hf, XT=self._featT.get(feat_buf.ptr),
-                               xt_ready=self._featT_ready.get(feat_buf.ptr, False))
+            # (pipelined training: these GEMMs run while the next batch's deepest encoder scan holds the chip - the forms of the
+            # pre-split products that fit on a CU beside a scan workgroup, not the 8-wave ones that wait for the scan to end)
+            with self._narrow_tiles(self._beside_scans):
+                self._project_pair(feat_buf, W, pair, Ls_pair, B, T, W, Hf, XT=self._featT.get(feat_buf.ptr),
+                                   xt_ready=self._featT_ready.get(feat_buf.ptr, False))
             dev.record(self.EV_FPROJ)   # (the next step's depth-1 scan is launched after these GEMMs, _enqueue_next_encoders)
             for di, dname in enumerate(("fwd", "bwd")):
                 L = self.dirs["fusion/%s" % dname]
@@ -645,6 +686,25 @@ class Engine:
                      self._wview("dense/W"), self._wview("dense/b"), self.P, B, T, D, Cn)
         self._feat = (feat, ldf)
         self.rng_step = saved_step
+
+    _early_for = None        # the inputs the generator started last was announced for
+    _early_gen = None        # _next_encoders_free generator of the batch after next, its first part already enqueued
+    _beside_scans = False    # the fusion layer's GEMMs of the step being enqueued run beside encoder scans of the next batch
+
+    def _narrow_tiles(self, on):
+        """Context manager: the pre-split products enqueued inside take their 4-wave forms (tune key 12 = 1, mgr.h)."""
+        eng = self
+
+        class _Ctx:
+            def __enter__(self_):
+                if on:
+                    eng.dev.call("mgr_tune", 12, 1)
+
+            def __exit__(self_, *exc):
+                if on:
+                    eng.dev.call("mgr_tune", 12, 0)
+                return False
+        return _Ctx()
 
     def _scan_multi(self, jobs, wsname):
         """One multi-scan call on the current stream; `wsname` keeps the encoder and fusion workspaces apart (they may
@@ -1040,10 +1100,15 @@ class Engine:
     EV_FPROJ = 45   # this step's fusion projection GEMMs are done
 
     def enqueue_train_step(self, inputs, labels, input_length, label_length, rand=None, apply_update=True,
-                           upload=True, prefetch_next=False, next_inputs=None):
+                           upload=True, prefetch_next=False, next_inputs=None, prefetch_after_next=False, after_next_inputs=None):
         """Enqueue one training step.  With prefetch_next (device-RNG training of a network whose encoders are frozen)
         the NEXT step's encoder pass is enqueued on a second stream into the other FEAT buffer right after this step's
-        fusion work, and this step consumes the encoder pass enqueued by the previous call (Schedule)."""
+        fusion work, and this step consumes the encoder pass enqueued by the previous call (Schedule).
+        prefetch_after_next (round 5; the caller promises that the call after the next one comes, with prefetch_next, for
+        after_next_inputs): the encoder stream also gets the first part of THAT batch's pass - up to its deepest projections - at
+        the end of this call instead of at the start of the next one.  The next call can only be made once the host has this step's
+        loss (the CTC kernel, half-way through the step): the encoder stream used to sit idle from the end of its deepest scan
+        until then (0.9 - 3.9 ms per step in the traces of round 5)."""
         sp, dev, B, T = self.spec, self.dev, self.B, self.T
         sch, ES = self.schedule, self.ES
         self._bind()
@@ -1084,10 +1149,20 @@ class Engine:
         # host needs ~1-2 ms to enqueue the fusion layer and the head, during which that stream would sit idle
         any_tr_stream_ = any(s_["trainable"] for s_ in sp.streams)
         free_gen = None
-        if pipelined and ahead and sch.bptt_beside_deepest_scan and sp.fusion and not any_tr_stream_:
+        free_ok = pipelined and ahead and sch.bptt_beside_deepest_scan and sp.fusion and not any_tr_stream_
+        early, self._early_gen = self._early_gen, None
+        if early is not None and not (free_ok and (not upload or next_inputs is self._early_for)):
+            # the caller did not come back as announced: what the encoder stream was handed early is dropped
+            dev.wait(0, ES)
+            self._feat_idx ^= 1
+            early = None
+        if early is not None:
+            free_gen = early                   # (its first part was enqueued at the end of the previous call)
+        elif free_ok:
             free_gen = self._next_encoders_free(next_inputs, depth, self.rng_step + 1, self._step_id + 1)
             next(free_gen)
         # ---- 2. fusion layer, head, CTC, loss read-back point
+        self._beside_scans = bool(pipelined)
         self._enqueue_fusion_head(True, rand, cur, self.rng_step, dense=False)
         self.rng_step += 1
         Cn, D = sp.num_classes, sp.head_width
@@ -1163,8 +1238,13 @@ class Engine:
             finish()
         elif free_gen is not None:
             free_gen.send(finish)
+            if prefetch_after_next and sch.encoders_two_ahead:
+                # the first part of the pass of the batch AFTER the next one (rng_step / _step_id were advanced above)
+                self._early_gen = self._next_encoders_free(after_next_inputs, depth, self.rng_step + 1, self._step_id + 1)
+                next(self._early_gen)
         else:
             self._enqueue_next_encoders(next_inputs, finish, defer, ahead, depth, free_running=late_bptt is not None)
+        self._beside_scans = False
         dev.stream(0)
 
     def _next_encoders_free(self, next_inputs, depth, rng_step, consumer_step):
@@ -1175,7 +1255,7 @@ class Engine:
         dev, ES = self.dev, self.ES
         self._feat_idx ^= 1
         nxt = self._feat_ring[self._feat_idx]
-        self._prefetched_for = next_inputs
+        self._early_for = next_inputs          # (becomes _prefetched_for when the pass is complete: two announcements may be in flight)
         if next_inputs is not None:
             dev.stream(ES)
             self._upload_inputs(next_inputs, None, True, stream=ES)
@@ -1193,6 +1273,7 @@ class Engine:
         for _ in phases:
             pass
         self._prefetched = nxt
+        self._prefetched_for = next_inputs
         dev.stream(0)
         yield
 
@@ -1268,12 +1349,18 @@ class Engine:
             self._ws_bwd_multi = self.mem.bytes(need)
         _capi.check(self.lib.mgr_lstm_scan_bwd_multi(dev.ctx, len(jobs), arr, self._ws_bwd_multi.ptr,
                                                      self._ws_bwd_multi.nbytes))
+        beside_scans = self._beside_scans     # (the deferred GEMMs run beside the next batch's encoder scans as well)
+
         def param_grads():
             for di, dname in enumerate(("fwd", "bwd")):
                 L = self.dirs["%s/%s" % (prefix, dname)]
                 H = L.H
                 mptr = self._masks.get((L.prefix, L.d), 0)
-                if mptr and XinT is not None and self.lib.mgr_lstm_param_grads_dropout_wants_transposed(
+                if mptr and XinT is not None and self._xt_split.get(XinT.ptr, False):
+                    with self._narrow_tiles(beside_scans):
+                        dev.call("mgr_lstm_param_grads_dropout_ts", XinT, self.ldt, mptr, float(L.p), Hbuf.view(di * H, (1,)), ldh, L.dZ,
+                                 L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes)
+                elif mptr and XinT is not None and self.lib.mgr_lstm_param_grads_dropout_wants_transposed(
                         dev.ctx, C.c_float(float(L.p)), int(fin)):
                     need = self.lib.mgr_lstm_param_grads_dropout_t_ws_bytes(B, T, fin, H, self.ldt)
                     if L.ws_pg.nbytes < need:          # (+ the transposed dZ; first use only)

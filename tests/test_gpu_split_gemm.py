@@ -67,3 +67,100 @@ def test_projection_from_split_rows(device, B, T, F, H, p):
         M2[g0, b0, f0] *= f32(1.5)
         dev.call("mgr_lstm_input_proj_dropout_ts", XS, ldt, dev.array(M2), p, dW, db, Z, B, T, F, H, ws, ws.nbytes)
         assert np.all(np.isnan(Z.download()))
+
+
+@pytest.mark.parametrize("B,T,F,H,p,reverse", [(3, 130, 128, 100, 0.5, 0), (2, 300, 1600, 100, 0.5, 1), (2, 77, 1000, 130, 0.5, 0),
+                                               (2, 140, 600, 300, 0.6, 1), (2, 100, 131, 20, 0.9, 0), (2, 64, 160, 40, 1.0, 0),
+                                               (9, 50, 200, 64, 0.5, 0)])
+def test_weight_gradient_from_split_rows(device, B, T, F, H, p, reverse):
+    """mgr_lstm_param_grads_dropout_ts against numpy fp64 (dW) and against mgr_lstm_param_grads (dU, db: the shared path, bit for
+    bit); the gate gradients spread over 24 orders of magnitude per (sample, gate column) - the per-row scaling must not care."""
+    dev = device
+    rng = np.random.default_rng(B * 977 + T + F + H)
+    N = 4 * H
+    X = rng.uniform(-2, 2, (B, T, F)).astype(f32)
+    Hs = rng.standard_normal((B, T, H)).astype(f32)
+    c = f32(1.0 / (1.0 - p)) if p < 1.0 else f32(1.0)
+    M = ((rng.random((4, B, F)) >= p) * c).astype(f32)
+    ldt = (T + 127) // 128 * 128
+    dX, dH, dM = dev.array(X), dev.array(Hs), dev.array(M)
+    XS = dev.zeros((B, F, ldt))
+    dev.call("mgr_transpose_bt_split", dX, F, XS, ldt, B, T, F)
+    ws = dev.bytes(dev.lib.mgr_lstm_param_grads_dropout_ts_ws_bytes(B, T, F, H, ldt))
+    wsr = dev.bytes(dev.lib.mgr_lstm_param_grads_ws_bytes(B, T, F, H))
+    gate = np.arange(N) % 4
+    base = (rng.standard_normal((B, T, N)) * 0.3).astype(f32)
+    for spread in (False, True):
+        dZ = base * (10.0 ** rng.uniform(-12, 12, size=(B, 1, N))).astype(f32) if spread else base
+        ref = np.empty((F, N))
+        for g in range(4):
+            ref[:, gate == g] = np.einsum("btf,btn->fn", X.astype(np.float64) * M[g][:, None, :], dZ[:, :, gate == g].astype(np.float64))
+        ddZ = dev.array(dZ)
+        gW, gU, gb = dev.empty((F, N)), dev.empty((H, N)), dev.empty((N,))
+        gW.upload(np.full((F, N), np.nan, f32))
+        dev.call("mgr_memset", ws, 0xFF, ws.nbytes)          # the workspace arrives dirty
+        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW, gU, gb, B, T, F, H, reverse, ws, ws.nbytes)
+        got = gW.download()
+        colscale = np.maximum(np.abs(ref).max(axis=0, keepdims=True), 1e-30)      # per column: the spread is per column
+        assert np.all(np.isfinite(got)) and (np.abs(got - ref) / colscale).max() <= 3e-5, (spread, (np.abs(got - ref) / colscale).max())
+        gW2, gU2, gb2 = dev.empty((F, N)), dev.empty((H, N)), dev.empty((N,))
+        dev.call("mgr_lstm_param_grads", dX, F, dM, dH, H, ddZ, gW2, gU2, gb2, B, T, F, H, reverse, wsr, wsr.nbytes)
+        assert np.array_equal(gU.download(), gU2.download()) and np.array_equal(gb.download(), gb2.download())
+
+
+@pytest.mark.parametrize("hs,B,T", [((500, 300), 40, 21), ((300,), 64, 19), ((100,), 33, 24), ((500,), 16, 9)])
+def test_pair_form_of_the_scan_is_bit_identical_and_scans_write_split_rows(device, hs, B, T):
+    """lstm_cluster.hip, cluster_run_k16p (two 16-sample groups per workgroup, one workgroup per CU; tune key 4 = 2 forces it, 1
+    forbids it): Y, gates, c and the transposed copies bit for bit those of the one-group form - B = 40 / 33 leave the last cluster
+    with a single group, B = 16 has nothing to pair.  And mgr_scan_job.yt_split: the transposed copy in the split row format is, bit
+    for bit, the split of the f32 copy (hi = rn_f16(y 2^13), lo = rn_f16(y 2^13 - hi)), zeros behind T."""
+    from mgr_amd import _capi
+    dev = device
+    rng = np.random.default_rng(sum(hs) + B + T)
+    ldt = (T + 127) // 128 * 128
+    W = 2 * sum(hs)
+    R = dev.array(rng.uniform(-1, 1, (B, T, W)).astype(f32))
+    keep, base_jobs = [], []
+    col = 0
+    for H in hs:
+        for d in range(2):
+            Z = dev.array((rng.standard_normal((B, T, 4 * H)) * 0.5).astype(f32))
+            U = dev.array((rng.standard_normal((H, 4 * H)) * 0.1 / np.sqrt(H)).astype(f32))
+            Up = dev.empty((H, 4 * H))
+            dev.call("mgr_lstm_pack", U, Up, H, H, 0)
+            keep += [Z, U, Up]
+            base_jobs.append(dict(Z=Z, Up=Up, H=H, reverse=d, col=col))
+            col += H
+
+    def run(pair, split):
+        Y = dev.zeros((B, T, W))
+        YT = dev.array(np.full((B, W, ldt), 7.0, f32))
+        jobs = []
+        outs = []
+        for j in base_jobs:
+            H, c0 = j["H"], j["col"]
+            G, Cs = dev.zeros((B, T, H, 4)), dev.zeros((B, T, H))
+            outs += [G, Cs]
+            jobs.append(dict(Z=j["Z"], Up=j["Up"], Y=Y.view(c0, (1,)), ldy=W, R=R.view(c0, (1,)), ldr=W, gates=G, cs=Cs, B=B, T=T, H=H,
+                             reverse=j["reverse"], YT=YT.ptr + c0 * ldt * 4, ytb=W * ldt, ldt=ldt, yt_split=int(split)))
+        dev.call("mgr_tune", 0, 3)      # clusters with an exchange at every H (the K-split step)
+        dev.call("mgr_tune", 1, 1)
+        dev.call("mgr_tune", 4, 2 if pair else 1)
+        try:
+            arr = _capi.make_scan_jobs(jobs)
+            ws = dev.bytes(dev.lib.mgr_lstm_scan_multi_ws_bytes(len(jobs), arr))
+            _capi.check(dev.lib.mgr_lstm_scan_fwd_multi(dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes))
+        finally:
+            dev.call("mgr_tune", 0, 0)
+            dev.call("mgr_tune", 1, 0)
+            dev.call("mgr_tune", 4, 0)
+        return Y.download(), YT.download(), [o.download() for o in outs]
+
+    y0, yt0, o0 = run(False, False)
+    y1, yt1, o1 = run(True, False)
+    assert np.array_equal(y0, y1) and np.array_equal(yt0, yt1) and all(np.array_equal(a, b) for a, b in zip(o0, o1))
+    assert np.array_equal(yt0[:, :, :T], y0.transpose(0, 2, 1)) and not yt0[:, :, T:].any()
+    for pair in (False, True):
+        y2, yts, o2 = run(pair, True)
+        assert np.array_equal(y2, y0) and all(np.array_equal(a, b) for a, b in zip(o0, o2))
+        assert np.array_equal(yts.view(np.uint32), _split_rows(y0, ldt).view(np.uint32))

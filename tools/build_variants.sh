@@ -8,7 +8,7 @@ mkdir -p $R/variants
 for V in "$@"; do
   NAME=${V%%:*}; FLAGS=${V#*:}
   O=/tmp/mgr_variant_$NAME; mkdir -p $O
-  for S in ctx elementwise ctc dense gemm lstm_simple lstm_mfma lstm_cluster lstm_cluster_bwd lstm comm beam skeletal; do
+  for S in ctx elementwise ctc dense gemm gemm_split lstm_simple lstm_mfma lstm_cluster lstm_cluster_bwd lstm comm beam skeletal; do
     echo "hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-unused-result $FLAGS -c $PKG/csrc/$S.hip -o $O/$S.o"
   done | xargs -P 6 -I{} sh -c "{}"
   hipcc --offload-arch=gfx950 -shared -fPIC -o $R/variants/lib_$NAME.so $O/*.o -ldl

@@ -1,0 +1,61 @@
+"""Same-box A/B of the forward cluster scans between library builds with DIFFERENT C ABIs (e.g. an older round's libmgr.so): raw ctypes,
+only the entry points every round has.  python tools/scan_ab_raw.py <lib.so> [<lib.so> ...]; SCAN_PROBE_H as tools/scan_variant_probe.py."""
+import ctypes as C, os, sys
+import numpy as np
+vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+
+
+class ScanJob(C.Structure):
+    _fields_ = [("Z", vp), ("Up", vp), ("Y", vp), ("R", vp), ("gates", vp), ("cs", vp), ("ldy", i32), ("ldr", i32), ("B", i32), ("T", i32),
+                ("H", i32), ("reverse", i32), ("YT", vp), ("ytb", C.c_longlong), ("ldt", i32), ("yt_split", i32)]
+
+
+B, T = 64, 1900
+HS = [tuple(int(h) for h in a.split("+")) for a in os.environ.get("SCAN_PROBE_H", "500+300,500").split(",")]
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+for path in sys.argv[1:]:
+    lib = C.CDLL(path)
+    lib.mgr_lstm_scan_multi_ws_bytes.restype = sz
+    lib.mgr_lstm_scan_multi_ws_bytes.argtypes = [i32, vp]
+    lib.mgr_last_error.restype = C.c_char_p
+    lib.mgr_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    lib.mgr_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    lib.mgr_h2d.argtypes = [vp, vp, vp, sz]
+    lib.mgr_lstm_scan_fwd_multi.argtypes = [vp, i32, vp, vp, sz]
+    lib.mgr_sync.argtypes = [vp]
+    lib.mgr_event_record.argtypes = [vp, i32]
+    lib.mgr_event_elapsed_ms.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
+    lib.mgr_ctx_destroy.argtypes = [vp]
+    ctx = vp()
+    assert lib.mgr_ctx_create(0, C.byref(ctx)) == 0
+
+    def alloc(n):
+        p = vp()
+        assert lib.mgr_alloc(ctx, n, C.byref(p)) == 0
+        return p
+
+    rng = np.random.default_rng(0)
+    for hs in HS:
+        jobs = []
+        for H in hs:
+            for rev in (0, 1):
+                z = (rng.standard_normal((B, T, 4 * H)) * 0.5).astype(np.float32)
+                u = (rng.standard_normal((H, 4 * H)) * 0.05).astype(np.float32)
+                Z, U, Y = alloc(z.nbytes), alloc(u.nbytes), alloc(B * T * H * 4)
+                lib.mgr_h2d(ctx, Z, z.ctypes.data, z.nbytes); lib.mgr_h2d(ctx, U, u.ctypes.data, u.nbytes)
+                jobs.append((Z, U, Y, H, rev))
+        arr = (ScanJob * len(jobs))()
+        for a, (Z, U, Y, H, rev) in zip(arr, jobs):
+            a.Z, a.Up, a.Y, a.ldy, a.B, a.T, a.H, a.reverse = Z.value, U.value, Y.value, H, B, T, H, rev
+        n = lib.mgr_lstm_scan_multi_ws_bytes(len(jobs), C.cast(arr, vp))
+        ws = alloc(n)
+        assert lib.mgr_lstm_scan_fwd_multi(ctx, len(jobs), C.cast(arr, vp), ws, n) == 0, lib.mgr_last_error()
+        lib.mgr_sync(ctx)
+        lib.mgr_event_record(ctx, 0)
+        for _ in range(4):
+            lib.mgr_lstm_scan_fwd_multi(ctx, len(jobs), C.cast(arr, vp), ws, n)
+        lib.mgr_event_record(ctx, 1)
+        ms = C.c_float()
+        lib.mgr_event_elapsed_ms(ctx, 0, 1, C.byref(ms))
+        print("%-28s H=%-10s %7.3f ms  %5.2f us/step" % (os.path.basename(path), hs, ms.value / 4, ms.value / 4 * 1e3 / T), flush=True)
+    lib.mgr_ctx_destroy(ctx)
