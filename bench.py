@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the second timed leg on the f32 MFMA kernels (tune 14 = 15 = 1)")
     ap.add_argument("--tune", action="append", default=[], help="KEY=VALUE for mgr_tune (A/B of kernel variants; may be repeated)")
     ap.add_argument("--no-transposed", action="store_true", help="dropout-aware projections gather columns of the row-major input")
+    ap.add_argument("--scan-with-fproj", action="store_true", help="the deepest encoder scan starts together with the fusion projections (round 4)")
     ap.add_argument("--no-two-ahead", action="store_true", help="the encoder stream is handed a batch's pass one call ahead only (round 4)")
     ap.add_argument("--no-split-rows", action="store_true", help="transposed copies as f32 rows, converted by every product (round 4's kernels)")
     ap.add_argument("--cpu-T", type=int, default=0, help="T of the CPU leg's sample; 0 (default) = the configuration's own T: the full step")
@@ -204,7 +205,8 @@ def main():
 
     from mgr_amd.engine import Schedule
     eng = Engine(spec, B, T, Lmax, device=dev, seed=1000 + rank, comm=comm, world=world,
-                 schedule=Schedule(transposed_inputs=not args.no_transposed, split_rows=not args.no_split_rows))
+                 schedule=Schedule(transposed_inputs=not args.no_transposed, split_rows=not args.no_split_rows,
+                                   deepest_scan_after_fusion_proj=not args.scan_with_fproj))
     eng.set_weights(synthetic_weights(spec, 20131900 + 3))
     xs, labels, il, ll = synthetic_arrays(spec, B, T, Lmax, 20131900 + 3 + 17 * rank)
     eng._upload_inputs(xs, None, True)

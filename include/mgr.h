@@ -269,6 +269,10 @@ typedef struct mgr_scan_bwd_job {
   const float* Up;
   float* dZ;
   int lddy, B, T, H, reverse;
+  /* optional: dzmax[b * 4H + col] = the largest |dZ[b, t, col]| over t as float bits - what mgr_lstm_param_grads_dropout_ts scales
+   * the rows of dZ^T by.  The multi-CU kernel keeps it in four registers of the thread that owns a (sample, unit) for all T steps
+   * (free); any other kernel family is followed by a reduction pass inside the call.  NULL: not wanted. */
+  unsigned* dzmax;
 } mgr_scan_bwd_job;
 size_t mgr_lstm_scan_bwd_multi_ws_bytes(int njobs, const mgr_scan_bwd_job* jobs);
 int mgr_lstm_scan_bwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_bwd_job* jobs, void* ws, size_t ws_bytes);
@@ -308,7 +312,8 @@ int mgr_lstm_param_grads_dropout_t(mgr_ctx* ctx, const float* XT, int ldt, const
 size_t mgr_lstm_param_grads_dropout_ts_ws_bytes(int B, int T, int F, int H, int ldt);
 int mgr_lstm_param_grads_dropout_ts(mgr_ctx* ctx, const float* XS, int ldt, const float* mask4, float drop_rate,
                                     const float* Hs, int ldh, const float* dZ, float* dWp, float* dUp, float* dbp, int B,
-                                    int T, int F, int H, int reverse, void* ws, size_t ws_bytes);
+                                    int T, int F, int H, int reverse, void* ws, size_t ws_bytes, const unsigned* dzmax);
+/* (dzmax: the row maxima of dZ if the BPTT left them - mgr_scan_bwd_job.dzmax - or NULL: this call finds them with one more pass.) */
 /* dX[b,t,0:F] (stride lddx) (+)= sum_g mask4[g] (.) (dZ_g . W_g^T); accumulate=1 adds into dX. */
 int mgr_lstm_input_grad(mgr_ctx* ctx, const float* dZ, const float* Wp, const float* mask4, float* dX,
                         int lddx, int accumulate, int B, int T, int F, int H);

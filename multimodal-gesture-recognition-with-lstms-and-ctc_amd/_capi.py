@@ -87,7 +87,7 @@ SIGNATURES = {
     "mgr_lstm_param_grads_dropout_t_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
     "mgr_lstm_param_grads_dropout_t": (i32, [vp, vp, i32, vp, C.c_float, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, C.c_float]),
     "mgr_lstm_param_grads_dropout_ts_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
-    "mgr_lstm_param_grads_dropout_ts": (i32, [vp, vp, i32, vp, C.c_float, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz]),
+    "mgr_lstm_param_grads_dropout_ts": (i32, [vp, vp, i32, vp, C.c_float, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
     "mgr_lstm_input_grad": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32]),
     "mgr_dense_softmax_fwd": (i32, [vp, vp, i32, vp, C.c_float, u64, vp, vp, vp, i32, i32, i32, i32]),
     "mgr_dense_bwd_ws_bytes": (sz, [i32, i32, i32, i32]),
@@ -129,15 +129,15 @@ class ScanJob(C.Structure):
 class ScanBwdJob(C.Structure):
     """struct mgr_scan_bwd_job"""
     _fields_ = [("dY", vp), ("gates", vp), ("cs", vp), ("Up", vp), ("dZ", vp),
-                ("lddy", i32), ("B", i32), ("T", i32), ("H", i32), ("reverse", i32)]
+                ("lddy", i32), ("B", i32), ("T", i32), ("H", i32), ("reverse", i32), ("dzmax", vp)]
 
 
 def make_scan_bwd_jobs(jobs):
     arr = (ScanBwdJob * len(jobs))()
     for a, j in zip(arr, jobs):
-        for k in ("dY", "gates", "cs", "Up", "dZ"):
-            v = j[k]
-            setattr(a, k, v.ptr if isinstance(v, DeviceArray) else v)
+        for k in ("dY", "gates", "cs", "Up", "dZ", "dzmax"):
+            v = j.get(k, 0)
+            setattr(a, k, v.ptr if isinstance(v, DeviceArray) else (v or 0))
         for k in ("lddy", "B", "T", "H", "reverse"):
             setattr(a, k, int(j[k]))
     return arr

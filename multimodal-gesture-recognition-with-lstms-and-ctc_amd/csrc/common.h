@@ -98,3 +98,6 @@ int mgr_transpose_bt_split_strided(mgr_ctx* c, const float* X, int ldx, float* X
 // dU / db of one LSTM direction (gemm.hip); ws: mgr_lstm_param_grads_ws_bytes(B, T, F, H) bytes
 int mgr_param_grads_du_db(mgr_ctx* c, const float* Hs, int ldh, const float* dZ, float* dUp, float* dbp, int B, int T, int F, int H, int reverse,
                           void* ws);
+
+// zmax[b * N + col] = largest |dZ[b, t, col]| over t as float bits (gemm_split.hip)
+int mgr_rowmax_bt(mgr_ctx* c, const float* dZ, int N, int T, int B, unsigned* zmax);

@@ -718,7 +718,7 @@ size_t mgr_lstm_param_grads_dropout_ts_ws_bytes(int B, int T, int F, int H, int 
 
 int mgr_lstm_param_grads_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const float* mask4, float drop_rate, const float* Hs, int ldh,
                                     const float* dZ, float* dWp, float* dUp, float* dbp, int B, int T, int F, int H, int reverse,
-                                    void* ws, size_t ws_bytes) {
+                                    void* ws, size_t ws_bytes, const unsigned* dzmax) {
   MGR_REQUIRE(c && XS && mask4 && Hs && dZ && dWp && dUp && dbp, "null argument");
   MGR_REQUIRE(B > 0 && T > 0 && H > 0 && F >= 16 && F <= 2048 && ldh >= H, "bad shape (16 <= F <= 2048)");
   MGR_REQUIRE(ldt % 32 == 0 && ldt >= (T + DW_TK - 1) / DW_TK * DW_TK, "the split copy must be padded to whole stages of %d time steps (ldt %d, T %d)", DW_TK, ldt, T);
@@ -744,7 +744,7 @@ int mgr_lstm_param_grads_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const 
   w += mgr_align_up((size_t)4 * B * Fp32 * H * sizeof(float), 256);
   float* dZS = reinterpret_cast<float*>(w);
   w += mgr_align_up((size_t)B * N * ldt * sizeof(float), 256);
-  unsigned* zmax = reinterpret_cast<unsigned*>(w);
+  const unsigned* zmax = dzmax ? dzmax : reinterpret_cast<unsigned*>(w);   // (the BPTT's own row maxima, or found here)
   hipStream_t s = mgr_stream(c);
   if (!(c->attr_done & 32u)) {
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dw_split<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * DW_STAGE));
@@ -753,7 +753,7 @@ int mgr_lstm_param_grads_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const 
   }
   MGR_HIP(hipMemsetAsync(words, 0, 2 * sizeof(unsigned), s));
   hipLaunchKernelGGL(k_lists32, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp32, lists, kcnt, kpos, words + 1);
-  hipLaunchKernelGGL(k_rowmax_bt, dim3((N + 63) / 64, B), dim3(256), 0, s, dZ, N, T, zmax);
+  if (!dzmax) hipLaunchKernelGGL(k_rowmax_bt, dim3((N + 63) / 64, B), dim3(256), 0, s, dZ, N, T, reinterpret_cast<unsigned*>(w));
   hipLaunchKernelGGL(k_transpose_split_scaled, dim3((ldt + 63) / 64, (N + 63) / 64, B), dim3(256), 0, s, dZ, N, dZS, ldt, T, zmax);
   const int grid = 8 * ((B + 7) / 8) * 4 * ((Fp32 + DW_BM - 1) / DW_BM) * ((H + DW_BN - 1) / DW_BN);
   // tune key 12 (the tile switch of the projection): 1 = the 4-wave form, which fits on a CU beside a workgroup of a persistent scan
@@ -781,6 +781,12 @@ int mgr_transpose_bt_split(mgr_ctx* c, const float* X, int ldx, float* XS, int l
 }
 
 }  // extern "C"
+
+int mgr_rowmax_bt(mgr_ctx* c, const float* dZ, int N, int T, int B, unsigned* zmax) {
+  hipLaunchKernelGGL(k_rowmax_bt, dim3((N + 63) / 64, B), dim3(256), 0, mgr_stream(c), dZ, N, T, zmax);
+  MGR_LAUNCH_CHECK();
+  return 0;
+}
 
 int mgr_transpose_bt_split_strided(mgr_ctx* c, const float* X, int ldx, float* XS, int ldt, long long xsb, int ldt_fill, int B, int T, int F) {
   hipLaunchKernelGGL(k_transpose_split, dim3((ldt_fill + 63) / 64, (F + 63) / 64, B), dim3(256), 0, mgr_stream(c), X, ldx, XS, ldt, T, F, xsb, ldt_fill);

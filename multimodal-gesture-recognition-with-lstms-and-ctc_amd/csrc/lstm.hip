@@ -454,7 +454,7 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
     if (!use_cluster[i]) continue;
     const mgr_scan_bwd_job& j = jobs[i];
     ClusterBwdJob& cj = L.job[L.njobs++];
-    cj.dY = j.dY; cj.gates = j.gates; cj.cs = j.cs; cj.Up = j.Up; cj.dZ = j.dZ;
+    cj.dY = j.dY; cj.gates = j.gates; cj.cs = j.cs; cj.Up = j.Up; cj.dZ = j.dZ; cj.dzmax = j.dzmax;
     cj.lddy = j.lddy; cj.B = j.B; cj.T = j.T; cj.H = j.H; cj.reverse = j.reverse;
     cj.G_ = (j.H + 15) / 16; cj.nbg = nbg[i];
     cj.cls_begin = cb[i]; cj.cls_nclusters = cn[i]; cj.cls_cluster0 = c0[i]; cj.cls_rot = cr[i];
@@ -506,6 +506,12 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
     }
     if (r < 0) return r;
   }
+  for (int i = 0; i < njobs; ++i) {   // the row maxima of dZ where the kernel that ran did not leave them itself
+    const mgr_scan_bwd_job& j = jobs[i];
+    if (!j.dzmax || use_cluster[i]) continue;
+    r = mgr_rowmax_bt(c, j.dZ, 4 * j.H, j.T, j.B, j.dzmax);
+    if (r) return r;
+  }
   r = mgr_prof_end(c, MGR_K_SCAN_BWD);
   if (r) return r;
   if (L.njobs > 0 && c->tune[1]) return check_launch_status(c, status, "cluster BPTT");
@@ -517,6 +523,7 @@ int mgr_lstm_scan_bwd(mgr_ctx* c, const float* dY, int lddy, const float* gates,
   mgr_scan_bwd_job j;
   j.dY = dY; j.gates = gates; j.cs = cs; j.Up = Up; j.dZ = dZ;
   j.lddy = lddy; j.B = B; j.T = T; j.H = H; j.reverse = reverse;
+  j.dzmax = nullptr;
   return mgr_lstm_scan_bwd_multi(c, 1, &j, ws, ws_bytes);
 }
 

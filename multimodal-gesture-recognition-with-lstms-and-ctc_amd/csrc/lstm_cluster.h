@@ -79,6 +79,7 @@ struct ClusterBwdJob {
   const float* cs;
   const float* Up;
   float* dZ;
+  unsigned* dzmax;   // optional [B][4H]: largest |dZ| over t per (sample, gate column), float bits (mgr_scan_bwd_job)
   float* xbuf;  // [nbg][2][IMG]
   int lddy, B, T, H, reverse;
   int G_, nbg;

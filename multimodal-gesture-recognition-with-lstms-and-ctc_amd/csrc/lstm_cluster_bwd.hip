@@ -169,6 +169,7 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
   // (a wait hipcc can see: with the weight loads retired here its scoreboard enters the time loop empty - lstm_cluster.hip)
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   float dcc = 0.f;
+  float4 zmx = make_float4(0.f, 0.f, 0.f, 0.f);   // largest |dz| of this thread's (sample, unit) per gate over all steps (jb.dzmax)
   f32x4 own_tile = {0.f, 0.f, 0.f, 0.f};  // the partial tile this workgroup computed for itself (held by wave ug % 4)
   bool failed = false;
   __syncthreads();
@@ -270,6 +271,7 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
       const float cp = has_prev ? rp[320 + lane] : 0.f;
       dz = mgr_cell_bwd(dh, ug4, ru[320 + lane], cp, dcc);
       if (bvalid) *reinterpret_cast<float4*>(jb.dZ + ((size_t)b * T + t) * N + unit * 4) = dz;
+      zmx = make_float4(fmaxf(zmx.x, fabsf(dz.x)), fmaxf(zmx.y, fabsf(dz.y)), fmaxf(zmx.z, fabsf(dz.z)), fmaxf(zmx.w, fabsf(dz.w)));
     }
     if (!has_prev) break;   // the first forward step has no predecessor: nothing to send (workgroup-uniform; it is the last iteration)
     if (computer) {
@@ -368,6 +370,8 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
       }
     }
   }
+  if (jb.dzmax && computer && uvalid && bvalid)   // (fmaxf drops a NaN: a NaN gradient shows in dZ itself, not here)
+    *reinterpret_cast<float4*>(jb.dzmax + (size_t)b * N + unit * 4) = zmx;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the wave ends
 }
 

@@ -64,7 +64,7 @@ class _LstmDir:
         self.gWp = self.gUp = self.gbp = None
         self.mask = None       # device [4,B,fin] when input dropout is active
         self.Z = None
-        self.gates = self.cs = self.dZ = None
+        self.gates = self.cs = self.dZ = self.dzmax = None
         self.ws_scan = self.ws_pg = self.ws_sp = None
 
 
@@ -84,6 +84,8 @@ class Schedule:
     encoders_two_ahead  (round 5; needs bptt_beside_deepest_scan) a caller that announces TWO batches ahead (enqueue_train_step's
                         prefetch_after_next) gets the first part of the batch-after-next's encoder pass enqueued at the end of a
                         step instead of at the start of the next call, which has to wait for the step's loss
+    deepest_scan_after_fusion_proj  (round 5) the next batch's deepest encoder scan is launched behind this step's fusion projections
+                        instead of at the same instant
     split_rows          (round 5) the transposed copies are written in the split row format (f16 hi / lo pairs) and the wide products
                         run as loader / matrix pipelines on pre-split operands (gemm_split.hip); False: f32 rows, converted by
                         every product that reads them (round 4's kernels)
@@ -94,7 +96,9 @@ class Schedule:
     """
 
     def __init__(self, pipeline=True, defer_param_grads=True, encoders_run_ahead=True, resident_wait_us=2000,
-                 transposed_inputs=True, bptt_beside_deepest_scan=True, split_rows=True, encoders_two_ahead=True):
+                 transposed_inputs=True, bptt_beside_deepest_scan=True, split_rows=True, encoders_two_ahead=True,
+                 deepest_scan_after_fusion_proj=True):
+        self.deepest_scan_after_fusion_proj = bool(deepest_scan_after_fusion_proj)
         self.encoders_two_ahead = bool(encoders_two_ahead)
         self.split_rows = bool(split_rows)
         self.bptt_beside_deepest_scan = bool(bptt_beside_deepest_scan)
@@ -182,6 +186,7 @@ class Engine:
                     L.gates = dev.empty((B, T, H, 4))
                     L.cs = dev.empty((B, T, H))
                     L.dZ = dev.empty((B, T, 4 * H))
+                    L.dzmax = dev.zeros((B, 4 * H), np.uint32)   # row maxima of dZ^T, left by the BPTT (mgr_scan_bwd_job.dzmax)
                     L.ws_scan = dev.bytes(self.lib.mgr_lstm_scan_ws_bytes(B, T, H))
                     need = (self.lib.mgr_lstm_param_grads_dropout_ws_bytes(B, T, fin, H) if p > 0
                             else self.lib.mgr_lstm_param_grads_ws_bytes(B, T, fin, H))
@@ -1161,8 +1166,31 @@ class Engine:
         elif free_ok:
             free_gen = self._next_encoders_free(next_inputs, depth, self.rng_step + 1, self._step_id + 1)
             next(free_gen)
+        # ---- 2., 3. fusion layer, head, CTC, loss read-back point, backward
+        finish = self._enqueue_trainable_part(cur, rand, pipelined, defer, sch.bptt_beside_deepest_scan, have is None, apply_update)
+
+        # ---- 4. parameter gradients + optimizer, and (pipelined) the next step's encoder pass
+        if not pipelined:
+            finish()
+        elif free_gen is not None:
+            free_gen.send(finish)
+            if prefetch_after_next and sch.encoders_two_ahead:
+                # the first part of the pass of the batch AFTER the next one (rng_step / _step_id were advanced above)
+                self._early_gen = self._next_encoders_free(after_next_inputs, depth, self.rng_step + 1, self._step_id + 1)
+                next(self._early_gen)
+        else:
+            self._enqueue_next_encoders(next_inputs, finish, defer, ahead, depth,
+                                        free_running=bool(defer and sch.bptt_beside_deepest_scan and sp.fusion and not any_tr_stream_))
+        self._beside_scans = False
+        dev.stream(0)
+
+    def _enqueue_trainable_part(self, cur, rand, beside_scans, defer, late_ok, own_inputs, apply_update):
+        """Steps 2 and 3 of a training step on stream 0 - fusion layer, head, CTC, the loss read-back point, the backward pass up to
+        what `defer` / `late_ok` hold back - and the closure `finish(gate=None)` that enqueues the rest (held-back BPTT, dW / dU / db
+        GEMMs, optimizer)."""
+        sp, dev, B, T = self.spec, self.dev, self.B, self.T
         # ---- 2. fusion layer, head, CTC, loss read-back point
-        self._beside_scans = bool(pipelined)
+        self._beside_scans = bool(beside_scans)
         self._enqueue_fusion_head(True, rand, cur, self.rng_step, dense=False)
         self.rng_step += 1
         Cn, D = sp.num_classes, sp.head_width
@@ -1195,7 +1223,7 @@ class Engine:
         this_step = self._step_id
         self._step_id += 1
         self._lab_user[self._lab_slot] = this_step
-        if have is None:   # this step's own inputs (a prefetched set was tagged when it was uploaded)
+        if own_inputs:   # this step's own inputs (a prefetched set was tagged when it was uploaded)
             # trainable first layers read them again in their dW GEMMs, which only the NEXT step's loss read-back covers
             self._xin_user[self._xin_slot] = this_step + (1 if any_tr_stream else 0)
         # ---- 3. backward
@@ -1205,7 +1233,7 @@ class Engine:
             Hf = sp.fusion["H"]
             bargs = ("fusion", self.dYF, 2 * Hf, self._featin, W, W, self.YF, 2 * Hf, self.dFEAT if any_tr_stream else None, W)
             bkw = dict(defer_param_grads=defer, XinT=self._featT.get(self._featin.ptr))
-            if defer and sch.bptt_beside_deepest_scan and not any_tr_stream:
+            if defer and late_ok and not any_tr_stream:
                 late_bptt = lambda: self._bilstm_backward(*bargs, **bkw)
             else:
                 deferred = self._bilstm_backward(*bargs, **bkw)
@@ -1232,20 +1260,7 @@ class Engine:
                 d()
             if apply_update:
                 self.apply_gradients()
-
-        # ---- 4. parameter gradients + optimizer, and (pipelined) the next step's encoder pass
-        if not pipelined:
-            finish()
-        elif free_gen is not None:
-            free_gen.send(finish)
-            if prefetch_after_next and sch.encoders_two_ahead:
-                # the first part of the pass of the batch AFTER the next one (rng_step / _step_id were advanced above)
-                self._early_gen = self._next_encoders_free(after_next_inputs, depth, self.rng_step + 1, self._step_id + 1)
-                next(self._early_gen)
-        else:
-            self._enqueue_next_encoders(next_inputs, finish, defer, ahead, depth, free_running=late_bptt is not None)
-        self._beside_scans = False
-        dev.stream(0)
+        return finish
 
     def _next_encoders_free(self, next_inputs, depth, rng_step, consumer_step):
         """Schedule.bptt_beside_deepest_scan, as a two-part generator.  Part 1 (before this step's fusion work is enqueued): the next
@@ -1270,6 +1285,11 @@ class Engine:
         dev.stream(0)
         finish(self._resident_gate())
         dev.wait_event(ES, self.EV_PREV)   # (the deepest scan overwrites the FEAT buffer the previous step's dW GEMMs read)
+        if self.schedule.deepest_scan_after_fusion_proj:
+            # ... and it lets THIS step's fusion projections go first: both become ready at the same instant (the end of the previous
+            # step's optimizer), and beside the scan's 408 workgroups the two GEMMs took 4.5 ms instead of 1.1 - on the chain of
+            # the stream that sets the step time, while the encoder stream has ~3 ms to spare (profiles/r05_scan_probes.txt)
+            dev.wait_event(ES, self.EV_FPROJ)
         for _ in phases:
             pass
         self._prefetched = nxt
@@ -1341,7 +1361,7 @@ class Engine:
             H = L.H
             dYv = dY.view(di * H, (1,)) if isinstance(dY, DeviceArray) else dY
             jobs.append(dict(dY=dYv, gates=L.gates, cs=L.cs, Up=L.Up, dZ=L.dZ, lddy=lddy, B=B, T=T, H=H,
-                             reverse=L.reverse))
+                             reverse=L.reverse, dzmax=L.dzmax))
         dev.stream(0)
         arr = _capi.make_scan_bwd_jobs(jobs)   # both directions in ONE call (one persistent launch of CU clusters)
         need = self.lib.mgr_lstm_scan_bwd_multi_ws_bytes(len(jobs), arr)
@@ -1359,7 +1379,7 @@ class Engine:
                 if mptr and XinT is not None and self._xt_split.get(XinT.ptr, False):
                     with self._narrow_tiles(beside_scans):
                         dev.call("mgr_lstm_param_grads_dropout_ts", XinT, self.ldt, mptr, float(L.p), Hbuf.view(di * H, (1,)), ldh, L.dZ,
-                                 L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes)
+                                 L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes, L.dzmax)
                 elif mptr and XinT is not None and self.lib.mgr_lstm_param_grads_dropout_wants_transposed(
                         dev.ctx, C.c_float(float(L.p)), int(fin)):
                     need = self.lib.mgr_lstm_param_grads_dropout_t_ws_bytes(B, T, fin, H, self.ldt)

@@ -415,7 +415,8 @@ def test_bwd_multi_matches_oracle(device, B, T, H, path, f32_mfma):
         dev.call("mgr_lstm_scan_fwd", Z, Up, Y, H, 0, 0, G, Cs, B, T, H, reverse, ws0, ws0.nbytes)
         dYd = dev.array(np.ascontiguousarray(dy).astype(f32))
         dZ = dev.empty((B, T, 4 * H))
-        jobs.append(dict(dY=dYd, gates=G, cs=Cs, Up=Up, dZ=dZ, lddy=H, B=B, T=T, H=H, reverse=reverse))
+        zm = dev.array(np.full((B, 4 * H), 0xFFFFFFFF, np.uint32))     # dirty: the call must write every word
+        jobs.append(dict(dY=dYd, gates=G, cs=Cs, Up=Up, dZ=dZ, lddy=H, B=B, T=T, H=H, reverse=reverse, dzmax=zm))
         refs.append((dx_ref, dW_ref, dU_ref, db_ref))
         outs.append((dX, Y, dZ, Wp))
     dev.call("mgr_tune", 0, path)
@@ -427,6 +428,9 @@ def test_bwd_multi_matches_oracle(device, B, T, H, path, f32_mfma):
         for rep in range(2):
             _capi.check(dev.lib.mgr_lstm_scan_bwd_multi(dev.ctx, 2, arr, ws.ptr, ws.nbytes))
             for reverse, ((dX, Y, dZ, Wp), (dx_ref, dW_ref, dU_ref, db_ref)) in enumerate(zip(outs, refs)):
+                # mgr_scan_bwd_job.dzmax: the largest |dZ| over time per (sample, gate column), whatever kernel family ran
+                zm = jobs[reverse]["dzmax"].download().view(np.float32)
+                assert np.array_equal(zm, np.abs(dZ.download()).max(axis=1))
                 gW, gU, gb = dev.empty((F, 4 * H)), dev.empty((H, 4 * H)), dev.empty((4 * H,))
                 ws2 = dev.bytes(dev.lib.mgr_lstm_param_grads_ws_bytes(B, T, F, H))
                 dev.call("mgr_lstm_param_grads", dX, F, 0, Y, H, dZ, gW, gU, gb, B, T, F, H, reverse, ws2, ws2.nbytes)

@@ -99,7 +99,12 @@ def test_weight_gradient_from_split_rows(device, B, T, F, H, p, reverse):
         gW, gU, gb = dev.empty((F, N)), dev.empty((H, N)), dev.empty((N,))
         gW.upload(np.full((F, N), np.nan, f32))
         dev.call("mgr_memset", ws, 0xFF, ws.nbytes)          # the workspace arrives dirty
-        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW, gU, gb, B, T, F, H, reverse, ws, ws.nbytes)
+        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW, gU, gb, B, T, F, H, reverse, ws, ws.nbytes, 0)
+        # ... and with the row maxima handed in (what the BPTT leaves: mgr_scan_bwd_job.dzmax): the same bits
+        zmx = dev.array(np.abs(dZ).max(axis=1).astype(f32).view(np.uint32))
+        gW3 = dev.empty((F, N))
+        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW3, gU, gb, B, T, F, H, reverse, ws, ws.nbytes, zmx)
+        assert np.array_equal(gW3.download(), gW.download())
         got = gW.download()
         colscale = np.maximum(np.abs(ref).max(axis=0, keepdims=True), 1e-30)      # per column: the spread is per column
         assert np.all(np.isfinite(got)) and (np.abs(got - ref) / colscale).max() <= 3e-5, (spread, (np.abs(got - ref) / colscale).max())
