@@ -335,57 +335,47 @@ __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_proj_split(const 
             cA[j][x2] = sb + offA[j][x2];
             cB[j][x2] = sb + C::A_BYTES + offB[j][x2];
           }
-        tr4 fa[2][2][2][2], fb[2][2][2];   // A: [k-step][row block][plane][read], B: [k-step][plane][read]
-#define PS_TR(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr) : "memory")
-#define PS_READS(KS, AOFF0, AOFF1, BOFF)                    \
-  PS_TR(fa[KS][0][0][0], cA[0][0], AOFF0);                  \
-  PS_TR(fa[KS][0][0][1], cA[1][0], AOFF0);                  \
-  PS_TR(fb[KS][0][0], cB[0][0], BOFF);                      \
-  PS_TR(fb[KS][0][1], cB[1][0], BOFF);                      \
-  PS_TR(fa[KS][1][0][0], cA[0][1], AOFF0);                  \
-  PS_TR(fa[KS][1][0][1], cA[1][1], AOFF0);                  \
-  PS_TR(fa[KS][0][1][0], cA[0][0], AOFF1);                  \
-  PS_TR(fa[KS][0][1][1], cA[1][0], AOFF1);                  \
-  PS_TR(fa[KS][1][1][0], cA[0][1], AOFF1);                  \
-  PS_TR(fa[KS][1][1][1], cA[1][1], AOFF1);                  \
-  PS_TR(fb[KS][1][0], cB[0][1], BOFF);                      \
-  PS_TR(fb[KS][1][1], cB[1][1], BOFF);
-        PS_READS(0, 0, 256, 0)
-        if constexpr (WC == 2) {
-          PS_READS(1, 8192, 8448, 4096)
-        } else {
-          PS_READS(1, 8192, 8448, 8192)
-        }
-#undef PS_READS
-#undef PS_TR
-#define PS_WAIT(KS, CNT)                                                                                                          \
-  asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                                      \
-               : "+v"(fa[KS][0][0][0]), "+v"(fa[KS][0][0][1]), "+v"(fa[KS][0][1][0]), "+v"(fa[KS][0][1][1]), "+v"(fa[KS][1][0][0]), \
-                 "+v"(fa[KS][1][0][1]), "+v"(fa[KS][1][1][0]), "+v"(fa[KS][1][1][1]), "+v"(fb[KS][0][0]), "+v"(fb[KS][0][1]),       \
-                 "+v"(fb[KS][1][0]), "+v"(fb[KS][1][1])                                                                            \
-               :                                                                                                                   \
+        // ONE asm statement per k-step: its 12 reads AND the wait for them.  The destination of an LDS read is written when the data
+        // arrive, not when the instruction issues: a destination that the compiler can see before the wait may be COPIED by it while
+        // the read is in flight (round 5 found exactly that in k_dw_split: a v_mov_b64 of a fragment in front of the s_waitcnt, 3 NaN
+        // rows in one run of ten when two processes shared the GPU).  Inside one statement nothing can come between; the next k-step's
+        // reads still fly under this k-step's MFMAs, which are queued in the matrix pipe by then.
+#define PS_KSTEP(FA, FB, AOFF0, AOFF1, BOFF)                                                                                          \
+  asm volatile("ds_read_b64_tr_b16 %0, %12 offset:" #AOFF0 "\n\tds_read_b64_tr_b16 %1, %13 offset:" #AOFF0                             \
+               "\n\tds_read_b64_tr_b16 %8, %16 offset:" #BOFF "\n\tds_read_b64_tr_b16 %9, %17 offset:" #BOFF                            \
+               "\n\tds_read_b64_tr_b16 %4, %14 offset:" #AOFF0 "\n\tds_read_b64_tr_b16 %5, %15 offset:" #AOFF0                          \
+               "\n\tds_read_b64_tr_b16 %2, %12 offset:" #AOFF1 "\n\tds_read_b64_tr_b16 %3, %13 offset:" #AOFF1                          \
+               "\n\tds_read_b64_tr_b16 %6, %14 offset:" #AOFF1 "\n\tds_read_b64_tr_b16 %7, %15 offset:" #AOFF1                          \
+               "\n\tds_read_b64_tr_b16 %10, %18 offset:" #BOFF "\n\tds_read_b64_tr_b16 %11, %19 offset:" #BOFF                          \
+               "\n\ts_waitcnt lgkmcnt(0)"                                                                                              \
+               : "=&v"(FA[0][0][0]), "=&v"(FA[0][0][1]), "=&v"(FA[0][1][0]), "=&v"(FA[0][1][1]), "=&v"(FA[1][0][0]), "=&v"(FA[1][0][1]), \
+                 "=&v"(FA[1][1][0]), "=&v"(FA[1][1][1]), "=&v"(FB[0][0]), "=&v"(FB[0][1]), "=&v"(FB[1][0]), "=&v"(FB[1][1])               \
+               : "v"(cA[0][0]), "v"(cA[1][0]), "v"(cA[0][1]), "v"(cA[1][1]), "v"(cB[0][0]), "v"(cB[1][0]), "v"(cB[0][1]), "v"(cB[1][1])   \
                : "memory")
+        auto frag = [](tr4 x0, tr4 x1) {
+          const tr8 v = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+          return __builtin_bit_cast(f16x8, v);
+        };
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          // (LDS operations return in order; a scalar load that may be outstanding beside them only makes a counted wait longer)
-          if (ks == 0)
-            PS_WAIT(0, 12);
-          else
-            PS_WAIT(1, 0);
-          auto frag = [](tr4 a, tr4 b2) {
-            const tr8 v = __builtin_shufflevector(a, b2, 0, 1, 2, 3, 4, 5, 6, 7);
-            return __builtin_bit_cast(f16x8, v);
-          };
-          const f16x8 bh = frag(fb[ks][0][0], fb[ks][0][1]), bl = frag(fb[ks][1][0], fb[ks][1][1]);
+          tr4 fa[2][2][2], fb[2][2];   // A: [row block][plane][read], B: [plane][read]
+          if (ks == 0) {
+            PS_KSTEP(fa, fb, 0, 256, 0);
+          } else if constexpr (WC == 2) {
+            PS_KSTEP(fa, fb, 8192, 8448, 4096);
+          } else {
+            PS_KSTEP(fa, fb, 8192, 8448, 8192);
+          }
+          const f16x8 bh = frag(fb[0][0], fb[0][1]), bl = frag(fb[1][0], fb[1][1]);
 #pragma unroll
           for (int mb = 0; mb < 2; ++mb) {
-            const f16x8 ah = frag(fa[ks][mb][0][0], fa[ks][mb][0][1]), al = frag(fa[ks][mb][1][0], fa[ks][mb][1][1]);
+            const f16x8 ah = frag(fa[mb][0][0], fa[mb][0][1]), al = frag(fa[mb][1][0], fa[mb][1][1]);
             acc[g][mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[g][mb], 0, 0, 0);
             acc[g][mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[g][mb], 0, 0, 0);
             acc[g][mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[g][mb], 0, 0, 0);
           }
         }
-#undef PS_WAIT
+#undef PS_KSTEP
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the re-issued last stages: nothing of this workgroup's LDS is in flight at exit)
@@ -558,55 +548,38 @@ __global__ __launch_bounds__(64 * NW, 1) void k_dw_split(const char* __restrict_
     __syncthreads();
     issue(n + PD);
     const unsigned sb = lds0 + (unsigned)(n % NBUF) * DW_STAGE;
-    dw_f4 fa[2][MB][2], fb[2][2][2];   // [k-step][block][part]
-#define DW_RD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr) : "memory")
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {     // the reads of both k-steps first: the second set lands under the first set's MFMAs
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const unsigned ca = sb + oA[mb][ks];
-        DW_RD(fa[ks][mb][0], ca, 0);
-        DW_RD(fa[ks][mb][1], ca, 8192);
-      }
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        const unsigned cb = sb + oB[nb][ks];
-        DW_RD(fb[ks][nb][0], cb, 0);
-        DW_RD(fb[ks][nb][1], cb, 8192);
-      }
-    }
-#undef DW_RD
-    // (explicit waits with the fragments as operands: no MFMA can be scheduled in front of the wait that covers its operands;
-    // LDS operations return in order: 2 MB + 4 reads of the second k-step may stay in flight at the first wait)
-#define DW_WAIT(KS, CNT)                                                                                                              \
-  asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                                          \
-               : "+v"(fa[KS][0][0]), "+v"(fa[KS][0][1]), "+v"(fa[KS][MB - 1][0]), "+v"(fa[KS][MB - 1][1]), "+v"(fb[KS][0][0]), "+v"(fb[KS][0][1]), \
-                 "+v"(fb[KS][1][0]), "+v"(fb[KS][1][1])                                                                                \
-               :                                                                                                                       \
-               : "memory")
+    // ONE asm statement per k-step: its reads AND the wait for them (see k_proj_split: a fragment the compiler can see before the
+    // wait may be copied while the read is in flight)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      if (ks == 0) {
-        if constexpr (MB == 1)
-          DW_WAIT(0, 6);
-        else
-          DW_WAIT(0, 8);
-      } else {
-        DW_WAIT(1, 0);
-      }
+      dw_f4 fa[MB][2], fb[2][2];   // [block][part]
+      const unsigned ca0 = sb + oA[0][ks], ca1 = sb + oA[MB - 1][ks], cb0 = sb + oB[0][ks], cb1 = sb + oB[1][ks];
+      if constexpr (MB == 1)
+        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %2, %7\n\tds_read_b128 %4, %8\n\tds_read_b128 %1, %6 offset:8192"
+                     "\n\tds_read_b128 %3, %7 offset:8192\n\tds_read_b128 %5, %8 offset:8192\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(fa[0][0]), "=&v"(fa[0][1]), "=&v"(fb[0][0]), "=&v"(fb[0][1]), "=&v"(fb[1][0]), "=&v"(fb[1][1])
+                     : "v"(ca0), "v"(cb0), "v"(cb1)
+                     : "memory");
+      else
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %4, %10\n\tds_read_b128 %6, %11\n\tds_read_b128 %2, %9"
+                     "\n\tds_read_b128 %1, %8 offset:8192\n\tds_read_b128 %5, %10 offset:8192\n\tds_read_b128 %7, %11 offset:8192"
+                     "\n\tds_read_b128 %3, %9 offset:8192\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(fa[0][0]), "=&v"(fa[0][1]), "=&v"(fa[MB - 1][0]), "=&v"(fa[MB - 1][1]), "=&v"(fb[0][0]), "=&v"(fb[0][1]),
+                       "=&v"(fb[1][0]), "=&v"(fb[1][1])
+                     : "v"(ca0), "v"(ca1), "v"(cb0), "v"(cb1)
+                     : "memory");
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const f16x8 ah = __builtin_bit_cast(f16x8, fa[ks][mb][0]), al = __builtin_bit_cast(f16x8, fa[ks][mb][1]);
+        const f16x8 ah = __builtin_bit_cast(f16x8, fa[mb][0]), al = __builtin_bit_cast(f16x8, fa[mb][1]);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
-          const f16x8 bh = __builtin_bit_cast(f16x8, fb[ks][nb][0]), bl = __builtin_bit_cast(f16x8, fb[ks][nb][1]);
+          const f16x8 bh = __builtin_bit_cast(f16x8, fb[nb][0]), bl = __builtin_bit_cast(f16x8, fb[nb][1]);
           acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[mb][nb], 0, 0, 0);
           acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[mb][nb], 0, 0, 0);
           acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[mb][nb], 0, 0, 0);
         }
       }
     }
-#undef DW_WAIT
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const float cf = __uint_as_float(*cword) * (1.f / XS_SCALE);

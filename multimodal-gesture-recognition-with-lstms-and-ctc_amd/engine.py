@@ -1046,12 +1046,16 @@ class Engine:
         lb = self.loss_b.download()
         return self._end_pass(blk.download(), lb)
 
-    def train_step(self, inputs, labels, input_length, label_length, rand=None, apply_update=True, next_inputs=None):
+    def train_step(self, inputs, labels, input_length, label_length, rand=None, apply_update=True, next_inputs=None,
+                   after_next_inputs=None):
         """One optimizer step (Keras train_on_batch).  Returns the mean CTC loss of the local batch.
         next_inputs (optional): the inputs of the FOLLOWING call; when the encoders are frozen their pass for that batch
-        is overlapped with this step's fusion / BPTT / Adam work (bit-identical results)."""
+        is overlapped with this step's fusion / BPTT / Adam work (bit-identical results); after_next_inputs: those of the call
+        after that (the encoder stream gets the first part of its pass a call early)."""
         self.enqueue_train_step(inputs, labels, input_length, label_length, rand, apply_update,
-                                prefetch_next=next_inputs is not None, next_inputs=next_inputs)
+                                prefetch_next=next_inputs is not None, next_inputs=next_inputs,
+                                prefetch_after_next=next_inputs is not None and after_next_inputs is not None,
+                                after_next_inputs=after_next_inputs)
         return self.read_loss()
 
     LOSS_STREAM = 6   # (pipelined inference: decode / result copies)

@@ -426,10 +426,11 @@ class Model:
                                       "path, multimodal.py:206-208) - compile(optimizer=Adam(...)) before training"
                                       % type(self.optimizer).__name__)
 
-    def train_on_batch(self, x, y=None, rand=None, next_x=None, _lagged=False):
+    def train_on_batch(self, x, y=None, rand=None, next_x=None, _lagged=False, after_next_x=None):
         """next_x: the batch of the FOLLOWING call (fit_generator passes it): with frozen encoders the engine overlaps
-        that batch's encoder pass with this step's trainable part.  Data parallel: returns the mean over the GLOBAL batch
-        (Engine.read_global_loss), the same number on every rank."""
+        that batch's encoder pass with this step's trainable part; after_next_x: the batch of the call after that - the
+        encoder stream is handed the first part of its pass a call early (Engine.enqueue_train_step, prefetch_after_next).
+        Data parallel: returns the mean over the GLOBAL batch (Engine.read_global_loss), the same number on every rank."""
         self._require_trainable()
         ins = self._cached_split(x)
         first = next(iter(ins.values()))
@@ -437,13 +438,14 @@ class Model:
         labels = np.asarray(x["the_labels"])
         e = self._ensure_engine(B, T, labels.shape[1])
         nxt = self._cached_split(next_x) if next_x is not None else None
+        nxt2 = self._cached_split(after_next_x) if (after_next_x is not None and nxt is not None) else None
         if not _lagged:
-            return e.train_step(ins, labels, x["input_length"], x["label_length"], rand=rand, next_inputs=nxt)
+            return e.train_step(ins, labels, x["input_length"], x["label_length"], rand=rand, next_inputs=nxt, after_next_inputs=nxt2)
         # fit_generator, world > 1: the global loss arrives with the gradient all-reduce at the END of the step; waiting for it
         # here would leave the device idle while the host assembles the next batch - pace on the local loss, collect the global
         # one a step later (Engine.read_global_loss)
         e.enqueue_train_step(ins, labels, x["input_length"], x["label_length"], rand, True, prefetch_next=nxt is not None,
-                             next_inputs=nxt)
+                             next_inputs=nxt, prefetch_after_next=nxt2 is not None, after_next_inputs=nxt2)
         e.read_loss(local=True)
         return e._step_id - 1
 
@@ -451,11 +453,12 @@ class Model:
         """_split_inputs with identity preserved across calls (the engine matches a prefetched batch by identity).
         The cache entry holds a reference to `x` itself and is matched with `is`: an `id()` key alone can be reused by
         CPython for a NEW batch as soon as the old dict is freed, which would silently train on stale inputs."""
-        c = getattr(self, "_split_cache", None)
-        if c is not None and c[0] is x:
-            return c[1]
+        c = getattr(self, "_split_cache", None) or []
+        for cx, cins in c:
+            if cx is x:
+                return cins
         ins = self._split_inputs(x)
-        self._split_cache = (x, ins)
+        self._split_cache = (c + [(x, ins)])[-3:]     # (the batch of this call and the two announced behind it)
         return ins
 
     def test_on_batch(self, x, y=None, rand=None):
@@ -502,11 +505,13 @@ class Model:
             owed = None       # (data parallel) id of the step whose global loss has not been collected yet
             skipped0 = self._engine.updates_skipped if self._engine is not None else 0
             pending = next(generator) if steps_per_epoch > 0 else None
+            pending2 = next(generator) if steps_per_epoch > 1 else None
             for step in range(steps_per_epoch):
                 x, y = pending
-                # fetch the next batch early (never across an epoch boundary: on_epoch_end reshuffles the file lists)
-                pending = next(generator) if step + 1 < steps_per_epoch else None
-                r = self.train_on_batch(x, y, next_x=pending[0] if pending is not None else None, _lagged=lagged)
+                # fetch the next TWO batches early (never across an epoch boundary: on_epoch_end reshuffles the file lists)
+                pending, pending2 = pending2, (next(generator) if step + 2 < steps_per_epoch else None)
+                r = self.train_on_batch(x, y, next_x=pending[0] if pending is not None else None, _lagged=lagged,
+                                        after_next_x=pending2[0] if pending2 is not None else None)
                 if lagged:
                     if owed is not None:
                         losses.append(self._engine.read_global_loss(owed))
