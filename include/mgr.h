@@ -329,9 +329,10 @@ size_t mgr_dense_bwd_ws_bytes(int B, int T, int D, int C);
 int mgr_dense_bwd(mgr_ctx* ctx, const float* A, int lda, const float* dmask, float p, uint64_t seed,
                   const float* dLogits, const float* Wd, float* dWd, float* dbd, float* dA, int ldda, int B,
                   int T, int D, int C, void* ws, size_t ws_bytes);
-/* The whole head of a training step in ONE call: Dropout -> Dense -> softmax (P written), CTC loss + gradient, Dense backward, and the
- * mean loss if loss_mean != NULL (written between the CTC kernel and the Dense backward, so a read-back of it does not wait for the
- * backward).  Reference: multimodal_fusion/multimodal.py:171-179 (Dropout / Dense / Activation('softmax')), losses.py:4-15
+/* The whole head of a training step behind ONE entry point - a host-side sequence of four launches on the context's stream
+ * (k_dense_softmax_fwd*, k_ctc, k_mean, k_dense_bwd*), NOT a fused kernel: Dropout -> Dense -> softmax (P written), CTC loss +
+ * gradient, Dense backward, and the mean loss if loss_mean != NULL (written between the CTC kernel and the Dense backward, so a
+ * read-back of it does not wait for the backward).  Reference: multimodal_fusion/multimodal.py:171-179 (Dropout / Dense / Activation('softmax')), losses.py:4-15
  * (ctc_lambda_func) and Keras' backward pass through them.  Bit for bit the results of mgr_dense_softmax_fwd + mgr_ctc_loss_grad
  * (+ mgr_mean) + mgr_dense_bwd with the same arguments; dLogits [B,T,C] is a required scratch / output; ws >= mgr_head_ws_bytes. */
 size_t mgr_head_ws_bytes(int B, int T, int D, int C, int Lmax);

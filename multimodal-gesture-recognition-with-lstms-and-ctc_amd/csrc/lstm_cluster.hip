@@ -618,16 +618,29 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // the f16 nearest to x among those whose last mantissa bit is `lsb`, given bits = rn_f16(x): bits itself, or its neighbour on the
 // side x lies on (the f16 bit patterns of one sign are ordered like their magnitudes, exponent boundaries included; x is finite
 // and far below the f16 maximum here)
-__device__ __forceinline__ unsigned k16_with_lsb(unsigned bits, unsigned lsb, float x) {
-  if ((bits & 1u) == lsb) return bits;
-  const unsigned mag = bits & 0x7FFFu;
-  const float v = (float)__builtin_bit_cast(_Float16, (unsigned short)mag);
-  const unsigned m2 = (mag == 0u || fabsf(x) >= v) ? mag + 1u : mag - 1u;
-  return (bits & 0x8000u) | m2;
+__device__ __forceinline__ unsigned k16_with_lsb(unsigned bits, unsigned lsb, float x, unsigned on) {   // on = 0: bits as they are
+  // branch-free (the step is one dependent chain; a divergent branch costs it more than these six instructions): bits + 1 is the next
+  // magnitude of the same sign, bits - 1 the previous one (never below zero: |x| >= 0 picks + 1 there; far below the f16 maximum)
+  const unsigned need = (bits ^ lsb) & on;
+  const float v = (float)__builtin_bit_cast(_Float16, (unsigned short)(bits & 0x7FFFu));
+  return bits + (fabsf(x) >= v ? need : 0u - need);
 }
 constexpr int K16_TILE = 260 * 4;   // floats of one tile's partial sums: 4 source waves x 64 cells x f32x4, + 4 cells of padding
 constexpr int K16_LDS_FLOATS = 2 * 4 * K16_TILE + 4 * KS_STG * 64 + 4 * 2 * 256 + 4 * 2 * 64 + 16;
 
+#ifdef MGR_STAMP
+__device__ unsigned long long g_stamps[64];
+#define KSTAMP(i, dep) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory"); \
+    st_acc[i] += t_ - st_prev; st_prev = t_; } while (0)
+extern "C" int mgr_debug_stamps(unsigned long long* out) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+  unsigned long long z[64] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
+  return 0;
+}
+#else
+#define KSTAMP(i, dep) do { } while (0)
+#endif
 template <int NBW>   // K-blocks (of 32 units) per wave: H <= 128 * NBW
 __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const ClusterCommon& cm, int bg, int ug, float* smem, bool fast) {
   static_assert(NBW >= 1 && NBW <= 4, "1..4 K-blocks per wave (H <= 512)");
@@ -728,12 +741,11 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
   const int zunit = cvalid ? unit : 0;   // (padding cells fetch a valid address and ignore it)
   const unsigned zvoff = (unsigned)(((size_t)bc * T * N + (size_t)zunit * 4) * sizeof(float));
   const unsigned rvoff = Rp ? (unsigned)(((size_t)bc * T * ldr + zunit) * sizeof(float)) : 0u;
-  auto prefetch = [&](int step) {   // (everything wave-uniform except the lane offsets)
-    if (step < T) {
-      const int t = reverse ? T - 1 - step : step;
-      mgr_dma_b128(Z + (size_t)t * N, zvoff, zring_lds + (step & 1) * 1024);
-      if (Rp) mgr_dma_b32(Rp + (size_t)t * ldr, rvoff, rring_lds + (step & 1) * 256);
-    }
+  auto prefetch = [&](int step) {   // (everything wave-uniform except the lane offsets; no branch on the last step: it re-fetches
+    const int sc = step < T ? step : T - 1;   //  its own row into the ring slot nobody reads any more, retired behind the loop)
+    const int t = reverse ? T - 1 - sc : sc;
+    mgr_dma_b128(Z + (size_t)t * N, zvoff, zring_lds + (step & 1) * 1024);
+    if (Rp) mgr_dma_b32(Rp + (size_t)t * ldr, rvoff, rring_lds + (step & 1) * 256);
   };
   prefetch(0);
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the weight loads are retired before the time loop (see cluster_run_ks)
@@ -760,6 +772,10 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
     }
   };
 
+#ifdef MGR_STAMP
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev));
+#endif
   for (int step = 0; step < T; ++step) {
     const int t = reverse ? T - 1 - step : step;
     f32x4 acc[4];
@@ -774,6 +790,9 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
           v[2 * i] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i], sbase, 16);              // sc1
           v[2 * i + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i] + 1024u, sbase, 16);   // sc1
         }
+        // (both chains, selected afterwards: a branch on the wave-uniform parity would save 16 of these 32 three-input operations, but
+        //  hipcc then merges its wait-count scoreboard over a path that runs neither chain and waits for the gathered blocks - and with
+        //  them for the Z prefetch issued in between - inside the MFMA chain: +240 cycles per step, measured)
         unsigned a_and = 0xFFFFFFFFu, a_or = 0u;
 #pragma unroll
         for (int i = 0; i < 2 * NBW; ++i) {
@@ -786,6 +805,7 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
         if (failed) break;
       }
     }
+    KSTAMP(0, v[0].x);
     if (gather && !failed) {
 #pragma unroll
       for (int i = 0; i < NBW; ++i) {
@@ -807,6 +827,7 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
     float* rbuf = red + (step & 1) * (4 * K16_TILE);
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(rbuf + tt * K16_TILE + (wave * 64 + wslot) * 4) = acc[tt];
+    KSTAMP(1, acc[0][0]);
     if (Rp)
       asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else
@@ -814,6 +835,7 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
     const f32x4 zt = *reinterpret_cast<const f32x4*>(zring + (step & 1) * 256 + lane * 4);
     const float rt = Rp ? rring[(step & 1) * 64 + lane] : 0.f;
     __syncthreads();
+    KSTAMP(2, zt[0]);
     const unsigned par = (((unsigned)step >> 1) & 1u) ^ 1u;
     unsigned packed = par | (par << 16);   // a padding cell: (hi, lo) = (0, 0) with the current parity
     float h = 0.f, yv = 0.f;
@@ -827,14 +849,9 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
 #pragma unroll
       for (int g = 0; g < 4; ++g) tot[g] = fmaf(sum[g], inv, zt[g]);
       h = mgr_cell_fwd(tot[0], tot[1], tot[2], tot[3], c, g4);
-      if (!(fabsf(h) < 2.f) && !nonfinite) {
-        __hip_atomic_fetch_or(cm.sticky, MGR_ST_NONFINITE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        nonfinite = true;
-      }
-      if (nonfinite) {
-        h = 0.f;
-        c = 0.f;
-      }
+      nonfinite |= !(fabsf(h) < 2.f);   // (latched; reported once, behind the time loop)
+      h = nonfinite ? 0.f : h;
+      c = nonfinite ? 0.f : c;
       yv = nonfinite ? __uint_as_float(0x7FC00000u) : h;
       // h 2^15 = hi + lo.  The epoch parity rides in bit 0 of each published word: the last mantissa bit of the EVEN unit's hi (word
       // (hi_even, hi_odd)) and of the even unit's lo (word (lo_even, lo_odd)).  The bit is not forced: the value moves to the NEAREST
@@ -846,15 +863,16 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
       float hs = h * 32768.f;
       asm volatile("" : "+v"(hs));   // (as above)
       unsigned hib = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)hs);
-      if (!(lane & 1)) hib = k16_with_lsb(hib, par, hs);
+      hib = k16_with_lsb(hib, par, hs, ~lane & 1u);
       const float hif = (float)__builtin_bit_cast(_Float16, (unsigned short)hib);
       float ls = hs - hif;
       asm volatile("" : "+v"(ls));
       unsigned lob = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)ls);
-      if (!(lane & 1)) lob = k16_with_lsb(lob, par, ls);
+      lob = k16_with_lsb(lob, par, ls, ~lane & 1u);
       packed = hib | (lob << 16);
     }
-    if (step + 1 < T) {
+    KSTAMP(3, packed);
+    {   // (the last step publishes too: nobody reads it, and the step has one branch less)
       const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)packed, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: the pair's other lane
       const unsigned w = (lane & 1) ? ((other >> 16) | (packed & 0xFFFF0000u))      // (lo_even, lo_odd)
                                     : ((packed & 0xFFFFu) | (other << 16));         // (hi_even, hi_odd)
@@ -863,6 +881,7 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
       else
         __builtin_amdgcn_raw_buffer_store_b32(w, rs, poff, (step & 1) * IMGB, 16);  // sc1
     }
+    KSTAMP(4, packed);
     if (cvalid && bvalid) {
       size_t row = (size_t)b * T + t;
       const float yo = yv + rt;
@@ -880,8 +899,22 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
         }
       }
     }
+    KSTAMP(5, yv);
   }
-  if (nonfinite) mgr_mark_sample(cm, b);   // (latched: marked once, behind the time loop)
+#ifdef MGR_STAMP
+  if (lane == 0) {
+    const int cls = (H > 400 ? 0 : 1) * 16;
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_stamps[cls + i], st_acc[i]);
+    atomicAdd(&g_stamps[cls + 8], (unsigned long long)T);
+    atomicAdd(&g_stamps[cls + 9], (unsigned long long)rounds);
+    if (wave == 0 && ug == 0 && bg == 0 && !reverse) for (int i = 0; i < 6; ++i) g_stamps[32 + cls / 2 + i] = st_acc[i];
+  }
+#endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last step's ring re-fetch: no LDS-DMA may outlive the workgroup)
+  if (nonfinite) {   // (latched: reported and marked once, behind the time loop)
+    __hip_atomic_fetch_or(cm.sticky, MGR_ST_NONFINITE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mgr_mark_sample(cm, b);
+  }
   if (ytrow) ks_zero_tail(ytrow, T, jb.ldt, yt_split);
 }
 
@@ -1135,12 +1168,12 @@ __device__ __forceinline__ void cluster_run_k16p(const ClusterJob& jb, const Clu
       float hs = h * 32768.f;   // (the flag bits: cluster_run_k16)
       asm volatile("" : "+v"(hs));
       unsigned hib = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)hs);
-      if (!(lane & 1)) hib = k16_with_lsb(hib, par, hs);
+      hib = k16_with_lsb(hib, par, hs, ~lane & 1u);
       const float hif = (float)__builtin_bit_cast(_Float16, (unsigned short)hib);
       float ls = hs - hif;
       asm volatile("" : "+v"(ls));
       unsigned lob = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)ls);
-      if (!(lane & 1)) lob = k16_with_lsb(lob, par, ls);
+      lob = k16_with_lsb(lob, par, ls, ~lane & 1u);
       packed = hib | (lob << 16);
     }
     if (step + 1 < T) {

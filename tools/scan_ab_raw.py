@@ -58,4 +58,14 @@ for path in sys.argv[1:]:
         ms = C.c_float()
         lib.mgr_event_elapsed_ms(ctx, 0, 1, C.byref(ms))
         print("%-28s H=%-10s %7.3f ms  %5.2f us/step" % (os.path.basename(path), hs, ms.value / 4, ms.value / 4 * 1e3 / T), flush=True)
+        if hasattr(lib, "mgr_debug_stamps"):   # a -DMGR_STAMP build: cycles per phase of the k16 step, averaged over all waves
+            out = (C.c_ulonglong * 64)()
+            lib.mgr_debug_stamps(out)
+            for cls, name in ((0, "H>400"), (16, "H<=400")):
+                if out[cls + 8]:
+                    n = float(out[cls + 8])
+                    print("   %-7s cycles/step: gather %5.0f | mfma+partials %5.0f | wait+barrier %5.0f | reduce+cell+flags %5.0f | publish %5.0f | outputs %5.0f"
+                          "  (sum %5.0f; %.3f re-fetch rounds/step)" % ((name,) + tuple(out[cls + i] / n for i in range(6))
+                                                                         + (sum(out[cls + i] for i in range(6)) / n, out[cls + 9] / n)))
+                    print("   %-7s one wave (wg 0, wave 0):  %s" % (name, " ".join("%5.0f" % (out[32 + cls // 2 + i] / float(T)) for i in range(6))))
     lib.mgr_ctx_destroy(ctx)
