@@ -198,8 +198,12 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
  * key 13: 1 = mgr_dense_softmax_fwd / mgr_dense_bwd keep their LDS-tiled vector-ALU kernels where the matrix-core forms would run.
  * key 14: K-split scan step: 0 = recurrent product on the f16 matrix pipe with every f32 operand split into an f16 (hi, lo) pair and
  *        f32 accumulation (22+ significant bits per operand; lstm_cluster.hip cluster_run_k16), 1 = v_mfma_f32_16x16x4_f32.
- * key 15: 1 = the transposed-input projection / parameter-gradient GEMMs keep their f32 MFMA kernels whatever bound the caller states. */
-enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 16 };
+ * key 15: 1 = the transposed-input projection / parameter-gradient GEMMs keep their f32 MFMA kernels whatever bound the caller states.
+ * key 16: 1 = the BPTT of narrow layers (H <= 128) launched next runs BESIDE persistent scans of another stream: it takes the form that
+ *         yields to them (two barriers, partial sums through LDS) instead of the one trimmed along its dependent chain, which is faster
+ *         alone (H = 100: 1.77 against 2.29 us per step) and costs the step beside them; same results bit for bit.  The engine sets it
+ *         from its schedule (a deterministic choice: it never depends on what happens to be running). */
+enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 24 };
 int mgr_tune(mgr_ctx* ctx, int key, int value);
 int mgr_tune_get(mgr_ctx* ctx, int key, int* value);   /* what a key is set to (a host of the library that lays out buffers by it) */
 /* Health of the persistent multi-CU scans launched on this context since the last mgr_scan_status_clear: *out receives the OR

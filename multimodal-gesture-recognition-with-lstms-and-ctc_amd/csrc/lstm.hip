@@ -470,7 +470,7 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
     r = mgr_persist_admit(c, grid, waves, per_cu, &L.cm.seq);
     if (r) return r;
     MGR_HIP(hipMemsetAsync(base, 0, (size_t)(w - base), mgr_stream(c)));
-    r = mgr_cluster_bwd_launch(c, L, grid);
+    r = mgr_cluster_bwd_launch(c, L, grid, c->tune[16] == 0);
     if (r) return r;
     r = mgr_persist_commit(c, grid, waves, per_cu);
     if (r) return r;

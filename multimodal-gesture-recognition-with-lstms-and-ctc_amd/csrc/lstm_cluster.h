@@ -94,7 +94,7 @@ struct ClusterBwdLaunch {
 bool mgr_cluster_bwd_supported(int H);
 size_t mgr_cluster_bwd_img_floats(int H);
 void mgr_cluster_bwd_geometry(const mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs, int* waves, int* per_cu);
-int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs);
+int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs, bool alone);
 
 // ---- admission of persistent launches (lstm.hip): co-residency by construction across the streams of a context
 int mgr_persist_admit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu, unsigned* seq_out);

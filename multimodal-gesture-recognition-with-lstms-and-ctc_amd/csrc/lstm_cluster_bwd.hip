@@ -32,7 +32,11 @@ typedef __attribute__((address_space(3))) float lds_float;
 constexpr unsigned POLL_LIMIT = 1u << 20;
 constexpr int BW_WAVES = 4;
 constexpr int BW_RING_FLOATS = 3 * (256 + 64 + 64);   // per compute wave: 3 slots x { gates [64] float4 | dy [64] | c [64] }
-constexpr int BW_LDS_FLOATS = 4 * 256 + 5 * 256 + BW_WAVES * BW_RING_FLOATS + 16;   // (+16: the four dz factors of the split-f16 form)
+constexpr int BW16_RING_FLOATS = 4 * (256 + 64 + 64);  // cluster_bwd_run16: 4 slots, fetched three steps ahead
+constexpr int BW16_IMG = 4 * 2 * 64 * 2;               // cluster_bwd_run16: floats of one B-operand image: [source wave][hi | lo][lane] 8 bytes
+constexpr int BW_LDS_FLOATS_A = 4 * 256 + 5 * 256 + BW_WAVES * BW_RING_FLOATS + 16;   // (+16: the four dz factors of the split-f16 form)
+constexpr int BW_LDS_FLOATS_B = 2 * BW16_IMG + 16 + BW_WAVES * BW16_RING_FLOATS + 1024;
+constexpr int BW_LDS_FLOATS = BW_LDS_FLOATS_A > BW_LDS_FLOATS_B ? BW_LDS_FLOATS_A : BW_LDS_FLOATS_B;   // (what a caller may assume at most)
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // LDS-DMA: one wave-instruction copies 64 x 16 B (64 x 4 B) from global memory [gbase + voff] (gbase wave-uniform, voff per
@@ -64,6 +68,30 @@ __device__ __forceinline__ void mgr_dma_b32(const void* gbase, unsigned voff, un
 // thread's cell are exactly its lane's operand of that block - it writes its own (hi, lo) pair, nobody gathers), the K loop keeps
 // one accumulator per source wave and the four partial sums meet as f32, each divided by its source's factor: exact scaling, no
 // maximum to agree on, no extra barrier.  12 MFMAs of 16 cycles per tile instead of 16 of 35.
+#ifdef MGR_STAMP
+__device__ unsigned long long g_bstamps[64];
+#define BSTAMP(i, dep) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory"); \
+    st_acc[i] += t_ - st_prev; st_prev = t_; } while (0)
+extern "C" int mgr_debug_bstamps(unsigned long long* out) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bstamps), sizeof(g_bstamps));
+  unsigned long long z[64] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_bstamps), z, sizeof(z));
+  return 0;
+}
+#else
+#define BSTAMP(i, dep) do { } while (0)
+#endif
+// mgr_cell_bwd with tanh(c) given: both forms of the step below go through THIS function with an opaque tc, so that hipcc contracts the
+// cell arithmetic the same way in both (their results are compared bit for bit)
+__device__ __forceinline__ float4 mgr_cell_bwd_tc(float dh, float4 g4, float tc, float c_prev, float& dc_carry) {
+#pragma clang fp contract(off)   // (every fused operation below is written out: no context-dependent contraction)
+  const float i = g4.x, f = g4.y, g = g4.z, o = g4.w;
+  const float dO = dh * tc;
+  const float dc = __builtin_fmaf(dh * o, __builtin_fmaf(-tc, tc, 1.f), dc_carry);
+  const float di = dc * g, df = dc * c_prev, dg = dc * i;
+  dc_carry = dc * f;
+  return make_float4(di * mgr_hsig_grad(i), df * mgr_hsig_grad(f), dg * __builtin_fmaf(-g, g, 1.f), dO * mgr_hsig_grad(o));
+}
 template <int H, bool SPLIT, bool F16>
 __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg, int ug, float* smem, unsigned* status, bool fast) {
   constexpr int N = 4 * H;
@@ -174,6 +202,10 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
   bool failed = false;
   __syncthreads();
 
+#ifdef MGR_STAMP
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev));
+#endif
   for (int k = 0; k < T; ++k) {
     const int n = T - 1 - k;
     const int t = reverse ? T - 1 - n : n;
@@ -237,6 +269,7 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
       } else if (GT <= 1) {
         if (wave == 0 && computer) sum = own_tile;
       }
+      BSTAMP(0, sum[0]);
       prefetch(k + 2);   // behind the gather of this step (memory operations complete in issue order)
       if (SPLIT && GT > 1) {
         if (gatherer) *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = sum;
@@ -251,6 +284,7 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
     } else {
       prefetch(k + 2);
     }
+    BSTAMP(1, dhr);
     // ---- 2. cell backward for (unit, sample); own dz slice -> global dZ and the LDS B-operand image
     float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
     if (computer) {
@@ -269,10 +303,13 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
       const float4 ug4 = *reinterpret_cast<const float4*>(ru + lane * 4);
       const float dh = ru[256 + lane] + dhr;
       const float cp = has_prev ? rp[320 + lane] : 0.f;
-      dz = mgr_cell_bwd(dh, ug4, ru[320 + lane], cp, dcc);
+      float tc = mgr_tanh(ru[320 + lane]);
+      asm volatile("" : "+v"(tc));
+      dz = mgr_cell_bwd_tc(dh, ug4, tc, cp, dcc);
       if (bvalid) *reinterpret_cast<float4*>(jb.dZ + ((size_t)b * T + t) * N + unit * 4) = dz;
       zmx = make_float4(fmaxf(zmx.x, fabsf(dz.x)), fmaxf(zmx.y, fabsf(dz.y)), fmaxf(zmx.z, fabsf(dz.z)), fmaxf(zmx.w, fabsf(dz.w)));
     }
+    BSTAMP(2, dz.x);
     if (!has_prev) break;   // the first forward step has no predecessor: nothing to send (workgroup-uniform; it is the last iteration)
     if (computer) {
       if constexpr (F16) {
@@ -305,7 +342,9 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
         p[3 * 64] = dz.w;
       }
     }
+    BSTAMP(3, dz.y);
     __syncthreads();
+    BSTAMP(4, dz.y);
     // ---- 3. partial sums for every tile of 16 units from this workgroup's 64 gate columns; send tile m to workgroup m
     if (computer) {
       const int slot = k & 1;
@@ -369,8 +408,324 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
         }
       }
     }
+    BSTAMP(5, dz.z);
   }
+#ifdef MGR_STAMP
+  if (lane == 0 && computer) {
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_bstamps[i], st_acc[i]);
+    atomicAdd(&g_bstamps[8], (unsigned long long)T);
+  }
+#endif
   if (jb.dzmax && computer && uvalid && bvalid)   // (fmaxf drops a NaN: a NaN gradient shows in dZ itself, not here)
+    *reinterpret_cast<float4*>(jb.dzmax + (size_t)b * N + unit * 4) = zmx;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the wave ends
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 5: the split-f16 step of the NARROW layers (4 waves, 2 <= G <= 8) trimmed along its dependent chain, for launches that have
+// the chip to themselves.  Cycle stamps of cluster_bwd_run<100, false, true> per step, alone: gather 1544 | partial sums through LDS
+// + barrier 1199 | cell 759 | factor + image 793 | barrier 94 | MFMA + publish 1002 = 5.4 k cycles for 24 MFMAs.  Here:
+//   * the saved state of the step is read from a FOUR-slot ring (fetched three steps ahead: what a step reads at its top was
+//     retired by the previous step's counted wait) and tanh(c) is computed while the gather is in flight;
+//   * the wave's dz factor comes from DPP row maxima + v_readlane and scalar exponent arithmetic instead of six ds_bpermute round
+//     trips and frexpf / ldexpf;
+//   * the B-operand image and the factors are double-buffered on the step parity; the retry loop of the gather is scalar.
+// Same arithmetic, same summation order, same exchange layout: bit-identical to cluster_bwd_run<H, false, true>.  H = 100: 2.29 ->
+// 1.77 us per step alone, H = 128: 2.12 -> 1.76; configuration S 4.62 -> 4.15 ms per step (profiles/r05_bptt_probes.txt).
+// NOT used beside other persistent launches (the fusion layer of config F under the encoder scans): there the step is paced by
+// contention, not by this chain, and the shorter chain takes issue slots from the encoder scans (18.2 -> 18.4 ms per step).
+// Measured on the way and not kept (same notes): every wave gathering the words of its own cells from all G sources - no partial
+// sums through LDS, ONE barrier per step (1.58 us alone at H = 100 with 16-byte elements, 1.76 with component-major tiles; 20.2 /
+// 19.1 ms per step in config F: 28 KiB instead of 6 per workgroup and step through the texture path the encoder scans saturate).
+template <int CTRL>
+__device__ __forceinline__ float bw_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int H>
+__device__ __forceinline__ void cluster_bwd_run16(const ClusterBwdJob& jb, int bg, int ug, float* smem, unsigned* status, bool fast) {
+  constexpr int N = 4 * H;
+  constexpr int GT = (H + 15) / 16;
+  constexpr int TPW = (GT + BW_WAVES - 1) / BW_WAVES;
+  static_assert(GT >= 2 && GT <= 8, "narrow layers with an exchange");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, uq = lane >> 4;
+  const int B = jb.B, T = jb.T, reverse = jb.reverse;
+  const int b = bg * 16 + j;
+  const bool bvalid = b < B;
+  const int bc = bvalid ? b : B - 1;
+  float* dzi = smem;                          // [2 step parities] BW16_IMG
+  float* scl = smem + 2 * BW16_IMG;           // [2][4] 1 / (factor of wave w's dz); [8..11] prologue scratch
+  // saved-state ring of this wave: [4 slots] x { gates [64] float4 | dy [64] | c [64] }, fetched THREE steps ahead: what step k reads
+  // at its top (slots k and k + 1) was retired by the counted wait of step k - 1
+  float* ring = smem + 2 * BW16_IMG + 16 + wave * BW16_RING_FLOATS;
+  float* red = smem + 2 * BW16_IMG + 16 + BW_WAVES * BW16_RING_FLOATS;   // [4 waves][64 lanes][4]
+  f32x4 own_tile = {0.f, 0.f, 0.f, 0.f};
+  const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_float*)ring);
+
+  // A fragments (as cluster_bwd_run, F16): tile i = units 16 (wave + 4 i) .., K-block w' = the 16 gate columns of source wave w'
+  f16x4 ah[TPW][4], al[TPW][4];
+  float sUinv;
+  {
+    auto uval = [&](int i, int wsrc, int e) -> float {
+      const int m = wave + BW_WAVES * i, ur = m * 16 + j, su = ug * 16 + 4 * uq + wsrc;
+      return (m < GT && ur < H && su < H) ? jb.Up[(size_t)ur * N + 4 * su + e] : 0.f;
+    };
+    float umax = 0.f;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int wsrc = 0; wsrc < 4; ++wsrc)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) umax = fmaxf(umax, fabsf(uval(i, wsrc, e)));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) umax = fmaxf(umax, __shfl_xor(umax, o));
+    if (lane == 0) scl[8 + wave] = umax;
+    __syncthreads();
+    umax = fmaxf(fmaxf(scl[8], scl[9]), fmaxf(scl[10], scl[11]));
+    int ex = 0;
+    if (umax > 0.f && umax < 3.0e38f) (void)frexpf(umax, &ex);
+    ex = ex < -60 ? -60 : ex;
+    const float sU = ldexpf(1.f, 15 - ex);   // largest |U| sU in [2^14, 2^15)
+    sUinv = ldexpf(1.f, ex - 15);
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int wsrc = 0; wsrc < 4; ++wsrc)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = uval(i, wsrc, e) * sU;
+          asm volatile("" : "+v"(x));   // (hi and the residual from ONE f32 value: gemm.hip, mgr_split_f16)
+          const _Float16 hi = (_Float16)x;
+          ah[i][wsrc][e] = hi;
+          al[i][wsrc][e] = (_Float16)(x - (float)hi);
+        }
+  }
+  const unsigned sUinv_bits = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sUinv));
+
+  // cell backward ownership: unit = 16 ug + 4 uq + wave (component `wave` of the 16-byte element lane (j, uq) holds of a tile), sample j
+  const int unit = ug * 16 + uq * 4 + wave;
+  const bool uvalid = unit < H;
+  constexpr int SLOT = GT * GT * 256;   // exchange slots: [slot][dest GT][src GT][256 floats]
+  float* xb = jb.xbuf + (size_t)bg * 2 * SLOT;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, 2 * SLOT * 4, 0x00020000);
+
+  const int ul = uvalid ? unit : 0;
+  const unsigned dyoff = (unsigned)(((size_t)bc * T * jb.lddy + ul) * sizeof(float));
+  const unsigned goff = (unsigned)(((size_t)bc * T * H + ul) * 4 * sizeof(float));
+  const unsigned coff = (unsigned)(((size_t)bc * T * H + ul) * sizeof(float));
+  auto prefetch = [&](int k) {       // saved state of iteration k -> ring slot k & 3 (three DMAs; everything wave-uniform but the offsets)
+    if (k < T) {
+      const int n = T - 1 - k;
+      const int t = reverse ? T - 1 - n : n;
+      const unsigned base = ring_lds + (unsigned)(k & 3) * (BW16_RING_FLOATS / 4 * 4);
+      mgr_dma_b128(jb.gates + (size_t)t * H * 4, goff, base);
+      mgr_dma_b32(jb.dY + (size_t)t * jb.lddy, dyoff, base + 1024);
+      mgr_dma_b32(jb.cs + (size_t)t * H, coff, base + 1280);
+    }
+  };
+  prefetch(0);
+  prefetch(1);
+  prefetch(2);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the weight loads and the first ring slots (a wait hipcc can see)
+  float dcc = 0.f;
+  float4 zmx = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool failed = false;
+  unsigned spins = 0;
+  __syncthreads();
+#ifdef MGR_STAMP
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev));
+#endif
+
+  for (int k = 0; k < T; ++k) {
+    const int n = T - 1 - k;
+    const int t = reverse ? T - 1 - n : n;
+    const bool has_prev = n > 0;
+    const int p = k & 1;
+    // ---- 1. the saved state of this step (its DMAs were retired a step ago) and what does not depend on dh, under the gather
+    const float* ru = ring + (k & 3) * (BW16_RING_FLOATS / 4);
+    const float* rp = ring + ((k + 1) & 3) * (BW16_RING_FLOATS / 4);
+    const unsigned sbase = (unsigned)__builtin_amdgcn_readfirstlane(((k - 1) & 1) * SLOT * 4);   // (an SGPR operand: no waterfall loop)
+    const bool gather = k > 0 && !failed;
+    u32x4 v4[TPW];
+    const unsigned g4base = (unsigned)((ug * GT * 256 + lane * 4) * 4);
+    if (gather) {
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const int src = wave + BW_WAVES * i;
+        if (src < GT && src != ug) v4[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, g4base + src * 1024u, sbase, 16);
+      }
+    }
+    const float4 ug4 = *reinterpret_cast<const float4*>(ru + lane * 4);
+    const float dy = ru[256 + lane];
+    float tc = mgr_tanh(ru[320 + lane]);
+    const float cp = has_prev ? rp[320 + lane] : 0.f;
+    asm volatile("" : "+v"(tc));            // (computed HERE, under the gather - not sunk to its use behind the verification)
+    __builtin_amdgcn_sched_barrier(0);
+    float dhr = 0.f;
+    {
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+      if (gather) {
+        const unsigned par = (((unsigned)(k - 1) >> 1) & 1u) ^ 1u;
+        for (bool again = false;; again = true) {
+          if (again) {
+            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+              const int src = wave + BW_WAVES * i;
+              if (src < GT && src != ug) v4[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, g4base + src * 1024u, sbase, 16);
+            }
+          }
+          unsigned a_and = 0xFFFFFFFFu, a_or = 0u;
+#pragma unroll
+          for (int i = 0; i < TPW; ++i) {
+            const int src = wave + BW_WAVES * i;
+            if (src < GT && src != ug) {
+              a_and &= v4[i].x & v4[i].y & v4[i].z & v4[i].w;
+              a_or |= v4[i].x | v4[i].y | v4[i].z | v4[i].w;
+            }
+          }
+          const bool fresh = par ? (a_and & 1u) != 0u : (a_or & 1u) == 0u;
+          if (__builtin_amdgcn_readfirstlane((int)(__all(fresh) || failed))) break;
+          spins = (unsigned)__builtin_amdgcn_readfirstlane((int)(spins + 1u));
+          if ((spins & 255u) == 0) {
+            unsigned st;
+            asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(st) : "v"(status) : "memory");
+            if (__builtin_amdgcn_readfirstlane(st) != 0u) failed = true;
+          }
+          if (spins > POLL_LIMIT) {
+            failed = true;
+            if (lane == 0) __hip_atomic_store(status, MGR_ST_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          failed = __builtin_amdgcn_readfirstlane((int)failed) != 0;
+          if (failed) break;
+        }
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+          const int src = wave + BW_WAVES * i;
+          if (src < GT) {
+            if (src == ug) {
+              sum += own_tile;
+            } else {
+              sum[0] += __uint_as_float(v4[i].x);
+              sum[1] += __uint_as_float(v4[i].y);
+              sum[2] += __uint_as_float(v4[i].z);
+              sum[3] += __uint_as_float(v4[i].w);
+            }
+          }
+        }
+      }
+      if (k > 0) {
+        *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = sum;
+        __syncthreads();
+        dhr = red[(0 * 64 + lane) * 4 + wave] + red[(1 * 64 + lane) * 4 + wave] + red[(2 * 64 + lane) * 4 + wave] + red[(3 * 64 + lane) * 4 + wave];
+      }
+    }
+    BSTAMP(0, dhr);
+    prefetch(k + 3);   // behind the gather of this step (memory operations complete in issue order)
+    // the saved state of iterations k + 1 and k + 2 must have landed before the next step reads it: everything but the three newest
+    // operations (the DMAs of iteration k + 3; the last three iterations issue none: wait for everything there)
+    if (k + 3 < T)
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BSTAMP(1, dhr);
+    // ---- 2. cell backward for (unit, sample); own dz slice -> global dZ and the LDS B-operand image
+    float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (uvalid) {
+      dz = mgr_cell_bwd_tc(dy + dhr, ug4, tc, cp, dcc);
+      if (bvalid) *reinterpret_cast<float4*>(jb.dZ + ((size_t)b * T + t) * N + unit * 4) = dz;
+      zmx = make_float4(fmaxf(zmx.x, fabsf(dz.x)), fmaxf(zmx.y, fabsf(dz.y)), fmaxf(zmx.z, fabsf(dz.z)), fmaxf(zmx.w, fabsf(dz.w)));
+    }
+    BSTAMP(2, dz.x);
+    if (!has_prev) break;   // the first forward step has no predecessor: nothing to send (workgroup-uniform; it is the last iteration)
+    {
+      // this wave's factor: the power of two that puts its largest |dz| of the step in [2^14, 2^15) (wave-uniform: scalar arithmetic
+      // on the exponent field; zero, Inf / NaN -> 2^15 as before - a NaN gradient stays visible in dZ)
+      float m = fmaxf(fmaxf(fabsf(dz.x), fabsf(dz.y)), fmaxf(fabsf(dz.z), fabsf(dz.w)));
+      m = fmaxf(m, bw_dpp<0x111>(m));   // row_shr:1, 2, 4, 8: lane 15 of a row holds the row's maximum
+      m = fmaxf(m, bw_dpp<0x112>(m));
+      m = fmaxf(m, bw_dpp<0x114>(m));
+      m = fmaxf(m, bw_dpp<0x118>(m));
+      const int mi = __float_as_int(m);
+      m = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(mi, 15)), __int_as_float(__builtin_amdgcn_readlane(mi, 31))),
+                fmaxf(__int_as_float(__builtin_amdgcn_readlane(mi, 47)), __int_as_float(__builtin_amdgcn_readlane(mi, 63))));   // (fmaxf drops a NaN as before)
+      const int mb = __builtin_amdgcn_readfirstlane(__float_as_int(m));
+      int e2 = ((mb >> 23) & 0xff) - 126;                       // m = f 2^e2, f in [0.5, 1) (denormals: below the clamp anyway)
+      e2 = e2 < -100 ? -100 : e2;
+      if (!(mb > 0 && mb < 0x7f61b1e6)) e2 = 0;                 // (0x7f61b1e6 = 3.0e38f; zero, Inf, NaN)
+      const float sz = __int_as_float((127 + 15 - e2) << 23);
+      if (lane == 0) scl[p * 4 + wave] = __int_as_float((127 + e2 - 15) << 23) * __uint_as_float(sUinv_bits);
+      float vs[4] = {dz.x * sz, dz.y * sz, dz.z * sz, dz.w * sz};
+      f16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        asm volatile("" : "+v"(vs[e]));
+        const _Float16 h = (_Float16)vs[e];
+        hi[e] = h;
+        lo[e] = (_Float16)(vs[e] - (float)h);
+      }
+      float* img = dzi + p * BW16_IMG;
+      *reinterpret_cast<f16x4*>(img + ((wave * 2) * 64 + lane) * 2) = hi;
+      *reinterpret_cast<f16x4*>(img + ((wave * 2 + 1) * 64 + lane) * 2) = lo;
+    }
+    BSTAMP(3, dz.y);
+    __syncthreads();   // the only barrier of the step: image and factors of parity p complete; those of parity p ^ 1 are free again
+    BSTAMP(4, dz.y);
+    // ---- 3. partial sums for every tile of 16 units from this workgroup's 64 gate columns; send tile m to workgroup m
+    {
+      const int slot = k & 1;
+      const unsigned par = (((unsigned)k >> 1) & 1u) ^ 1u;
+      const float* img = dzi + p * BW16_IMG;
+      f16x4 bh[4], bl[4];
+      float fs[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bh[q] = *reinterpret_cast<const f16x4*>(img + ((q * 2) * 64 + lane) * 2);
+        bl[q] = *reinterpret_cast<const f16x4*>(img + ((q * 2 + 1) * 64 + lane) * 2);
+        fs[q] = scl[p * 4 + q];
+      }
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const int m = wave + BW_WAVES * i;
+        if (m < GT) {  // wave-uniform
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+          f32x4 as[4], a0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) as[q] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[i][q], bh[q], zero, 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) as[q] = __builtin_amdgcn_mfma_f32_16x16x16f16(al[i][q], bh[q], as[q], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) as[q] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[i][q], bl[q], as[q], 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a0[r] = fmaf(as[3][r], fs[3], fmaf(as[2][r], fs[2], fmaf(as[1][r], fs[1], as[0][r] * fs[0])));
+          if (m == ug) {
+            own_tile = a0;
+          } else {
+            u32x4 w;
+            w.x = (__float_as_uint(a0[0]) & ~1u) | par;
+            w.y = (__float_as_uint(a0[1]) & ~1u) | par;
+            w.z = (__float_as_uint(a0[2]) & ~1u) | par;
+            w.w = (__float_as_uint(a0[3]) & ~1u) | par;
+            if (fast)
+              __builtin_amdgcn_raw_buffer_store_b128(w, rs, (slot * SLOT + (m * GT + ug) * 256 + lane * 4) * 4, 0, 0);
+            else
+              __builtin_amdgcn_raw_buffer_store_b128(w, rs, (slot * SLOT + (m * GT + ug) * 256 + lane * 4) * 4, 0, 16);  // sc1
+          }
+        }
+      }
+    }
+    BSTAMP(5, dz.z);
+  }
+#ifdef MGR_STAMP
+  if (lane == 0) {
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_bstamps[i], st_acc[i]);
+    atomicAdd(&g_bstamps[8], (unsigned long long)T);
+    atomicAdd(&g_bstamps[9], (unsigned long long)spins);
+  }
+#endif
+  if (jb.dzmax && uvalid && bvalid)   // (fmaxf drops a NaN: a NaN gradient shows in dZ itself, not here)
     *reinterpret_cast<float4*>(jb.dzmax + (size_t)b * N + unit * 4) = zmx;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the wave ends
 }
@@ -381,7 +736,7 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
 
 // SMALL: every job of the launch is narrow (H <= 128) - its own kernel, so that the fusion layer's BPTT (56 workgroups beside
 // the projection GEMMs of the other stream) is allocated ~100 VGPRs instead of the 256 the H = 500 instantiation needs
-template <bool SPLIT, bool SMALL = false, bool F16 = false>
+template <bool SPLIT, bool SMALL = false, bool F16 = false, bool LEAN = false>
 __device__ __forceinline__ void scan_cluster_bwd_body(const ClusterBwdLaunch& L, float* smem) {
   mgr_cluster_enter(L.cm);
   const int bid = blockIdx.x;
@@ -402,8 +757,14 @@ __device__ __forceinline__ void scan_cluster_bwd_body(const ClusterBwdLaunch& L,
     }
     const int bg = cl - jb.cls_cluster0;
     if (bg < 0 || bg >= jb.nbg) continue;
-#define BW_CASE(HH) \
-  if (jb.H == HH) { cluster_bwd_run<HH, SPLIT, F16>(jb, bg, ug, smem, L.cm.status, fast); return mgr_cluster_exit(L.cm); }
+#define BW_CASE(HH)                                                                                                      \
+  if (jb.H == HH) {                                                                                                      \
+    if constexpr (!SPLIT && SMALL && F16 && LEAN && (HH > 16))                                                                   \
+      cluster_bwd_run16<HH>(jb, bg, ug, smem, L.cm.status, fast);                                                        \
+    else                                                                                                                 \
+      cluster_bwd_run<HH, SPLIT, F16>(jb, bg, ug, smem, L.cm.status, fast);                                              \
+    return mgr_cluster_exit(L.cm);                                                                                       \
+  }
     if constexpr (SMALL) {
       BW_SMALL(BW_CASE)
     } else {
@@ -434,6 +795,11 @@ __global__ __launch_bounds__(2 * BW_WAVES * 64) void k_scan_cluster_bwd_split(Cl
 __global__ __launch_bounds__(BW_WAVES * 64) void k_scan_cluster_bwd16_s(ClusterBwdLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   scan_cluster_bwd_body<false, true, true>(L, smem);
+}
+// narrow layers with the chip to themselves: cluster_bwd_run16
+__global__ __launch_bounds__(BW_WAVES * 64) void k_scan_cluster_bwd16_sl(ClusterBwdLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  scan_cluster_bwd_body<false, true, true, true>(L, smem);
 }
 __global__ __launch_bounds__(BW_WAVES * 64, 2) void k_scan_cluster_bwd16(ClusterBwdLaunch L) {   // (two workgroups per CU: <= 256 VGPRs)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -480,7 +846,7 @@ void mgr_cluster_bwd_geometry(const mgr_ctx* c, const ClusterBwdLaunch& L, int t
   *per_cu = split ? 1 : 2;
 }
 
-int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs) {
+int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs, bool alone) {
   MGR_REQUIRE(total_wgs <= 2 * c->cu_count, "cluster BPTT needs %d co-resident workgroups", total_wgs);
   if (!(c->attr_done & 2u)) {
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -489,6 +855,7 @@ int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs)
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd16_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd16_s), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd16_sl), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     c->attr_done |= 2u;
   }
   const bool f16 = c->tune[14] == 0;   // split-f16 operands (tune key 14 = 1: f32 MFMA)
@@ -499,10 +866,12 @@ int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs)
     else
       hipLaunchKernelGGL(k_scan_cluster_bwd_split, dim3(total_wgs), dim3(2 * BW_WAVES * 64), lds, mgr_stream(c), L);
   } else {
-    size_t lds = (size_t)BW_LDS_FLOATS * sizeof(float);
+    size_t lds = (size_t)BW_LDS_FLOATS_A * sizeof(float);
     bool small = true;
     for (int i = 0; i < L.njobs; ++i) small = small && L.job[i].H <= 128;
-    if (small && f16)
+    if (small && f16 && alone)
+      hipLaunchKernelGGL(k_scan_cluster_bwd16_sl, dim3(total_wgs), dim3(BW_WAVES * 64), (size_t)BW_LDS_FLOATS_B * sizeof(float), mgr_stream(c), L);
+    else if (small && f16)
       hipLaunchKernelGGL(k_scan_cluster_bwd16_s, dim3(total_wgs), dim3(BW_WAVES * 64), lds, mgr_stream(c), L);
     else if (small)
       hipLaunchKernelGGL(k_scan_cluster_bwd_s, dim3(total_wgs), dim3(BW_WAVES * 64), lds, mgr_stream(c), L);

@@ -1371,9 +1371,15 @@ class Engine:
         need = self.lib.mgr_lstm_scan_bwd_multi_ws_bytes(len(jobs), arr)
         if getattr(self, "_ws_bwd_multi", None) is None or self._ws_bwd_multi.nbytes < need:
             self._ws_bwd_multi = self.mem.bytes(need)
-        _capi.check(self.lib.mgr_lstm_scan_bwd_multi(dev.ctx, len(jobs), arr, self._ws_bwd_multi.ptr,
-                                                     self._ws_bwd_multi.nbytes))
         beside_scans = self._beside_scans     # (the deferred GEMMs run beside the next batch's encoder scans as well)
+        if beside_scans:
+            dev.call("mgr_tune", 16, 1)       # the form of the narrow-layer BPTT that yields to the encoder scans beside it (mgr.h)
+        try:
+            _capi.check(self.lib.mgr_lstm_scan_bwd_multi(dev.ctx, len(jobs), arr, self._ws_bwd_multi.ptr,
+                                                         self._ws_bwd_multi.nbytes))
+        finally:
+            if beside_scans:
+                dev.call("mgr_tune", 16, 0)
 
         def param_grads():
             for di, dname in enumerate(("fwd", "bwd")):
