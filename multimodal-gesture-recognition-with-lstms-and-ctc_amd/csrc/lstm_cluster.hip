@@ -759,8 +759,10 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
   bool nonfinite = false;
   bool failed = false;
   unsigned rounds = 0;
+  // (rounds / failed are wave-uniform and hipcc must SEE that - readfirstlane: taken as divergent, the retry loop of the gather is an
+  //  exec-masked region of a dozen s_cbranch_execz)
   auto tick = [&]() {
-    ++rounds;
+    rounds = (unsigned)__builtin_amdgcn_readfirstlane((int)(rounds + 1u));
     if ((rounds & 255u) == 0) {
       unsigned st;
       asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(st) : "v"(status) : "memory");
@@ -770,6 +772,7 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
       failed = true;
       if (lane == 0) __hip_atomic_store(status, MGR_ST_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    failed = __builtin_amdgcn_readfirstlane((int)failed) != 0;
   };
 
 #ifdef MGR_STAMP
@@ -800,7 +803,7 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
           a_or |= v[i].x | v[i].y | v[i].z | v[i].w;
         }
         const bool lane_fresh = par ? (a_and & 1u) != 0u : (a_or & 1u) == 0u;
-        if (__all(lane_fresh) || failed) break;
+        if (__builtin_amdgcn_readfirstlane((int)(__all(lane_fresh) || failed))) break;
         tick();
         if (failed) break;
       }
