@@ -65,7 +65,7 @@ def family_of(k):   # (kernel names carry variant suffixes: _ks, _k16, _s, 16_sp
     if k in FAMILY:
         return FAMILY[k]
     for prefix, fam in (("k_scan_cluster_bwd", "scan_bwd"), ("k_scan_cluster", "scan_fwd"), ("k_gemm_nn", "gemm_nn"),
-                        ("k_gemm_tn", "gemm_tn")):
+                        ("k_gemm_tn", "gemm_tn"), ("k_proj_split", "gemm_nn"), ("k_dw_split", "gemm_tn")):
         if k.startswith(prefix):
             return fam
     return None
