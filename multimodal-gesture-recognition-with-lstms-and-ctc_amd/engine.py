@@ -448,6 +448,7 @@ class Engine:
     # o in [0, 1], so |h| <= 1 - or the residual sum of two of them (encoder stacks, multimodal.py:111,117): <= 2 by construction,
     # whether the scans wrote the copy themselves or mgr_transpose_bt made it from such a buffer.  A diverged state is NaN, not large.
     XT_BOUND = -2.0
+    _fmt_train = True      # the learning phase of the pass being enqueued (decides the row format of new transposed copies)
 
     @staticmethod
     def _ts_shape(fin):
@@ -457,7 +458,10 @@ class Engine:
     def _split_rows_wanted(self):
         """The format new transposed activation copies are written in: split rows (f16 hi / lo pairs, mgr.h) for the pre-split
         products on the f16 matrix pipe - unless tune key 15 keeps the GEMMs on their f32 MFMA kernels (bench.py's second leg)."""
-        if not self.schedule.split_rows:
+        if not self.schedule.split_rows or self.inference_only or not self._fmt_train:
+            # (learning phase 0 has no dropout mask: ONE dense K loop stages the A tile once for the four gates - k_gemm_nn_dense16 on
+            #  f32 rows; the pre-split kernel would stage it once per gate: 20.3 against 19.4 ms per pipelined batch.  By PHASE, not by
+            #  engine: predict on a training engine and on an inference engine give the same bits)
             return False
         v = C.c_int()
         self.dev.call("mgr_tune_get", 15, C.byref(v))
@@ -543,6 +547,7 @@ class Engine:
         sp, dev, B, T = self.spec, self.dev, self.B, self.T
         W = sp.concat_width
         save = train and not self.inference_only
+        self._fmt_train = bool(train)
         saved_step, self.rng_step = self.rng_step, rng_step
         slot = 0
         cols = {}
@@ -622,12 +627,14 @@ class Engine:
             self.rng_step = saved_step
             yield ("projected", k)
             saved_step, self.rng_step = self.rng_step, rng_step
+            self._fmt_train = bool(train)
             dev.stream(es)
             # all recurrences of this depth in ONE call (one persistent multi-CU launch when H is large)
             self._scan_multi(jobs, "_ws_multi")
             self.rng_step = saved_step
             yield ("scanned", k)
             saved_step, self.rng_step = self.rng_step, rng_step
+            self._fmt_train = bool(train)
             dev.stream(es)
         self._featT_ready[feat_buf.ptr] = feat_by_scans
         for si, s in enumerate(sp.streams):
@@ -644,6 +651,7 @@ class Engine:
         sp, dev, B, T = self.spec, self.dev, self.B, self.T
         W = sp.concat_width
         save = train and not self.inference_only
+        self._fmt_train = bool(train)
         saved_step, self.rng_step = self.rng_step, rng_step
         dev.stream(0)
         feat, ldf = feat_buf, W
