@@ -86,6 +86,12 @@ class Schedule:
                         step instead of at the start of the next call, which has to wait for the step's loss
     deepest_scan_after_fusion_proj  (round 5) the next batch's deepest encoder scan is launched behind this step's fusion projections
                         instead of at the same instant
+    depth1_proj_ahead   (round 5; needs encoders_two_ahead) the depth-1 projections of the batch after next are enqueued on the encoder
+                        stream IN FRONT of the next batch's deepest scan - into gate pre-activation buffers of their own - and run while
+                        that stream would wait for this step's fusion projections (a store-bound f32 GEMM beside a staging-bound one)
+    bptt_yields_beside_scans  (round 5) a narrow layer's BPTT that the schedule puts beside the next batch's encoder scans takes the form
+                        that yields to them (mgr.h, tune key 16) instead of the one trimmed along its dependent chain (faster alone,
+                        costs the step 0.1 - 0.2 ms there); bit-identical either way
     split_rows          (round 5) the transposed copies are written in the split row format (f16 hi / lo pairs) and the wide products
                         run as loader / matrix pipelines on pre-split operands (gemm_split.hip); False: f32 rows, converted by
                         every product that reads them (round 4's kernels)
@@ -97,7 +103,9 @@ class Schedule:
 
     def __init__(self, pipeline=True, defer_param_grads=True, encoders_run_ahead=True, resident_wait_us=2000,
                  transposed_inputs=True, bptt_beside_deepest_scan=True, split_rows=True, encoders_two_ahead=True,
-                 deepest_scan_after_fusion_proj=True):
+                 deepest_scan_after_fusion_proj=True, depth1_proj_ahead=False, bptt_yields_beside_scans=True):
+        self.bptt_yields_beside_scans = bool(bptt_yields_beside_scans)
+        self.depth1_proj_ahead = bool(depth1_proj_ahead)
         self.deepest_scan_after_fusion_proj = bool(deepest_scan_after_fusion_proj)
         self.encoders_two_ahead = bool(encoders_two_ahead)
         self.split_rows = bool(split_rows)
@@ -213,6 +221,7 @@ class Engine:
         self.Y2 = {}
         self.dY1 = {}
         self.Zbuf = {}
+        self.Z1buf = {}
         self._xcur = {}
         # host batches arrive through a dedicated copy stream into two alternating input / label buffer sets, so an upload
         # never has to wait for (or stall the host behind) whatever the compute streams still have queued
@@ -233,6 +242,10 @@ class Engine:
             zf = dev.empty((B, T, 4 * max(Hs)))
             zb = dev.empty((B, T, 4 * max(Hs)))
             self.Zbuf[s["name"]] = (zf, zb)
+            if train and self.can_pipeline and self.schedule.depth1_proj_ahead and len(Hs) == 2:
+                # (Schedule.depth1_proj_ahead: the depth-1 projections of a batch are written while the previous batch's deepest scan
+                #  still reads the shared buffers)
+                self.Z1buf[s["name"]] = (dev.empty((B, T, 4 * Hs[0])), dev.empty((B, T, 4 * Hs[0])))
             if len(Hs) == 2:
                 self.Y1[s["name"]] = dev.empty((B, T, 2 * Hs[0]))
                 if s["trainable"] and train:
@@ -1185,11 +1198,22 @@ class Engine:
         if not pipelined:
             finish()
         elif free_gen is not None:
-            free_gen.send(finish)
-            if prefetch_after_next and sch.encoders_two_ahead:
-                # the first part of the pass of the batch AFTER the next one (rng_step / _step_id were advanced above)
-                self._early_gen = self._next_encoders_free(after_next_inputs, depth, self.rng_step + 1, self._step_id + 1)
+            two = prefetch_after_next and sch.encoders_two_ahead
+            if two and sch.depth1_proj_ahead and self.Z1buf and depth > 1:
+                # the batch AFTER the next one: its depth-1 projections in front of the next batch's deepest scan, the rest of its
+                # first part at the end of this call (rng_step / _step_id were advanced above)
+                def pre():
+                    self._early_gen = self._next_encoders_free(after_next_inputs, depth, self.rng_step + 1, self._step_id + 1,
+                                                               split_first=True)
+                    next(self._early_gen)
+                free_gen.send((finish, pre))
                 next(self._early_gen)
+            else:
+                free_gen.send(finish)
+                if two:
+                    # the first part of the pass of the batch AFTER the next one (rng_step / _step_id were advanced above)
+                    self._early_gen = self._next_encoders_free(after_next_inputs, depth, self.rng_step + 1, self._step_id + 1)
+                    next(self._early_gen)
         else:
             self._enqueue_next_encoders(next_inputs, finish, defer, ahead, depth,
                                         free_running=bool(defer and sch.bptt_beside_deepest_scan and sp.fusion and not any_tr_stream_))
@@ -1274,11 +1298,15 @@ class Engine:
                 self.apply_gradients()
         return finish
 
-    def _next_encoders_free(self, next_inputs, depth, rng_step, consumer_step):
-        """Schedule.bptt_beside_deepest_scan, as a two-part generator.  Part 1 (before this step's fusion work is enqueued): the next
+    def _next_encoders_free(self, next_inputs, depth, rng_step, consumer_step, split_first=False):
+        """Schedule.bptt_beside_deepest_scan, as a generator.  Part 1 (before this step's fusion work is enqueued): the next
         batch's encoder pass on stream ES up to and including its deepest projection GEMMs.  Part 2 (after the loss read-back point,
-        resumed with send(finish)): stream 0 waits for those GEMMs, then - once the deepest scan launched behind them is resident -
-        runs `finish` (this step's BPTT, dW / dU / db GEMMs, optimizer) beside that scan."""
+        resumed with send(finish) or send((finish, pre))): stream 0 waits for those GEMMs, then - once the deepest scan launched behind
+        them is resident - runs `finish` (this step's BPTT, dW / dU / db GEMMs, optimizer) beside that scan; `pre`, if given, is called
+        with stream ES selected right in front of the deepest scan's waits.
+        split_first (Schedule.depth1_proj_ahead): part 1 comes in two pieces - upload, noise and the depth-1 projections into the
+        engine's second set of gate pre-activation buffers, then one more yield, then the rest - so that a caller can put the first
+        piece in front of the PREVIOUS batch's deepest scan (its `pre`)."""
         dev, ES = self.dev, self.ES
         self._feat_idx ^= 1
         nxt = self._feat_ring[self._feat_idx]
@@ -1287,15 +1315,25 @@ class Engine:
             dev.stream(ES)
             self._upload_inputs(next_inputs, None, True, stream=ES)
             self._xin_user[self._xin_slot] = consumer_step
-        phases = self._encoder_phases(True, None, nxt, ES, rng_step)
+        split_first = bool(split_first and self.Z1buf)
+        phases = self._encoder_phases(True, None, nxt, ES, rng_step, z_first=self.Z1buf if split_first else None)
         for tag, k in phases:
+            if tag == "projected" and k == 0 and split_first and depth > 1:
+                dev.stream(0)
+                yield "depth-1 projections"
+                continue
             if tag == "projected" and k == depth - 1:
                 break
         dev.stream(0)
-        finish = yield
+        got = yield
+        finish, pre = got if isinstance(got, tuple) else (got, None)
         dev.wait(0, ES)
         dev.stream(0)
         finish(self._resident_gate())
+        if pre is not None:
+            dev.stream(ES)
+            pre()
+            dev.stream(ES)
         dev.wait_event(ES, self.EV_PREV)   # (the deepest scan overwrites the FEAT buffer the previous step's dW GEMMs read)
         if self.schedule.deepest_scan_after_fusion_proj:
             # ... and it lets THIS step's fusion projections go first: both become ready at the same instant (the end of the previous
@@ -1380,13 +1418,14 @@ class Engine:
         if getattr(self, "_ws_bwd_multi", None) is None or self._ws_bwd_multi.nbytes < need:
             self._ws_bwd_multi = self.mem.bytes(need)
         beside_scans = self._beside_scans     # (the deferred GEMMs run beside the next batch's encoder scans as well)
-        if beside_scans:
+        yielding = beside_scans and self.schedule.bptt_yields_beside_scans
+        if yielding:
             dev.call("mgr_tune", 16, 1)       # the form of the narrow-layer BPTT that yields to the encoder scans beside it (mgr.h)
         try:
             _capi.check(self.lib.mgr_lstm_scan_bwd_multi(dev.ctx, len(jobs), arr, self._ws_bwd_multi.ptr,
                                                          self._ws_bwd_multi.nbytes))
         finally:
-            if beside_scans:
+            if yielding:
                 dev.call("mgr_tune", 16, 0)
 
         def param_grads():
