@@ -81,6 +81,11 @@ extern "C" int mgr_debug_bstamps(unsigned long long* out) {
 #else
 #define BSTAMP(i, dep) do { } while (0)
 #endif
+// DPP with the lane's own value where a row has no source (ctc.hip, dpp_f32)
+template <int CTRL>
+__device__ __forceinline__ float bw_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 // mgr_cell_bwd with tanh(c) given: both forms of the step below go through THIS function with an opaque tc, so that hipcc contracts the
 // cell arithmetic the same way in both (their results are compared bit for bit)
 __device__ __forceinline__ float4 mgr_cell_bwd_tc(float dh, float4 g4, float tc, float c_prev, float& dc_carry) {
@@ -315,13 +320,34 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
       if constexpr (F16) {
         // this wave's factor, then the thread's own lane operand of K-block `wave`: image [wave][hi | lo][lane] 8 bytes
         float m = fmaxf(fmaxf(fabsf(dz.x), fabsf(dz.y)), fmaxf(fabsf(dz.z), fabsf(dz.w)));
+        float sz;
+        if constexpr (SPLIT) {
+          // (round 5, the wide layers' split-role kernel: DPP row maxima + v_readlane + scalar exponent arithmetic instead of six
+          //  ds_bpermute round trips and frexpf / ldexpf - the same factor bit for bit, cluster_bwd_run16 below; the 4-wave form keeps
+          //  the old sequence: it is the one that runs beside the encoder scans of config F, where every change of its timing is a
+          //  change of the whole step, profiles/r05_bptt_probes.txt)
+          m = fmaxf(m, bw_dpp<0x111>(m));   // row_shr:1, 2, 4, 8: lane 15 of a row holds the row's maximum
+          m = fmaxf(m, bw_dpp<0x112>(m));
+          m = fmaxf(m, bw_dpp<0x114>(m));
+          m = fmaxf(m, bw_dpp<0x118>(m));
+          const int mi = __float_as_int(m);
+          m = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(mi, 15)), __int_as_float(__builtin_amdgcn_readlane(mi, 31))),
+                    fmaxf(__int_as_float(__builtin_amdgcn_readlane(mi, 47)), __int_as_float(__builtin_amdgcn_readlane(mi, 63))));
+          const int mb = __builtin_amdgcn_readfirstlane(__float_as_int(m));
+          int e2 = ((mb >> 23) & 0xff) - 126;
+          e2 = e2 < -100 ? -100 : e2;
+          if (!(mb > 0 && mb < 0x7f61b1e6)) e2 = 0;   // (0x7f61b1e6 = 3.0e38f; zero, Inf, NaN)
+          sz = __int_as_float((127 + 15 - e2) << 23);
+          if (lane == 0) scl[wave] = __int_as_float((127 + e2 - 15) << 23) * sUinv;
+        } else {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        int e2 = 0;
-        if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &e2);
-        e2 = e2 < -100 ? -100 : e2;
-        const float sz = ldexpf(1.f, 15 - e2);   // (an Inf / NaN gradient: NaN products - it stays visible in dZ)
-        if (lane == 0) scl[wave] = ldexpf(1.f, e2 - 15) * sUinv;
+          for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+          int e2 = 0;
+          if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &e2);
+          e2 = e2 < -100 ? -100 : e2;
+          sz = ldexpf(1.f, 15 - e2);   // (an Inf / NaN gradient: NaN products - it stays visible in dZ)
+          if (lane == 0) scl[wave] = ldexpf(1.f, e2 - 15) * sUinv;
+        }
         float vs[4] = {dz.x * sz, dz.y * sz, dz.z * sz, dz.w * sz};
         f16x4 hi, lo;
 #pragma unroll
@@ -437,10 +463,6 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
 // Measured on the way and not kept (same notes): every wave gathering the words of its own cells from all G sources - no partial
 // sums through LDS, ONE barrier per step (1.58 us alone at H = 100 with 16-byte elements, 1.76 with component-major tiles; 20.2 /
 // 19.1 ms per step in config F: 28 KiB instead of 6 per workgroup and step through the texture path the encoder scans saturate).
-template <int CTRL>
-__device__ __forceinline__ float bw_dpp(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
 template <int H>
 __device__ __forceinline__ void cluster_bwd_run16(const ClusterBwdJob& jb, int bg, int ug, float* smem, unsigned* status, bool fast) {
   constexpr int N = 4 * H;
