@@ -348,10 +348,11 @@ __global__ __launch_bounds__(256, 6) void k_dense_bwd_mfma(const float* __restri
   }
 }
 
-// the matrix-core forms: D <= 256 (Wd fragments in LDS / registers), C <= 24, rows readable as float4, 32-bit element offsets
-static bool dense_mfma_ok(const mgr_ctx* c, const float* A, int lda, int ldo, int D, int C, size_t nframes) {
+// the matrix-core forms: D <= maxD (forward: 256, its Wd fragments live in LDS; backward: a workgroup takes a 16-feature slice,
+// any width - 1024 covers the unimodal heads, D = 600 / 1000), C <= 24, rows readable as float4, 32-bit element offsets
+static bool dense_mfma_ok(const mgr_ctx* c, const float* A, int lda, int ldo, int D, int C, size_t nframes, int maxD = 256) {
   const size_t ld = (size_t)(lda > ldo ? lda : ldo);
-  return c->tune[13] == 0 && D <= 256 && D % 4 == 0 && C <= 24 && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
+  return c->tune[13] == 0 && D <= maxD && D % 4 == 0 && C <= 24 && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
          nframes * (ld > (size_t)D ? ld : (size_t)D) < ((size_t)1 << 31);
 }
 
@@ -431,7 +432,7 @@ int mgr_dense_bwd(mgr_ctx* c, const float* A, int lda, const float* dmask, float
   float* slabB = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + mgr_align_up((size_t)dense_bwd_wgs(nframes) * D * C * sizeof(float), 256));
   float inv_keep = 1.f / (1.f - p);
   mgr_prof_begin(c, MGR_K_DENSE_BWD);
-  if (dense_mfma_ok(c, A, lda, ldda, D, C, nframes)) {
+  if (dense_mfma_ok(c, A, lda, ldda, D, C, nframes, 1024)) {
     // one slab per workgroup column; 4 waves x 16-frame tiles, two halves of the feature range side by side (blockIdx.y)
     int gx = (int)(((nframes + 15) / 16 + 3) / 4);
     const int cap = dense_bwd_wgs(nframes);      // (what the workspace was sized for)
