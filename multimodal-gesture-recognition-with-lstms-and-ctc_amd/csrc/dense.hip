@@ -235,52 +235,59 @@ __global__ __launch_bounds__(256, 6) void k_dense_softmax_fwd_mfma(const float* 
 //   dA[f, d]  = dm * sum_c dL[f, c] Wd[d, c]      M = frames, N = features, K = classes (6 k-steps of 4; Wd^T fragments stationary)
 //   dWd[d, c] = sum_f (A dm)[f, d] dL[f, c]       M = features, N = classes, K = frames with k-step i <-> frames 4 kk + i
 // so A is loaded and its dropout factor evaluated ONCE per element.  Per-workgroup partial dWd / dbd slabs, reduced as before.
-template <int NTH>
-__global__ __launch_bounds__(256, 6) void k_dense_bwd_mfma(const float* __restrict__ A, int lda, const float* __restrict__ dmask, float p,
+// KS k-steps of 4 classes in the dA product, NC class tiles of 16 in the dWd product: (6, 2) for C <= 24, (12, 3) for C <= 48 (the
+// audio head, C = 44; 4 workgroups per CU instead of 6)
+template <int NTH, int KS = 6, int NC = 2>
+__global__ __launch_bounds__(256, KS > 6 ? 4 : 6) void k_dense_bwd_mfma(const float* __restrict__ A, int lda, const float* __restrict__ dmask, float p,
                                                            float inv_keep, uint64_t seed, const float* __restrict__ dL,
                                                            const float* __restrict__ Wd, float* __restrict__ slabW,
                                                            float* __restrict__ slabB, float* __restrict__ dA, int ldda, size_t nframes,
                                                            int D, int C) {
-  __shared__ f32x4_ red[4][NTH * 2][64];
+  __shared__ f32x4_ red[4][NTH * NC][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, kk = lane >> 4;
   const int d0 = blockIdx.y * NTH * 16;     // first feature of this workgroup's slice
   // Wd^T fragments: k-step s (classes 4 s + kk), feature tile t: B[k = kk][n] = Wd[d0 + 16 t + n][4 s + kk]
-  float wt[NTH][6];
+  float wt[NTH][KS];
 #pragma unroll
   for (int t = 0; t < NTH; ++t)
 #pragma unroll
-    for (int s6 = 0; s6 < 6; ++s6) {
+    for (int s6 = 0; s6 < KS; ++s6) {
       const int d = d0 + 16 * t + n, c = 4 * s6 + kk;
       wt[t][s6] = (d < D && c < C) ? Wd[(size_t)d * C + c] : 0.f;
     }
-  f32x4_ accW[NTH][2];
+  f32x4_ accW[NTH][NC];
 #pragma unroll
-  for (int t = 0; t < NTH; ++t) accW[t][0] = accW[t][1] = (f32x4_){0.f, 0.f, 0.f, 0.f};
-  float accb0 = 0.f, accb1 = 0.f;
+  for (int t = 0; t < NTH; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NC; ++nt) accW[t][nt] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+  float accb[NC];
+#pragma unroll
+  for (int nt = 0; nt < NC; ++nt) accb[nt] = 0.f;
   // (32-bit element offsets: the launcher sends tensors of 2^31 elements or more to the vector-ALU kernels)
   const unsigned nf = (unsigned)nframes, ntile = (nf + 15u) / 16u;
   for (unsigned tile = blockIdx.x * 4u + wave; tile < ntile; tile += gridDim.x * 4u) {
     const unsigned f0 = tile * 16u;
     // dL as A operand of the dA product: lane (m = frame n, k = class 4 s + kk)
-    float gl[6];
+    float gl[KS];
     {
       const unsigned f = f0 + n;
 #pragma unroll
-      for (int s6 = 0; s6 < 6; ++s6) {
+      for (int s6 = 0; s6 < KS; ++s6) {
         const int c = 4 * s6 + kk;
         gl[s6] = (f < nf && c < C) ? dL[f * (unsigned)C + c] : 0.f;
       }
     }
     // dL as B operand of the dWd product: k-step i <-> frame 4 kk + i, lane (k = kk, n = class)
-    float gb[4][2];
+    float gb[4][NC];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const unsigned f = f0 + 4 * kk + i;
-      gb[i][0] = (f < nf && n < C) ? dL[f * (unsigned)C + n] : 0.f;
-      gb[i][1] = (f < nf && 16 + n < C) ? dL[f * (unsigned)C + 16 + n] : 0.f;
-      accb0 += gb[i][0];
-      accb1 += gb[i][1];
+#pragma unroll
+      for (int nt = 0; nt < NC; ++nt) {
+        gb[i][nt] = (f < nf && 16 * nt + n < C) ? dL[f * (unsigned)C + 16 * nt + n] : 0.f;
+        accb[nt] += gb[i][nt];
+      }
     }
 #pragma unroll
     for (int t = 0; t < NTH; ++t) {
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(256, 6) void k_dense_bwd_mfma(const float* __restri
       if (dA) {
         f32x4_ o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s6 = 0; s6 < 6; ++s6) o = __builtin_amdgcn_mfma_f32_16x16x4f32(gl[s6], wt[t][s6], o, 0, 0, 0);
+        for (int s6 = 0; s6 < KS; ++s6) o = __builtin_amdgcn_mfma_f32_16x16x4f32(gl[s6], wt[t][s6], o, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const unsigned f = f0 + 4 * kk + i;
@@ -307,25 +314,23 @@ __global__ __launch_bounds__(256, 6) void k_dense_bwd_mfma(const float* __restri
       }
       // dWd: A operand lane (m = feature n of tile t, k = kk) for k-step i = am[i]
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        accW[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[i], gb[i][0], accW[t][0], 0, 0, 0);
-        accW[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[i], gb[i][1], accW[t][1], 0, 0, 0);
-      }
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int nt = 0; nt < NC; ++nt) accW[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[i], gb[i][nt], accW[t][nt], 0, 0, 0);
     }
   }
   // the four waves' partial dWd tiles meet in LDS (fixed order), one slab per workgroup column: a lane holds features
   // 16 t + 4 kk + i of class 16 nt + n
 #pragma unroll
-  for (int t = 0; t < NTH; ++t) {
-    red[wave][t * 2 + 0][lane] = accW[t][0];
-    red[wave][t * 2 + 1][lane] = accW[t][1];
-  }
+  for (int t = 0; t < NTH; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NC; ++nt) red[wave][t * NC + nt][lane] = accW[t][nt];
   __syncthreads();
   float* mySlabW = slabW + (size_t)blockIdx.x * D * C;
-  for (int idx = threadIdx.x; idx < NTH * 2 * 64; idx += 256) {
+  for (int idx = threadIdx.x; idx < NTH * NC * 64; idx += 256) {
     const int tn = idx >> 6, l = idx & 63;
     const f32x4_ sum = red[0][tn][l] + red[1][tn][l] + red[2][tn][l] + red[3][tn][l];
-    const int t = tn >> 1, nt = tn & 1, c = 16 * nt + (l & 15);
+    const int t = tn / NC, nt = tn % NC, c = 16 * nt + (l & 15);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int d = d0 + 16 * t + 4 * (l >> 4) + i;
@@ -335,24 +340,23 @@ __global__ __launch_bounds__(256, 6) void k_dense_bwd_mfma(const float* __restri
   if (blockIdx.y == 0) {   // dbd: sum over the four frame groups kk of a wave, then the waves
     __syncthreads();
     float* rb = reinterpret_cast<float*>(&red[0][0][0]);
-    accb0 += __shfl_xor(accb0, 16);
-    accb0 += __shfl_xor(accb0, 32);
-    accb1 += __shfl_xor(accb1, 16);
-    accb1 += __shfl_xor(accb1, 32);
-    if (kk == 0) {
-      rb[wave * 32 + n] = accb0;
-      rb[wave * 32 + 16 + n] = accb1;
+#pragma unroll
+    for (int nt = 0; nt < NC; ++nt) {
+      accb[nt] += __shfl_xor(accb[nt], 16);
+      accb[nt] += __shfl_xor(accb[nt], 32);
+      if (kk == 0) rb[wave * (16 * NC) + 16 * nt + n] = accb[nt];
     }
     __syncthreads();
-    if ((int)threadIdx.x < C) slabB[(size_t)blockIdx.x * C + threadIdx.x] = rb[threadIdx.x] + rb[32 + threadIdx.x] + rb[64 + threadIdx.x] + rb[96 + threadIdx.x];
+    if ((int)threadIdx.x < C)
+      slabB[(size_t)blockIdx.x * C + threadIdx.x] = rb[threadIdx.x] + rb[16 * NC + threadIdx.x] + rb[2 * 16 * NC + threadIdx.x] + rb[3 * 16 * NC + threadIdx.x];
   }
 }
 
 // the matrix-core forms: D <= maxD (forward: 256, its Wd fragments live in LDS; backward: a workgroup takes a 16-feature slice,
 // any width - 1024 covers the unimodal heads, D = 600 / 1000), C <= 24, rows readable as float4, 32-bit element offsets
-static bool dense_mfma_ok(const mgr_ctx* c, const float* A, int lda, int ldo, int D, int C, size_t nframes, int maxD = 256) {
+static bool dense_mfma_ok(const mgr_ctx* c, const float* A, int lda, int ldo, int D, int C, size_t nframes, int maxD = 256, int maxC = 24) {
   const size_t ld = (size_t)(lda > ldo ? lda : ldo);
-  return c->tune[13] == 0 && D <= maxD && D % 4 == 0 && C <= 24 && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
+  return c->tune[13] == 0 && D <= maxD && D % 4 == 0 && C <= maxC && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
          nframes * (ld > (size_t)D ? ld : (size_t)D) < ((size_t)1 << 31);
 }
 
@@ -432,14 +436,17 @@ int mgr_dense_bwd(mgr_ctx* c, const float* A, int lda, const float* dmask, float
   float* slabB = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + mgr_align_up((size_t)dense_bwd_wgs(nframes) * D * C * sizeof(float), 256));
   float inv_keep = 1.f / (1.f - p);
   mgr_prof_begin(c, MGR_K_DENSE_BWD);
-  if (dense_mfma_ok(c, A, lda, ldda, D, C, nframes, 1024)) {
+  if (dense_mfma_ok(c, A, lda, ldda, D, C, nframes, 1024, 48)) {
     // one slab per workgroup column; 4 waves x 16-frame tiles, two halves of the feature range side by side (blockIdx.y)
     int gx = (int)(((nframes + 15) / 16 + 3) / 4);
     const int cap = dense_bwd_wgs(nframes);      // (what the workspace was sized for)
     if (gx > cap) gx = cap;
     if (gx > 256) gx = 256;
     nwg = gx;
-    hipLaunchKernelGGL(k_dense_bwd_mfma<1>, dim3(gx, (D + 15) / 16), dim3(256), 0, mgr_stream(c), A, lda, dmask, p, inv_keep, seed, dLogits, Wd, slabW, slabB, dA, ldda, nframes, D, C);
+    if (C <= 24)
+      hipLaunchKernelGGL((k_dense_bwd_mfma<1, 6, 2>), dim3(gx, (D + 15) / 16), dim3(256), 0, mgr_stream(c), A, lda, dmask, p, inv_keep, seed, dLogits, Wd, slabW, slabB, dA, ldda, nframes, D, C);
+    else
+      hipLaunchKernelGGL((k_dense_bwd_mfma<1, 12, 3>), dim3(gx, (D + 15) / 16), dim3(256), 0, mgr_stream(c), A, lda, dmask, p, inv_keep, seed, dLogits, Wd, slabW, slabB, dA, ldda, nframes, D, C);
   } else if (C <= 24)
     hipLaunchKernelGGL(k_dense_bwd<24>, dim3(nwg), dim3(256), 0, mgr_stream(c), A, lda, dmask, p, inv_keep, seed, dLogits, Wd, slabW, slabB, dA, ldda, nframes, fpw, D, C);
   else
