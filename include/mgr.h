@@ -190,6 +190,10 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
  *        XCD-local exchange).
  * key 4: 2 = split-f16 K-split scan launches take the PAIR form (two 16-sample groups per workgroup, one workgroup per CU) whenever
  *        they qualify; bit-identical to the default (two workgroups per CU) and slower: kept as a measured alternative.
+ *        3 = launches that do not fit ONE workgroup per CU as they are (config F's encoder depths: 408 workgroups) take the FUSED form:
+ *        8-wave workgroups that run two unit groups of their cluster, a CU each (208), bit-identical; the CUs they leave free are what
+ *        4-wave persistent launches of other streams get - the admission ledger then counts those by the CUs they need two to a CU,
+ *        and their caller starts them once the fused launch is resident (mgr_stream_wait_resident) so that they do land there.
  * key 7: one-tile-per-wave clusters: 0 = K-split step (register-direct gather), 1 = LDS-image step.
  * key 8: 1 = the multi-CU BPTT keeps its 4-wave kernel instead of the split-role (4 compute + 4 gather waves) one, 2 = always split.
  * key 9: 1 = mgr_lstm_input_proj_dropout always takes the dense kernel.

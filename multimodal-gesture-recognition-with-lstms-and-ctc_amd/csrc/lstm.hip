@@ -284,6 +284,20 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
         for (int i = 0; i < njobs; ++i)
           if (P.cluster[i]) P.nbg[i] = (P.nbg[i] + 1) / 2;     // clusters of the job from here on
     }
+    // Fused form (lstm_cluster.hip, k_scan_cluster_k16f): 8-wave workgroups that run TWO unit groups of their cluster, one workgroup
+    // per CU (config F's encoder depths: 208 workgroups on 208 CUs, 48 CUs left to the other stream).  tune key 4: 3.
+    bool fused = !pair && ks_ok && P.exchange && c->tune[14] == 0 && c->tune[4] == 3 && c->tune[3] == 0;
+    for (int i = 0; i < njobs && fused; ++i) {
+      if (!P.cluster[i]) continue;
+      fused = P.cfg[i].nw == 4 && P.cfg[i].tpw == 1 && P.G[i] > 1 && mgr_cluster_ks_supported(jobs[i].H / 4);
+    }
+    {   // (only launches that do not fit one workgroup per CU as they are: the fusion layer's 56 workgroups stay what they are)
+      int unf = 0;
+      for (int i = 0; i < njobs; ++i)
+        if (P.cluster[i]) unf += P.G[i] * P.nbg[i];
+      fused = fused && unf > c->cu_count;
+    }
+    auto members = [&](int i) { return fused ? (P.G[i] + 1) / 2 : P.G[i]; };   // workgroups per cluster
     bool xcd = c->tune[3] == 0 && ks_ok && P.exchange;
     {
       int tot = 0, live_x = 0;
@@ -303,22 +317,23 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
           int clusters = 0;
           for (int k = i; k < njobs; ++k)
             if (P.cluster[k] && jobs[k].H == jobs[i].H) clusters += P.nbg[k];
-          tot += P.G[i] * ((clusters + 7) / 8 * 8);
-          live_x += P.G[i] * clusters;
+          tot += members(i) * ((clusters + 7) / 8 * 8);
+          live_x += members(i) * clusters;
         }
-        xcd = live_x <= (pair ? 1 : 2) * c->cu_count && tot <= 2 * c->cu_count && (size_t)tot * sizeof(unsigned) <= kScanHdrBytes - 256;
+        xcd = live_x <= ((pair || fused) ? 1 : 2) * c->cu_count && tot <= 2 * c->cu_count && (size_t)tot * sizeof(unsigned) <= kScanHdrBytes - 256;
       }
     }
     int cb[MGR_MAX_SCAN_JOBS], cn[MGR_MAX_SCAN_JOBS], c0[MGR_MAX_SCAN_JOBS], cr[MGR_MAX_SCAN_JOBS];
     // workgroups that really run (a class laid out in octets of clusters has empty ids when its cluster count is no multiple of 8:
     // those workgroups count themselves in and return): what co-residency and the admission ledger are about
+    fused = fused && xcd;   // (the fused kernel understands the octet layout only)
     int live = 0;
     for (int i = 0; i < njobs; ++i)
-      if (P.cluster[i]) live += P.G[i] * P.nbg[i];
+      if (P.cluster[i]) live += members(i) * P.nbg[i];
     P.total = layout_classes(
         njobs, P.cluster,
         [&](int a, int b) { return jobs[a].H == jobs[b].H && P.cfg[a].nw == P.cfg[b].nw && P.cfg[a].tpw == P.cfg[b].tpw; },
-        [&](int a) { return P.G[a]; }, P.nbg, cb, cn, c0, xcd, cr);
+        [&](int a) { return members(a); }, P.nbg, cb, cn, c0, xcd, cr);
     L.xcd_local = xcd;
     for (int i = 0; i < njobs; ++i) {
       if (!P.cluster[i]) continue;
@@ -335,6 +350,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
       w += mgr_align_up((size_t)nbg16[i] * 2 * img * sizeof(float), 256);
     }
     L.pair = pair ? 1 : 0;
+    L.fused = fused ? 1 : 0;
     L.live_wgs = live;
     // tune key 7: 0 = K-split step for one-tile-per-wave clusters, 1 = LDS-image step for every cluster
     L.ksplit = ks_ok ? 1 : 0;
@@ -543,7 +559,7 @@ int mgr_persist_admit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu, unsigne
   bool ordered[MGR_MAX_PERSIST] = {};   // launches this one has been put behind
   for (;;) {
     // launches of ONE stream run one after the other: a stream can hold at most its largest launch on the chip at a time
-    int per_stream[MGR_NUM_STREAMS] = {};
+    int per_stream[MGR_NUM_STREAMS] = {}, cus_stream[MGR_NUM_STREAMS] = {};
     int any_excl = per_cu == 1 ? 1 : 0, oldest = -1;
     for (int i = 0; i < MGR_MAX_PERSIST; ++i) {
       mgr_ctx::Persist& e = c->persist[i];
@@ -553,13 +569,21 @@ int mgr_persist_admit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu, unsigne
         continue;
       }
       per_stream[e.stream] = e.wgs > per_stream[e.stream] ? e.wgs : per_stream[e.stream];
+      const int cus = (e.wgs + e.per_cu - 1) / e.per_cu;
+      cus_stream[e.stream] = cus > cus_stream[e.stream] ? cus : cus_stream[e.stream];
       any_excl |= e.per_cu == 1;
       if (oldest < 0 || e.seq < c->persist[oldest].seq) oldest = i;
     }
-    int shared = wgs;
-    for (int s = 0; s < MGR_NUM_STREAMS; ++s) shared += per_stream[s];
+    int shared = wgs, cus = (wgs + per_cu - 1) / per_cu;
+    for (int s = 0; s < MGR_NUM_STREAMS; ++s) {
+      shared += per_stream[s];
+      cus += cus_stream[s];
+    }
+    // tune key 4 = 3 (fused scans: 8-wave workgroups that fill a CU's register file): beside them the 4-wave launches are counted by the
+    // CUs they need two to a CU - their caller (the engine) starts them once the exclusive launch is resident, so that they do land there
+    const bool by_cus = any_excl && c->tune[4] == 3;
     const int capacity = any_excl ? c->cu_count : 2 * c->cu_count;
-    if (oldest < 0 || shared <= capacity) break;
+    if (oldest < 0 || (by_cus ? cus : shared) <= capacity) break;
     // does not fit beside what may still be running: run behind the oldest of them, then look again
     MGR_HIP(hipStreamWaitEvent(mgr_stream(c), c->persist[oldest].done, 0));
     ordered[oldest] = true;

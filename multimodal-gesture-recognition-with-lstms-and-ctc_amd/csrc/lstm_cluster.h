@@ -59,6 +59,8 @@ struct ClusterLaunch {
   int split16;       // K-split launches: f16 (hi, lo) operands on the f16 matrix pipe (cluster_run_k16; tune key 14 = 1: f32 MFMA step)
   int live_wgs;      // workgroups of the grid that run a cluster (the others are empty ids of the octet layout)
   int pair;          // split16 K-split launches: every workgroup runs TWO 16-sample groups (cluster_run_k16p: one workgroup per CU)
+  int fused;         // split16 K-split launches: every workgroup (8 waves, a CU of its own) runs TWO unit groups of its cluster; the job
+                     // table's cls_* fields then count ceil(G_ / 2) members per cluster (k_scan_cluster_k16f)
   int xcd_local;     // K-split launches: clusters are laid out on workgroup ids congruent mod 8 (one XCD under the dispatcher's
                      // round-robin); a cluster that FINDS all its members on one XCD publishes with plain stores into that L2
   ClusterJob job[MGR_MAX_SCAN_JOBS];

@@ -641,11 +641,14 @@ extern "C" int mgr_debug_stamps(unsigned long long* out) {
 #else
 #define KSTAMP(i, dep) do { } while (0)
 #endif
-template <int NBW>   // K-blocks (of 32 units) per wave: H <= 128 * NBW
+// FUSED (round 5, k_scan_cluster_k16f): the workgroup has 512 threads and runs TWO unit groups of one cluster - threads 0..255 the
+// member 2 j, threads 256..511 the member 2 j + 1 - each through this function with its own half of the LDS; they share the CU and
+// the barriers (the same count in both: one in the prologue, one per step), nothing else.
+template <int NBW, bool FUSED = false>   // K-blocks (of 32 units) per wave: H <= 128 * NBW
 __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const ClusterCommon& cm, int bg, int ug, float* smem, bool fast) {
   static_assert(NBW >= 1 && NBW <= 4, "1..4 K-blocks per wave (H <= 512)");
   unsigned* status = cm.status;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = FUSED ? (int)(threadIdx.x & 255u) : (int)threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..3
   const int H = jb.H, N = 4 * H, G = jb.G_;
   const int NKB = (H + 31) >> 5;          // K-blocks of the layer
@@ -1377,6 +1380,37 @@ __global__ __launch_bounds__(256, 1) void k_scan_cluster_k16p(ClusterLaunch L) {
 #undef K16P_RUN
 }
 
+// the fused form: one 8-wave workgroup per CU = two unit groups (2 j, 2 j + 1) of one cluster; the launch lays out ceil(G / 2) members
+// per cluster (XCD-local octets as above); a unit group beyond G (odd G) only keeps the barrier count
+__global__ __launch_bounds__(512, 1) void k_scan_cluster_k16f(ClusterLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  mgr_cluster_enter(L.cm);
+  const int tg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  for (int k_ = 0; k_ < L.njobs; ++k_) {
+    const ClusterJob& jb = L.job[k_];
+    const int G = jb.G_, Gr = (G + 1) / 2;
+    const int w_ = (int)blockIdx.x - jb.cls_begin;
+    if (w_ < 0 || w_ >= (jb.cls_nclusters + 7) / 8 * 8 * Gr) continue;
+    int cl, ugr;
+    const bool same = mgr_cluster_octet(L.cm, jb.cls_begin, Gr, jb.cls_rot, w_, cl, ugr);
+    const int bg = cl - jb.cls_cluster0;
+    if (cl >= jb.cls_nclusters || bg < 0 || bg >= jb.nbg) continue;
+    const int ug = 2 * ugr + tg;
+    float* sm = smem + tg * K16_LDS_FLOATS;
+    if (ug >= G) {   // (odd G: the last workgroup's second half)
+      __syncthreads();
+      for (int step = 0; step < jb.T; ++step) __syncthreads();
+      return mgr_cluster_exit(L.cm);
+    }
+    const int nbw = (((jb.H + 31) >> 5) + 3) >> 2;
+    if (nbw == 1) cluster_run_k16<1, true>(jb, L.cm, bg, ug, sm, same);
+    else if (nbw == 2) cluster_run_k16<2, true>(jb, L.cm, bg, ug, sm, same);
+    else if (nbw == 3) cluster_run_k16<3, true>(jb, L.cm, bg, ug, sm, same);
+    else cluster_run_k16<4, true>(jb, L.cm, bg, ug, sm, same);
+    return mgr_cluster_exit(L.cm);
+  }
+}
+
 }  // namespace
 
 bool mgr_cluster_supported(int ks, int tpw) {
@@ -1425,9 +1459,14 @@ void mgr_cluster_geometry(const ClusterLaunch& L, bool any_exchange, int* waves,
   // 4-wave workgroups with <= 80 KiB of LDS fit two per CU (8 waves, <= 256 VGPRs each); anything else sits alone on its CU
   *per_cu = (*waves == 4 && (ks_eligible(L, any_exchange, *waves) || image_lds(L) <= 80 * 1024)) ? 2 : 1;
   if (L.pair && L.split16 && ks_eligible(L, any_exchange, *waves)) *per_cu = 1;   // (the pair form's 101 KiB of LDS: alone among scans on its CU)
+  if (L.fused && L.split16 && ks_eligible(L, any_exchange, *waves)) {              // (the fused form: 8 waves, 104 KiB, a CU of its own)
+    *waves = 8;
+    *per_cu = 1;
+  }
 }
 
 bool mgr_cluster_uses_ks(const ClusterLaunch& L, bool any_exchange) {
+  if (L.fused && L.split16 && ks_eligible(L, any_exchange, 4)) return true;
   int waves, per_cu;
   mgr_cluster_geometry(L, any_exchange, &waves, &per_cu);
   return ks_eligible(L, any_exchange, waves);
@@ -1454,8 +1493,17 @@ int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool a
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_k16p), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     c->attr_done |= 1u;
   }
-  MGR_REQUIRE(!L.xcd_local || ks_eligible(L, any_exchange, waves), "XCD-local layout is only understood by the K-split kernel");
-  if (ks_eligible(L, any_exchange, waves)) {
+  const bool fused = L.fused && L.split16 && ks_eligible(L, any_exchange, 4);
+  MGR_REQUIRE(!L.xcd_local || fused || ks_eligible(L, any_exchange, waves), "XCD-local layout is only understood by the K-split kernel");
+  if (fused) {
+    MGR_REQUIRE(L.xcd_local, "the fused form is laid out in octets");
+    static bool attr = false;
+    if (!attr) {
+      MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_k16f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr = true;
+    }
+    hipLaunchKernelGGL(k_scan_cluster_k16f, dim3(total_wgs), dim3(512), 2 * K16_LDS_FLOATS * sizeof(float), mgr_stream(c), L);
+  } else if (ks_eligible(L, any_exchange, waves)) {
     // partial-sum exchange, staging tiles of the transposed output, Z / R rings (no h image): 50 KiB, two workgroups per CU
     bool small = true;
     for (int i = 0; i < L.njobs; ++i) small = small && L.job[i].ks <= 32;

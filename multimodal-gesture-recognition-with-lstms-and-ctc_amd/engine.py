@@ -92,6 +92,12 @@ class Schedule:
     bptt_yields_beside_scans  (round 5) a narrow layer's BPTT that the schedule puts beside the next batch's encoder scans takes the form
                         that yields to them (mgr.h, tune key 16) instead of the one trimmed along its dependent chain (faster alone,
                         costs the step 0.1 - 0.2 ms there); bit-identical either way
+    fused_wide_tiles    (round 5) with fused encoder scans no GEMM shares a CU with a scan workgroup: the fusion layer's pre-split
+                        products take the library's own tile choice instead of the 4-wave forms
+    fused_encoder_scans (round 5; needs encoders_two_ahead) the encoder scans take the FUSED form (mgr.h, tune key 4 = 3: 8-wave
+                        workgroups that hold a CU each, 208 instead of 408) and leave 48 CUs to the fusion layer's recurrences, which
+                        are started once the encoder scan they run beside is resident (device-side waits for predicted launch numbers:
+                        a placement aid, bounded, never a correctness dependency)
     split_rows          (round 5) the transposed copies are written in the split row format (f16 hi / lo pairs) and the wide products
                         run as loader / matrix pipelines on pre-split operands (gemm_split.hip); False: f32 rows, converted by
                         every product that reads them (round 4's kernels)
@@ -103,7 +109,10 @@ class Schedule:
 
     def __init__(self, pipeline=True, defer_param_grads=True, encoders_run_ahead=True, resident_wait_us=2000,
                  transposed_inputs=True, bptt_beside_deepest_scan=True, split_rows=True, encoders_two_ahead=True,
-                 deepest_scan_after_fusion_proj=True, depth1_proj_ahead=False, bptt_yields_beside_scans=True):
+                 deepest_scan_after_fusion_proj=True, depth1_proj_ahead=True, bptt_yields_beside_scans=True,
+                 fused_encoder_scans=True, fused_wide_tiles=True):
+        self.fused_wide_tiles = bool(fused_wide_tiles)
+        self.fused_encoder_scans = bool(fused_encoder_scans)
         self.bptt_yields_beside_scans = bool(bptt_yields_beside_scans)
         self.depth1_proj_ahead = bool(depth1_proj_ahead)
         self.deepest_scan_after_fusion_proj = bool(deepest_scan_after_fusion_proj)
@@ -681,10 +690,14 @@ class Engine:
                 pair += [mptr, L.Wp, L.bp, self.ZF[di]]
             # (pipelined training: these GEMMs run while the next batch's deepest encoder scan holds the chip - the forms of the
             # pre-split products that fit on a CU beside a scan workgroup, not the 8-wave ones that wait for the scan to end)
-            with self._narrow_tiles(self._beside_scans):
+            with self._narrow_tiles(self._beside_scans and not self._wide_ok):
                 self._project_pair(feat_buf, W, pair, Ls_pair, B, T, W, Hf, XT=self._featT.get(feat_buf.ptr),
                                    xt_ready=self._featT_ready.get(feat_buf.ptr, False))
             dev.record(self.EV_FPROJ)   # (the next step's depth-1 scan is launched after these GEMMs, _enqueue_next_encoders)
+            if self._gate_seq[0] is not None:
+                # (Schedule.fused_encoder_scans: the fusion scan's 56 workgroups must land on the CUs the next batch's deepest encoder
+                #  scan - 208 whole CUs, released by the same event - leaves free, not on 56 CUs of their own)
+                dev.call("mgr_stream_wait_resident", int(self._gate_seq[0]), int(self.schedule.resident_wait_us))
             for di, dname in enumerate(("fwd", "bwd")):
                 L = self.dirs["fusion/%s" % dname]
                 jobs.append(dict(Z=self.ZF[di], Up=L.Up, Y=self.YF.view(di * Hf, (1,)), ldy=2 * Hf, R=0, ldr=0,
@@ -713,6 +726,8 @@ class Engine:
         self._feat = (feat, ldf)
         self.rng_step = saved_step
 
+    _wide_ok = False          # probe: with fused encoder scans no GEMM shares a CU with a scan workgroup - the library's own tile choice
+    _gate_seq = (None, None)  # fused encoder scans: the launch numbers the fusion scan / the BPTT of the step being enqueued wait for
     _early_for = None        # the inputs the generator started last was announced for
     _early_gen = None        # _next_encoders_free generator of the batch after next, its first part already enqueued
     _beside_scans = False    # the fusion layer's GEMMs of the step being enqueued run beside encoder scans of the next batch
@@ -1192,6 +1207,16 @@ class Engine:
             free_gen = self._next_encoders_free(next_inputs, depth, self.rng_step + 1, self._step_id + 1)
             next(free_gen)
         # ---- 2., 3. fusion layer, head, CTC, loss read-back point, backward
+        fused = bool(sch.fused_encoder_scans and free_gen is not None and early is not None)
+        self._gate_seq = (None, None)
+        if fused:
+            # persistent launches from here on, in host order: fusion scan (+1), BPTT (+2), the next batch's deepest scan (+3), and - when
+            # the batch after next is announced - its depth-1 scan (+4)
+            nl = C.c_int()
+            dev.call("mgr_persist_stats", C.byref(nl), None)
+            self._gate_seq = (nl.value + 3, nl.value + 4 if (prefetch_after_next and sch.encoders_two_ahead) else None)
+            self._wide_ok = bool(sch.fused_wide_tiles)
+            dev.call("mgr_tune", 4, 3)
         finish = self._enqueue_trainable_part(cur, rand, pipelined, defer, sch.bptt_beside_deepest_scan, have is None, apply_update)
 
         # ---- 4. parameter gradients + optimizer, and (pipelined) the next step's encoder pass
@@ -1218,6 +1243,10 @@ class Engine:
             self._enqueue_next_encoders(next_inputs, finish, defer, ahead, depth,
                                         free_running=bool(defer and sch.bptt_beside_deepest_scan and sp.fusion and not any_tr_stream_))
         self._beside_scans = False
+        if fused:
+            dev.call("mgr_tune", 4, 0)
+        self._wide_ok = False
+        self._gate_seq = (None, None)
         dev.stream(0)
 
     def _enqueue_trainable_part(self, cur, rand, beside_scans, defer, late_ok, own_inputs, apply_update):
@@ -1282,6 +1311,8 @@ class Engine:
             dev.stream(0)
             dev.record(self.EV_IN[self._xin_slot])   # trainable first layers read the inputs again in their dW GEMMs
 
+        gate_b = self._gate_seq[1]
+
         def finish(gate=None):
             """This step's (held-back) BPTT, its dW / dU / db GEMMs and the optimizer on stream 0.  gate: enqueues the device-side
             wait for the residency of the next persistent launch of the context - the deepest encoder scan the caller enqueues
@@ -1289,6 +1320,8 @@ class Engine:
             launch" would be the BPTT queued behind the gate) and in FRONT of the chip-filling GEMMs, which are what
             must not be placed before the scan's workgroups: recurrence beside recurrence starts at once, GEMMs wait."""
             dev.stream(0)
+            if gate_b is not None and late_bptt is not None:
+                dev.call("mgr_stream_wait_resident", int(gate_b), int(self.schedule.resident_wait_us))   # (as for the fusion scan)
             d = late_bptt() if late_bptt is not None else deferred
             if gate is not None:
                 gate()
@@ -1418,6 +1451,7 @@ class Engine:
         if getattr(self, "_ws_bwd_multi", None) is None or self._ws_bwd_multi.nbytes < need:
             self._ws_bwd_multi = self.mem.bytes(need)
         beside_scans = self._beside_scans     # (the deferred GEMMs run beside the next batch's encoder scans as well)
+        wide_ok = self._wide_ok
         yielding = beside_scans and self.schedule.bptt_yields_beside_scans
         if yielding:
             dev.call("mgr_tune", 16, 1)       # the form of the narrow-layer BPTT that yields to the encoder scans beside it (mgr.h)
@@ -1434,7 +1468,7 @@ class Engine:
                 H = L.H
                 mptr = self._masks.get((L.prefix, L.d), 0)
                 if mptr and XinT is not None and self._xt_split.get(XinT.ptr, False):
-                    with self._narrow_tiles(beside_scans):
+                    with self._narrow_tiles(beside_scans and not wide_ok):
                         dev.call("mgr_lstm_param_grads_dropout_ts", XinT, self.ldt, mptr, float(L.p), Hbuf.view(di * H, (1,)), ldh, L.dZ,
                                  L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes, L.dzmax)
                 elif mptr and XinT is not None and self.lib.mgr_lstm_param_grads_dropout_wants_transposed(

@@ -67,6 +67,35 @@ def test_config_F_full_size_step_and_pipelined_determinism(device):
     moved = [k for k in wf if not np.array_equal(wf[k], w[k])]
     assert moved and all(k.startswith(("fusion/", "dense/")) for k in moved)      # only the trainable part moved
 
+    # (3) round 5: the default schedule of bench.py / fit_generator - the encoder stream handed its work TWO calls ahead, FUSED encoder
+    # scans (8-wave workgroups, one per CU: only this shape has launches that take the form), the fusion layer's recurrences started
+    # behind their residency, the depth-1 projections in front of the deepest scan - against the plain schedule: the same losses and
+    # weights to the last bit over six steps
+    from mgr_amd.engine import Schedule
+
+    def run6(**sched):
+        eng = Engine(spec, B, T, Lmax, device=device, seed=5, schedule=Schedule(**sched))
+        eng.set_weights(w)
+        eng._upload_inputs(xs, None, True)
+        eng._upload_labels(labels, il, ll)
+        out = []
+        two = sched.get("encoders_two_ahead", True)
+        for i in range(6):
+            eng.enqueue_train_step(None, None, None, None, upload=False, prefetch_next=i < 5, prefetch_after_next=two and i < 4)
+            out.append(eng.read_loss())
+        device.sync()
+        wf_ = eng.get_weights()
+        nl, ns = ctypes.c_int(), ctypes.c_int()
+        device.call("mgr_persist_stats", ctypes.byref(nl), ctypes.byref(ns))
+        eng.close()
+        return out, wf_
+
+    la, wa = run6()
+    lp, wp = run6(fused_encoder_scans=False, depth1_proj_ahead=False, encoders_two_ahead=False)
+    assert la == lp and all(np.array_equal(wa[k], wp[k]) for k in wa)
+    device.call("mgr_scan_status", ctypes.byref(st))
+    assert st.value == 0
+
 
 def _oracle_chunk(args):
     """Pool worker: the oracle's loss_and_grads on a slice of the batch, in fp64 and in fp32 (the error model of

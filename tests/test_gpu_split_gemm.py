@@ -169,3 +169,56 @@ def test_pair_form_of_the_scan_is_bit_identical_and_scans_write_split_rows(devic
         y2, yts, o2 = run(pair, True)
         assert np.array_equal(y2, y0) and all(np.array_equal(a, b) for a, b in zip(o0, o2))
         assert np.array_equal(yts.view(np.uint32), _split_rows(y0, ldt).view(np.uint32))
+
+
+@pytest.mark.parametrize("B,T", [(64, 11), (55, 7)])
+def test_fused_form_of_the_encoder_scans_is_bit_identical(device, B, T):
+    """lstm_cluster.hip, k_scan_cluster_k16f (tune key 4 = 3): 8-wave workgroups that run TWO unit groups of their cluster, one workgroup
+    per CU - taken only by launches that do not fit one workgroup per CU as they are, i.e. the encoder depths of config F (audio H = 500 +
+    skeletal H = 300, both directions, B = 64: 408 workgroups -> 208).  Y, gates, c and the split transposed copies bit for bit those of
+    the default form; skeletal clusters have an odd number of unit groups (19): the last workgroup's second half only keeps the barriers."""
+    from mgr_amd import _capi
+    dev = device
+    hs = (500, 300)
+    rng = np.random.default_rng(B + T)
+    ldt = (T + 127) // 128 * 128
+    W = 2 * sum(hs)
+    R = dev.array(rng.uniform(-1, 1, (B, T, W)).astype(f32))
+    keep, base_jobs = [], []
+    col = 0
+    for H in hs:
+        for d in range(2):
+            Z = dev.array((rng.standard_normal((B, T, 4 * H)) * 0.5).astype(f32))
+            U = dev.array((rng.standard_normal((H, 4 * H)) * 0.1 / np.sqrt(H)).astype(f32))
+            Up = dev.empty((H, 4 * H))
+            dev.call("mgr_lstm_pack", U, Up, H, H, 0)
+            keep += [Z, U, Up]
+            base_jobs.append(dict(Z=Z, Up=Up, H=H, reverse=d, col=col))
+            col += H
+
+    def run(fused):
+        Y = dev.zeros((B, T, W))
+        YT = dev.array(np.full((B, W, ldt), 7.0, f32))
+        jobs, outs = [], []
+        for j in base_jobs:
+            H, c0 = j["H"], j["col"]
+            G, Cs = dev.zeros((B, T, H, 4)), dev.zeros((B, T, H))
+            outs += [G, Cs]
+            jobs.append(dict(Z=j["Z"], Up=j["Up"], Y=Y.view(c0, (1,)), ldy=W, R=R.view(c0, (1,)), ldr=W, gates=G, cs=Cs, B=B, T=T, H=H,
+                             reverse=j["reverse"], YT=YT.ptr + c0 * ldt * 4, ytb=W * ldt, ldt=ldt, yt_split=1))
+        dev.call("mgr_tune", 1, 1)
+        dev.call("mgr_tune", 4, 3 if fused else 0)
+        try:
+            arr = _capi.make_scan_jobs(jobs)
+            ws = dev.bytes(dev.lib.mgr_lstm_scan_multi_ws_bytes(len(jobs), arr))
+            _capi.check(dev.lib.mgr_lstm_scan_fwd_multi(dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes))
+        finally:
+            dev.call("mgr_tune", 1, 0)
+            dev.call("mgr_tune", 4, 0)
+        return Y.download(), YT.download(), [o.download() for o in outs]
+
+    y0, yt0, o0 = run(False)
+    y1, yt1, o1 = run(True)
+    assert np.isfinite(y0).all() and np.abs(y0).max() > 0.1
+    assert np.array_equal(y0, y1) and np.array_equal(yt0.view(np.uint32), yt1.view(np.uint32))
+    assert all(np.array_equal(a, b) for a, b in zip(o0, o1))

@@ -13,7 +13,12 @@ class ScanJob(C.Structure):
 B, T = 64, 1900
 HS = [tuple(int(h) for h in a.split("+")) for a in os.environ.get("SCAN_PROBE_H", "500+300,500").split(",")]
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+ref_out = {}
 for path in sys.argv[1:]:
+    tunes = []
+    while ":" in path and "=" in path.rsplit(":", 1)[1]:      # "<lib.so>:KEY=VALUE[:KEY=VALUE]" = mgr_tune settings for this run
+        path, kv = path.rsplit(":", 1)
+        tunes.append(tuple(int(x) for x in kv.split("=")))
     lib = C.CDLL(path)
     lib.mgr_lstm_scan_multi_ws_bytes.restype = sz
     lib.mgr_lstm_scan_multi_ws_bytes.argtypes = [i32, vp]
@@ -21,6 +26,7 @@ for path in sys.argv[1:]:
     lib.mgr_ctx_create.argtypes = [i32, C.POINTER(vp)]
     lib.mgr_alloc.argtypes = [vp, sz, C.POINTER(vp)]
     lib.mgr_h2d.argtypes = [vp, vp, vp, sz]
+    lib.mgr_d2h.argtypes = [vp, vp, vp, sz]
     lib.mgr_lstm_scan_fwd_multi.argtypes = [vp, i32, vp, vp, sz]
     lib.mgr_sync.argtypes = [vp]
     lib.mgr_event_record.argtypes = [vp, i32]
@@ -28,6 +34,10 @@ for path in sys.argv[1:]:
     lib.mgr_ctx_destroy.argtypes = [vp]
     ctx = vp()
     assert lib.mgr_ctx_create(0, C.byref(ctx)) == 0
+    if tunes:
+        lib.mgr_tune.argtypes = [vp, i32, i32]
+        for k, v in tunes:
+            assert lib.mgr_tune(ctx, k, v) == 0
 
     def alloc(n):
         p = vp()
@@ -57,7 +67,17 @@ for path in sys.argv[1:]:
         lib.mgr_event_record(ctx, 1)
         ms = C.c_float()
         lib.mgr_event_elapsed_ms(ctx, 0, 1, C.byref(ms))
-        print("%-28s H=%-10s %7.3f ms  %5.2f us/step" % (os.path.basename(path), hs, ms.value / 4, ms.value / 4 * 1e3 / T), flush=True)
+        print("%-28s H=%-10s %7.3f ms  %5.2f us/step" % (os.path.basename(path) + "".join(":%d=%d" % kv for kv in tunes), hs, ms.value / 4, ms.value / 4 * 1e3 / T), flush=True)
+        outs = []
+        for (Z, U, Y, H, rev) in jobs:
+            y = np.empty((B, T, H), np.float32)
+            lib.mgr_d2h(ctx, y.ctypes.data, Y, y.nbytes)
+            outs.append(y)
+        if hs not in ref_out:
+            ref_out[hs] = outs
+        else:
+            same = all(np.array_equal(a, b) for a, b in zip(outs, ref_out[hs]))
+            print("   outputs vs the first run: %s" % ("bit-identical" if same else "DIFFERENT (max |diff| %.3e)" % max(np.abs(a - b).max() for a, b in zip(outs, ref_out[hs]))), flush=True)
         if hasattr(lib, "mgr_debug_stamps"):   # a -DMGR_STAMP build: cycles per phase of the k16 step, averaged over all waves
             out = (C.c_ulonglong * 64)()
             lib.mgr_debug_stamps(out)
