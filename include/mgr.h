@@ -206,7 +206,10 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
  * key 16: 1 = the BPTT of narrow layers (H <= 128) launched next runs BESIDE persistent scans of another stream: it takes the form that
  *         yields to them (two barriers, partial sums through LDS) instead of the one trimmed along its dependent chain, which is faster
  *         alone (H = 100: 1.77 against 2.29 us per step) and costs the step beside them; same results bit for bit.  The engine sets it
- *         from its schedule (a deterministic choice: it never depends on what happens to be running). */
+ *         from its schedule (a deterministic choice: it never depends on what happens to be running).
+ *         2 = the direct gather: every wave fetches the words of its own cells from all sources, no partial sums through LDS, one barrier
+ *         per step - the fastest form alone (1.58 us per step), 4.7 x the texture-path traffic: for launches that have CUs of their own
+ *         (beside fused encoder scans).  All three forms give the same bits. */
 enum { MGR_TUNE_SCAN_PATH = 0, MGR_TUNE_COUNT = 24 };
 int mgr_tune(mgr_ctx* ctx, int key, int value);
 int mgr_tune_get(mgr_ctx* ctx, int key, int* value);   /* what a key is set to (a host of the library that lays out buffers by it) */

@@ -419,7 +419,10 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
             a0 += a1;
           }
           if (m == ug) {
-            own_tile = a0;
+            // (kept in registers - with the parity bit a published tile would carry, so that every form of the step, the direct
+            //  gather of cluster_bwd_run16 included, sums the same words)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) own_tile[r] = __uint_as_float((__float_as_uint(a0[r]) & ~1u) | par);
           } else {
             u32x4 w;
             w.x = (__float_as_uint(a0[0]) & ~1u) | par;
@@ -463,7 +466,12 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
 // Measured on the way and not kept (same notes): every wave gathering the words of its own cells from all G sources - no partial
 // sums through LDS, ONE barrier per step (1.58 us alone at H = 100 with 16-byte elements, 1.76 with component-major tiles; 20.2 /
 // 19.1 ms per step in config F: 28 KiB instead of 6 per workgroup and step through the texture path the encoder scans saturate).
-template <int H>
+// DIRECT: every wave gathers the words of ITS OWN cells from all G sources (one dword per source and lane: component `wave` of the
+// 16-byte element a source lane published; a workgroup's own tile travels through the exchange like the others) and sums them in the
+// same order - no partial sums through LDS, ONE barrier per step.  1.58 us per step alone at H = 100 (1.77 without), and 28 KiB per
+// workgroup and step through the texture path instead of 6: it lost 1 - 2 ms per step while encoder-scan workgroups shared its CUs,
+// and is the form the engine asks for (tune key 16 = 2) once the fused encoder scans leave the fusion layer CUs of its own.
+template <int H, bool DIRECT = false>
 __device__ __forceinline__ void cluster_bwd_run16(const ClusterBwdJob& jb, int bg, int ug, float* smem, unsigned* status, bool fast) {
   constexpr int N = 4 * H;
   constexpr int GT = (H + 15) / 16;
@@ -571,12 +579,19 @@ __device__ __forceinline__ void cluster_bwd_run16(const ClusterBwdJob& jb, int b
     const unsigned sbase = (unsigned)__builtin_amdgcn_readfirstlane(((k - 1) & 1) * SLOT * 4);   // (an SGPR operand: no waterfall loop)
     const bool gather = k > 0 && !failed;
     u32x4 v4[TPW];
+    unsigned vd[GT];
     const unsigned g4base = (unsigned)((ug * GT * 256 + lane * 4) * 4);
+    const unsigned gdbase = g4base + 4u * (unsigned)wave;   // DIRECT: component `wave` of the lane's element
     if (gather) {
+      if constexpr (DIRECT) {
 #pragma unroll
-      for (int i = 0; i < TPW; ++i) {
-        const int src = wave + BW_WAVES * i;
-        if (src < GT && src != ug) v4[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, g4base + src * 1024u, sbase, 16);
+        for (int sx = 0; sx < GT; ++sx) vd[sx] = __builtin_amdgcn_raw_buffer_load_b32(rs, gdbase + sx * 1024u, sbase, 16);   // sc1
+      } else {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+          const int src = wave + BW_WAVES * i;
+          if (src < GT && src != ug) v4[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, g4base + src * 1024u, sbase, 16);
+        }
       }
     }
     const float4 ug4 = *reinterpret_cast<const float4*>(ru + lane * 4);
@@ -586,6 +601,47 @@ __device__ __forceinline__ void cluster_bwd_run16(const ClusterBwdJob& jb, int b
     asm volatile("" : "+v"(tc));            // (computed HERE, under the gather - not sunk to its use behind the verification)
     __builtin_amdgcn_sched_barrier(0);
     float dhr = 0.f;
+    if constexpr (DIRECT) {
+      if (gather) {
+        const unsigned par = (((unsigned)(k - 1) >> 1) & 1u) ^ 1u;
+        for (bool again = false;; again = true) {   // (every exit lies behind a verification: lstm_cluster.hip, cluster_run_k16)
+          if (again) {
+#pragma unroll
+            for (int sx = 0; sx < GT; ++sx) vd[sx] = __builtin_amdgcn_raw_buffer_load_b32(rs, gdbase + sx * 1024u, sbase, 16);
+          }
+          unsigned a_and = 0xFFFFFFFFu, a_or = 0u;
+#pragma unroll
+          for (int sx = 0; sx < GT; ++sx) {
+            a_and &= vd[sx];
+            a_or |= vd[sx];
+          }
+          const bool fresh = par ? (a_and & 1u) != 0u : (a_or & 1u) == 0u;
+          if (__builtin_amdgcn_readfirstlane((int)(__all(fresh) || failed))) break;
+          spins = (unsigned)__builtin_amdgcn_readfirstlane((int)(spins + 1u));
+          if ((spins & 255u) == 0) {
+            unsigned st;
+            asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(st) : "v"(status) : "memory");
+            if (__builtin_amdgcn_readfirstlane(st) != 0u) failed = true;
+          }
+          if (spins > POLL_LIMIT) {
+            failed = true;
+            if (lane == 0) __hip_atomic_store(status, MGR_ST_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          failed = __builtin_amdgcn_readfirstlane((int)failed) != 0;
+          if (failed) break;
+        }
+        // the order of the other forms: wave w' summed its sources w', w' + 4 (ascending, from zero), then waves 0..3 in turn
+        float pw[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          pw[w] = 0.f;
+#pragma unroll
+          for (int i = 0; i < TPW; ++i)
+            if (w + BW_WAVES * i < GT) pw[w] += __uint_as_float(vd[w + BW_WAVES * i]);
+        }
+        dhr = pw[0] + pw[1] + pw[2] + pw[3];
+      }
+    } else
     {
       f32x4 sum = {0.f, 0.f, 0.f, 0.f};
       if (gather) {
@@ -722,8 +778,11 @@ __device__ __forceinline__ void cluster_bwd_run16(const ClusterBwdJob& jb, int b
           for (int q = 0; q < 4; ++q) as[q] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[i][q], bl[q], as[q], 0, 0, 0);
 #pragma unroll
           for (int r = 0; r < 4; ++r) a0[r] = fmaf(as[3][r], fs[3], fmaf(as[2][r], fs[2], fmaf(as[1][r], fs[1], as[0][r] * fs[0])));
-          if (m == ug) {
-            own_tile = a0;
+          if (m == ug && !DIRECT) {
+            // (kept in registers - with the parity bit a published tile would carry, so that every form of the step, the direct
+            //  gather included, sums the same words)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) own_tile[r] = __uint_as_float((__float_as_uint(a0[r]) & ~1u) | par);
           } else {
             u32x4 w;
             w.x = (__float_as_uint(a0[0]) & ~1u) | par;
@@ -758,7 +817,7 @@ __device__ __forceinline__ void cluster_bwd_run16(const ClusterBwdJob& jb, int b
 
 // SMALL: every job of the launch is narrow (H <= 128) - its own kernel, so that the fusion layer's BPTT (56 workgroups beside
 // the projection GEMMs of the other stream) is allocated ~100 VGPRs instead of the 256 the H = 500 instantiation needs
-template <bool SPLIT, bool SMALL = false, bool F16 = false, bool LEAN = false>
+template <bool SPLIT, bool SMALL = false, bool F16 = false, int LEAN = 0>
 __device__ __forceinline__ void scan_cluster_bwd_body(const ClusterBwdLaunch& L, float* smem) {
   mgr_cluster_enter(L.cm);
   const int bid = blockIdx.x;
@@ -781,8 +840,8 @@ __device__ __forceinline__ void scan_cluster_bwd_body(const ClusterBwdLaunch& L,
     if (bg < 0 || bg >= jb.nbg) continue;
 #define BW_CASE(HH)                                                                                                      \
   if (jb.H == HH) {                                                                                                      \
-    if constexpr (!SPLIT && SMALL && F16 && LEAN && (HH > 16))                                                                   \
-      cluster_bwd_run16<HH>(jb, bg, ug, smem, L.cm.status, fast);                                                        \
+    if constexpr (!SPLIT && SMALL && F16 && (LEAN != 0) && (HH > 16))                                                            \
+      cluster_bwd_run16<HH, LEAN == 2>(jb, bg, ug, smem, L.cm.status, fast);                                             \
     else                                                                                                                 \
       cluster_bwd_run<HH, SPLIT, F16>(jb, bg, ug, smem, L.cm.status, fast);                                              \
     return mgr_cluster_exit(L.cm);                                                                                       \
@@ -821,7 +880,12 @@ __global__ __launch_bounds__(BW_WAVES * 64) void k_scan_cluster_bwd16_s(ClusterB
 // narrow layers with the chip to themselves: cluster_bwd_run16
 __global__ __launch_bounds__(BW_WAVES * 64) void k_scan_cluster_bwd16_sl(ClusterBwdLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  scan_cluster_bwd_body<false, true, true, true>(L, smem);
+  scan_cluster_bwd_body<false, true, true, 1>(L, smem);
+}
+// ... with CUs of their own (beside fused encoder scans): the direct gather, one barrier per step
+__global__ __launch_bounds__(BW_WAVES * 64) void k_scan_cluster_bwd16_sd(ClusterBwdLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  scan_cluster_bwd_body<false, true, true, 2>(L, smem);
 }
 __global__ __launch_bounds__(BW_WAVES * 64, 2) void k_scan_cluster_bwd16(ClusterBwdLaunch L) {   // (two workgroups per CU: <= 256 VGPRs)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -878,6 +942,7 @@ int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs,
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd16_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd16_s), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd16_sl), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd16_sd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     c->attr_done |= 2u;
   }
   const bool f16 = c->tune[14] == 0;   // split-f16 operands (tune key 14 = 1: f32 MFMA)
@@ -891,7 +956,9 @@ int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs,
     size_t lds = (size_t)BW_LDS_FLOATS_A * sizeof(float);
     bool small = true;
     for (int i = 0; i < L.njobs; ++i) small = small && L.job[i].H <= 128;
-    if (small && f16 && alone)
+    if (small && f16 && c->tune[16] == 2)
+      hipLaunchKernelGGL(k_scan_cluster_bwd16_sd, dim3(total_wgs), dim3(BW_WAVES * 64), (size_t)BW_LDS_FLOATS_B * sizeof(float), mgr_stream(c), L);
+    else if (small && f16 && alone)
       hipLaunchKernelGGL(k_scan_cluster_bwd16_sl, dim3(total_wgs), dim3(BW_WAVES * 64), (size_t)BW_LDS_FLOATS_B * sizeof(float), mgr_stream(c), L);
     else if (small && f16)
       hipLaunchKernelGGL(k_scan_cluster_bwd16_s, dim3(total_wgs), dim3(BW_WAVES * 64), lds, mgr_stream(c), L);

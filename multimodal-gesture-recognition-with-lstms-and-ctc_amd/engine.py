@@ -92,6 +92,8 @@ class Schedule:
     bptt_yields_beside_scans  (round 5) a narrow layer's BPTT that the schedule puts beside the next batch's encoder scans takes the form
                         that yields to them (mgr.h, tune key 16) instead of the one trimmed along its dependent chain (faster alone,
                         costs the step 0.1 - 0.2 ms there); bit-identical either way
+    bptt_direct_when_alone  (round 5; measured, not the default) beside fused encoder scans the fusion layer's BPTT takes the direct-gather
+                        form (mgr.h, tune key 16 = 2: one barrier per step, the fastest form alone) - 16.64 - 16.72 against 16.60 - 16.61 ms
     fused_wide_tiles    (round 5) with fused encoder scans no GEMM shares a CU with a scan workgroup: the fusion layer's pre-split
                         products take the library's own tile choice instead of the 4-wave forms
     fused_encoder_scans (round 5; needs encoders_two_ahead) the encoder scans take the FUSED form (mgr.h, tune key 4 = 3: 8-wave
@@ -110,7 +112,8 @@ class Schedule:
     def __init__(self, pipeline=True, defer_param_grads=True, encoders_run_ahead=True, resident_wait_us=2000,
                  transposed_inputs=True, bptt_beside_deepest_scan=True, split_rows=True, encoders_two_ahead=True,
                  deepest_scan_after_fusion_proj=True, depth1_proj_ahead=True, bptt_yields_beside_scans=True,
-                 fused_encoder_scans=True, fused_wide_tiles=True):
+                 fused_encoder_scans=True, fused_wide_tiles=True, bptt_direct_when_alone=False):
+        self.bptt_direct_when_alone = bool(bptt_direct_when_alone)
         self.fused_wide_tiles = bool(fused_wide_tiles)
         self.fused_encoder_scans = bool(fused_encoder_scans)
         self.bptt_yields_beside_scans = bool(bptt_yields_beside_scans)
@@ -1207,7 +1210,10 @@ class Engine:
             free_gen = self._next_encoders_free(next_inputs, depth, self.rng_step + 1, self._step_id + 1)
             next(free_gen)
         # ---- 2., 3. fusion layer, head, CTC, loss read-back point, backward
-        fused = bool(sch.fused_encoder_scans and free_gen is not None and early is not None)
+        # (not with a host-blocking all-reduce: HostComm holds the host inside finish(), the depth-1 scan the BPTT's wait is for would only
+        #  be enqueued after it - the wait would always run into its bound; such runs share a GPU and use small per-rank batches anyway)
+        fused = bool(sch.fused_encoder_scans and free_gen is not None and early is not None
+                     and not getattr(self.comm, "host_blocking", False))
         self._gate_seq = (None, None)
         if fused:
             # persistent launches from here on, in host order: fusion scan (+1), BPTT (+2), the next batch's deepest scan (+3), and - when
@@ -1454,7 +1460,9 @@ class Engine:
         wide_ok = self._wide_ok
         yielding = beside_scans and self.schedule.bptt_yields_beside_scans
         if yielding:
-            dev.call("mgr_tune", 16, 1)       # the form of the narrow-layer BPTT that yields to the encoder scans beside it (mgr.h)
+            # the form of the narrow-layer BPTT that yields to the encoder scans beside it - or, beside FUSED encoder scans (CUs of its
+            # own), the direct gather with one barrier per step (mgr.h, tune key 16)
+            dev.call("mgr_tune", 16, 2 if (self._wide_ok or self._gate_seq[1] is not None) and self.schedule.bptt_direct_when_alone else 1)
         try:
             _capi.check(self.lib.mgr_lstm_scan_bwd_multi(dev.ctx, len(jobs), arr, self._ws_bwd_multi.ptr,
                                                          self._ws_bwd_multi.nbytes))

@@ -441,13 +441,14 @@ def test_bwd_multi_matches_oracle(device, B, T, H, path, f32_mfma):
                 dev.call("mgr_lstm_input_grad", dZ, Wp, 0, gX, F, 0, B, T, F, H)
                 assert rel_err(gX.download(), dx_ref) < 1e-4
         if f32_mfma == 0 and path == 0 and 16 < H <= 128:
-            # narrow layers have two forms of the split-f16 step (mgr.h, tune key 16): the one trimmed along its dependent chain (what ran
+            # narrow layers have three forms of the split-f16 step (mgr.h, tune key 16): the one trimmed along its dependent chain (what ran
             # above) and the one the engine asks for beside other persistent launches - same results bit for bit
             lean = [(o[2].download(), j["dzmax"].download()) for o, j in zip(outs, jobs)]
-            dev.call("mgr_tune", 16, 1)
-            _capi.check(dev.lib.mgr_lstm_scan_bwd_multi(dev.ctx, 2, arr, ws.ptr, ws.nbytes))
-            for (dz0, zm0), o, j in zip(lean, outs, jobs):
-                assert np.array_equal(o[2].download(), dz0) and np.array_equal(j["dzmax"].download(), zm0)
+            for form in (1, 2):      # 1: the form that yields to co-resident scans, 2: the direct gather (one barrier per step)
+                dev.call("mgr_tune", 16, form)
+                _capi.check(dev.lib.mgr_lstm_scan_bwd_multi(dev.ctx, 2, arr, ws.ptr, ws.nbytes))
+                for (dz0, zm0), o, j in zip(lean, outs, jobs):
+                    assert np.array_equal(o[2].download(), dz0) and np.array_equal(j["dzmax"].download(), zm0), form
     finally:
         dev.call("mgr_tune", 16, 0)
         dev.call("mgr_tune", 14, 0)

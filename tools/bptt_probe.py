@@ -19,6 +19,8 @@ for path in sys.argv[1:]:
     tune16 = 0
     if path.endswith(":16"):      # "<lib.so>:16" = the same library with tune key 16 = 1 (the form used beside other persistent launches)
         path, tune16 = path[:-3], 1
+    elif path.endswith(":16=2"):  # ... = 2: the direct gather (one barrier per step; the form used beside fused encoder scans)
+        path, tune16 = path[:-5], 2
     lib = C.CDLL(path)
     lib.mgr_lstm_scan_bwd_multi_ws_bytes.restype = sz
     lib.mgr_lstm_scan_bwd_multi_ws_bytes.argtypes = [i32, vp]
@@ -35,7 +37,7 @@ for path in sys.argv[1:]:
     assert lib.mgr_ctx_create(0, C.byref(ctx)) == 0
     if tune16:
         lib.mgr_tune.argtypes = [vp, i32, i32]
-        assert lib.mgr_tune(ctx, 16, 1) == 0
+        assert lib.mgr_tune(ctx, 16, tune16) == 0
 
     def alloc(n):
         p = vp()
@@ -91,7 +93,7 @@ for path in sys.argv[1:]:
                     if len(d):
                         i = tuple(d[0])
                         print("   %s: %d of %d differ; first at %s: %r vs %r; gates differing: %s" % (nm, len(d), a.size, i, a[i], b[i], sorted(set(int(x[-1]) % 4 for x in d[:2000]))))
-        print("%-24s H=%-4d %7.3f ms  %5.2f us/step   %s  (finite: %s)" % (os.path.basename(path) + (":16" if tune16 else ""), H, ms.value / 4, ms.value / 4 * 1e3 / T, cmp,
+        print("%-24s H=%-4d %7.3f ms  %5.2f us/step   %s  (finite: %s)" % (os.path.basename(path) + (":16=%d" % tune16 if tune16 else ""), H, ms.value / 4, ms.value / 4 * 1e3 / T, cmp,
                                                                              all(np.isfinite(a).all() for a in got)), flush=True)
         if hasattr(lib, "mgr_debug_bstamps"):
             out = (C.c_ulonglong * 64)()
