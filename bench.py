@@ -272,6 +272,9 @@ def main():
     import ctypes
     n_persist, n_serial = ctypes.c_int(), ctypes.c_int()
     dev.call("mgr_persist_stats", ctypes.byref(n_persist), ctypes.byref(n_serial))
+    # residency waits of the whole run (warm-up and every leg so far): how many were enqueued and how many ran into their bound - a
+    # wait at its bound costs its stream Schedule.resident_wait_us (2 ms) silently; the fused schedule is healthy when the second is 0
+    n_waits, n_waits_bound = eng.resident_wait_stats()
 
     frames = B * T * world * args.steps
     value = frames / dt
@@ -387,7 +390,8 @@ def main():
                "whole_step_frac_of_split16_peak_algorithmic": round(whole / MFMA_SPLIT16_PEAK_TFLOPS, 5),
                "whole_step_tflops_executed": round(whole_ex, 3),
                "whole_step_frac_of_f32_mfma_peak_executed": round(whole_ex / MFMA_F32_PEAK_TFLOPS, 5),
-               "persistent_launches": {"total": n_persist.value, "serialised_by_admission": n_serial.value},
+               "persistent_launches": {"total": n_persist.value, "serialised_by_admission": n_serial.value,
+                                       "residency_waits": n_waits, "waits_at_bound": n_waits_bound},
                "loss": losses[-1], "ctc_loss_parity": parity, "f32_mfma_path": f32_leg, "comm": comm_info, "kernel_ms": fam,
                "host_step_ms": {"median": round(sorted(b - a for a, b in zip(marks, marks[1:]))[len(marks) // 2 - 1 if len(marks) > 1 else 0] * 1e3, 3),
                                 "max": round(max(b - a for a, b in zip(marks, marks[1:])) * 1e3, 3),

@@ -183,6 +183,33 @@ typedef struct mgr_scan_job {
 } mgr_scan_job;
 size_t mgr_lstm_scan_multi_ws_bytes(int njobs, const mgr_scan_job* jobs);
 int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, void* ws, size_t ws_bytes);
+/* Explicit launch options of the two multi-scan calls (round 6; the same calls, with the choices a scheduler makes PER CALL passed
+ * as arguments instead of through context-wide tune keys, and with the launch number handed back).
+ *   struct_size  sizeof(mgr_scan_launch_opts) of the CALLER's header: members beyond it are taken as zero, so the struct can grow.
+ *   form         forward call: MGR_SCAN_FORM_*; backward call: MGR_BPTT_FORM_*.  AUTO (0) = what tune keys 4 / 16 say.
+ *   seq_out      host word (ordinary or page-locked memory; NULL: not wanted) that receives, BEFORE the call returns, the launch
+ *                number of the persistent multi-CU launch this call enqueued - what mgr_stream_wait_resident takes - or MGR_SEQ_NONE
+ *                when the call enqueued no launch that enters the residency ledger (single-CU kernels, fallbacks).  With a word from
+ *                mgr_host_alloc this is the hand-over for a wait that was enqueued BEFORE the launch it waits for
+ *                (mgr_stream_wait_resident_word). */
+enum { MGR_SCAN_FORM_AUTO = 0, MGR_SCAN_FORM_PLAIN = 1, MGR_SCAN_FORM_PAIR = 2, MGR_SCAN_FORM_FUSED = 3,
+       MGR_SCAN_FORM_FUSED_ANY = 4 };   /* FUSED: launches that do not fit one workgroup per CU as they are; FUSED_ANY: every launch the
+                                         * fused kernel can run (a narrow layer then holds ceil(G / 2) whole CUs per cluster) */
+enum { MGR_BPTT_FORM_AUTO = 0, MGR_BPTT_FORM_TRIMMED = 1, MGR_BPTT_FORM_YIELDING = 2, MGR_BPTT_FORM_DIRECT = 3 };   /* tune key 16 = 0 / 1 / 2 */
+#define MGR_SEQ_NONE 0xFFFFFFFFu
+typedef struct mgr_scan_launch_opts {
+  unsigned struct_size;
+  int form;
+  unsigned* seq_out;
+} mgr_scan_launch_opts;
+int mgr_lstm_scan_fwd_multi_ex(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, void* ws, size_t ws_bytes,
+                               const mgr_scan_launch_opts* opts);
+/* ABI guard for bindings that fill mgr_scan_job / mgr_scan_bwd_job / mgr_scan_launch_opts field by field: the sizes the LIBRARY was
+ * built with (round 5 appended mgr_scan_bwd_job.dzmax and turned mgr_scan_job's reserved word into yt_split - a caller built against
+ * an older header must not pass its structs to this library).  out[0..2] = sizeof of the three structs, out[3] =
+ * MGR_ABI_REVISION. */
+#define MGR_ABI_REVISION 6
+int mgr_abi_struct_sizes(unsigned out[4]);
 /* Tuning / test hooks.  key 0 (MGR_TUNE_SCAN_PATH): 0 auto, 1 force the L2-streaming fallback kernels,
  * 2 force one workgroup per batch group (no inter-CU exchange) where it fits, 3 force clusters with 4 tiles per
  * workgroup, 4 same with 8 tiles per workgroup.  key 1: !=0 makes scan_fwd check the give-up word synchronously.
@@ -253,6 +280,16 @@ int mgr_stream_wait_next_resident(mgr_ctx* ctx, int timeout_us);
 /* The same for ONE given launch: `seq` is the context's count of persistent launches (mgr_persist_stats: `launches`) read right
  * before that launch was enqueued, plus one.  Lets a stream wait for a launch that is already enqueued on another stream. */
 int mgr_stream_wait_resident(mgr_ctx* ctx, unsigned seq, int timeout_us);
+/* The same when the wait has to be enqueued BEFORE the launch it is for (the launch sits later in the host's order, on another
+ * stream): `seq_word` is a word of page-locked host memory (mgr_host_alloc) that the caller sets to 0 before this call and that the
+ * launch's call fills in (mgr_scan_launch_opts.seq_out = seq_word).  The wait kernel polls the word until it is non-zero, then waits
+ * for that launch's residency as mgr_stream_wait_resident does; MGR_SEQ_NONE releases it at once.  Bounded like the others. */
+int mgr_stream_wait_resident_word(mgr_ctx* ctx, const unsigned* seq_word, int timeout_us);
+/* Counters of the residency waits of this context since it was created (read on the current stream, a 16-byte read-back):
+ * out[0] = waits enqueued that have finished, out[1] = those that ran into their timeout (a wait whose launch never came, came too
+ * late, or could not become resident while the wait held its stream: each costs its full bound - silently, which is why this exists),
+ * out[2] = out[3] = 0. */
+int mgr_resident_wait_stats(mgr_ctx* ctx, unsigned out[4]);
 /* Persistent launches on different streams are admitted against the chip's workgroup slots; one that would not fit beside the
  * launches still in flight is ordered behind them (co-residency by construction).  Counters: launches so far, and how many of
  * them had to be serialised that way. */
@@ -287,6 +324,8 @@ typedef struct mgr_scan_bwd_job {
 } mgr_scan_bwd_job;
 size_t mgr_lstm_scan_bwd_multi_ws_bytes(int njobs, const mgr_scan_bwd_job* jobs);
 int mgr_lstm_scan_bwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_bwd_job* jobs, void* ws, size_t ws_bytes);
+int mgr_lstm_scan_bwd_multi_ex(mgr_ctx* ctx, int njobs, const mgr_scan_bwd_job* jobs, void* ws, size_t ws_bytes,
+                               const mgr_scan_launch_opts* opts);   /* opts->form: MGR_BPTT_FORM_* */
 /* Parameter gradients from dZ (all packed layouts, f32 MFMA split-K GEMMs, deterministic slab reduce):
  *   dWp[F,4H] = sum_rows (X (.) mask4)^T dZ ;  dUp[H,4H] = sum_rows hprev^T dZ ;  dbp[4H] = sum_rows dZ
  * Hs is the layer's own un-residualed output h (row stride ldh); hprev is its time-shifted view. */

@@ -57,6 +57,8 @@ SIGNATURES = {
     "mgr_lstm_scan_fwd": (i32, [vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, sz]),
     "mgr_lstm_scan_multi_ws_bytes": (sz, [i32, vp]),
     "mgr_lstm_scan_fwd_multi": (i32, [vp, i32, vp, vp, sz]),
+    "mgr_lstm_scan_fwd_multi_ex": (i32, [vp, i32, vp, vp, sz, vp]),
+    "mgr_abi_struct_sizes": (i32, [vp]),
     "mgr_tune": (i32, [vp, i32, i32]),
     "mgr_tune_get": (i32, [vp, i32, C.POINTER(i32)]),
     "mgr_probe_xcc": (i32, [vp, i32, i32, i32, vp]),
@@ -74,10 +76,13 @@ SIGNATURES = {
     "mgr_update_gate_set": (i32, [vp, vp]),
     "mgr_stream_wait_next_resident": (i32, [vp, i32]),
     "mgr_stream_wait_resident": (i32, [vp, C.c_uint, i32]),
+    "mgr_stream_wait_resident_word": (i32, [vp, vp, i32]),
+    "mgr_resident_wait_stats": (i32, [vp, vp]),
     "mgr_persist_stats": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
     "mgr_skeletal_features": (i32, [vp, vp, sz, vp]),
     "mgr_lstm_scan_bwd_multi_ws_bytes": (sz, [i32, vp]),
     "mgr_lstm_scan_bwd_multi": (i32, [vp, i32, vp, vp, sz]),
+    "mgr_lstm_scan_bwd_multi_ex": (i32, [vp, i32, vp, vp, sz, vp]),
     "mgr_lstm_scan_bwd": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz]),
     "mgr_lstm_param_grads_ws_bytes": (sz, [i32, i32, i32, i32]),
     "mgr_lstm_param_grads": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz]),
@@ -132,6 +137,27 @@ class ScanBwdJob(C.Structure):
                 ("lddy", i32), ("B", i32), ("T", i32), ("H", i32), ("reverse", i32), ("dzmax", vp)]
 
 
+class ScanLaunchOpts(C.Structure):
+    """struct mgr_scan_launch_opts"""
+    _fields_ = [("struct_size", C.c_uint), ("form", i32), ("seq_out", vp)]
+
+
+# enums of include/mgr.h (mgr_scan_launch_opts.form)
+SCAN_FORM_AUTO, SCAN_FORM_PLAIN, SCAN_FORM_PAIR, SCAN_FORM_FUSED, SCAN_FORM_FUSED_ANY = range(5)
+BPTT_FORM_AUTO, BPTT_FORM_TRIMMED, BPTT_FORM_YIELDING, BPTT_FORM_DIRECT = range(4)
+SEQ_NONE = 0xFFFFFFFF
+ABI_REVISION = 6
+
+
+def make_launch_opts(form=0, seq_out=0):
+    """seq_out: address of a host word (e.g. element of a Device.pinned() array: arr.ctypes.data + 4 * i) or 0."""
+    o = ScanLaunchOpts()
+    o.struct_size = C.sizeof(ScanLaunchOpts)
+    o.form = int(form)
+    o.seq_out = int(seq_out) or None
+    return o
+
+
 def make_scan_bwd_jobs(jobs):
     arr = (ScanBwdJob * len(jobs))()
     for a, j in zip(arr, jobs):
@@ -181,6 +207,11 @@ def load_library(build_if_missing=True):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    # ABI guard: this binding fills the job structs field by field - the library must have been built from the same header
+    sizes = (C.c_uint * 4)()
+    if lib.mgr_abi_struct_sizes(sizes) != 0 or tuple(sizes) != (C.sizeof(ScanJob), C.sizeof(ScanBwdJob), C.sizeof(ScanLaunchOpts), ABI_REVISION):
+        raise MgrError("libmgr.so was built from another include/mgr.h than this binding (struct sizes / revision %s, expected %s): rebuild it"
+                       % (tuple(sizes), (C.sizeof(ScanJob), C.sizeof(ScanBwdJob), C.sizeof(ScanLaunchOpts), ABI_REVISION)))
     _lib = lib
     return lib
 

@@ -41,7 +41,7 @@ struct mgr_ctx {
   // persistent launches that may still be running (lstm.hip: mgr_persist_admit / mgr_persist_commit)
   struct Persist {
     hipEvent_t done;
-    int active, stream, wgs, waves, per_cu;
+    int active, stream, wgs, waves, per_cu, fused;
     unsigned seq;
   };
   Persist persist[MGR_MAX_PERSIST];

@@ -4,6 +4,7 @@
 //   backward: H <= 128 -> lstm_mfma.hip (single-CU weight-stationary MFMA)
 //   anything else (H <= 1024) -> lstm_simple.hip (U streamed from L2; correctness fallback)
 #include <algorithm>
+#include <cstddef>
 
 #include "common.h"
 #include "lstm_cluster.h"
@@ -222,8 +223,39 @@ size_t mgr_lstm_scan_multi_ws_bytes(int njobs, const mgr_scan_job* jobs) {
   return s;
 }
 
+// what a mgr_scan_launch_opts says, read through its own struct_size (members beyond it are zero)
+static void read_opts(const mgr_scan_launch_opts* o, int* form, unsigned** seq_out) {
+  *form = 0;
+  *seq_out = nullptr;
+  if (!o) return;
+  if (o->struct_size >= offsetof(mgr_scan_launch_opts, form) + sizeof(o->form)) *form = o->form;
+  if (o->struct_size >= offsetof(mgr_scan_launch_opts, seq_out) + sizeof(o->seq_out)) *seq_out = o->seq_out;
+}
+
+int mgr_abi_struct_sizes(unsigned out[4]) {
+  MGR_REQUIRE(out, "null argument");
+  out[0] = (unsigned)sizeof(mgr_scan_job);
+  out[1] = (unsigned)sizeof(mgr_scan_bwd_job);
+  out[2] = (unsigned)sizeof(mgr_scan_launch_opts);
+  out[3] = MGR_ABI_REVISION;
+  return 0;
+}
+
 int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, void* ws, size_t ws_bytes) {
+  return mgr_lstm_scan_fwd_multi_ex(c, njobs, jobs, ws, ws_bytes, nullptr);
+}
+
+int mgr_lstm_scan_fwd_multi_ex(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, void* ws, size_t ws_bytes,
+                               const mgr_scan_launch_opts* opts) {
   MGR_REQUIRE(c && jobs && njobs > 0 && njobs <= MGR_MAX_SCAN_JOBS, "bad job list");
+  int form;
+  unsigned* seq_out;
+  read_opts(opts, &form, &seq_out);
+  MGR_REQUIRE(form >= MGR_SCAN_FORM_AUTO && form <= MGR_SCAN_FORM_FUSED_ANY, "unknown scan form %d", form);
+  if (seq_out) *seq_out = MGR_SEQ_NONE;   // (until a launch of this call enters the residency ledger)
+  // the form of the split-f16 K-split launches: the caller's, or tune key 4 (0 plain, 2 pair, 3 fused)
+  const int key4 = form == MGR_SCAN_FORM_AUTO ? c->tune[4] : form == MGR_SCAN_FORM_PLAIN ? 0 : form == MGR_SCAN_FORM_FUSED_ANY ? 3 : form;
+  const bool fused_any = form == MGR_SCAN_FORM_FUSED_ANY;
   for (int i = 0; i < njobs; ++i) {
     const mgr_scan_job& j = jobs[i];
     MGR_REQUIRE(j.Z && j.Up && j.Y, "job %d: null argument", i);
@@ -269,7 +301,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     // tune key 4: 2 = take it whenever the launch qualifies.
     int nbg16[MGR_MAX_SCAN_JOBS];
     for (int i = 0; i < njobs; ++i) nbg16[i] = P.cluster[i] ? P.nbg[i] : 0;
-    bool pair = ks_ok && P.exchange && c->tune[14] == 0 && c->tune[4] == 2;
+    bool pair = ks_ok && P.exchange && c->tune[14] == 0 && key4 == 2;
     {
       int unpaired = 0, most = 0;
       for (int i = 0; i < njobs && pair; ++i) {
@@ -286,7 +318,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     }
     // Fused form (lstm_cluster.hip, k_scan_cluster_k16f): 8-wave workgroups that run TWO unit groups of their cluster, one workgroup
     // per CU (config F's encoder depths: 208 workgroups on 208 CUs, 48 CUs left to the other stream).  tune key 4: 3.
-    bool fused = !pair && ks_ok && P.exchange && c->tune[14] == 0 && c->tune[4] == 3 && c->tune[3] == 0;
+    bool fused = !pair && ks_ok && P.exchange && c->tune[14] == 0 && key4 == 3 && c->tune[3] == 0;
     for (int i = 0; i < njobs && fused; ++i) {
       if (!P.cluster[i]) continue;
       fused = P.cfg[i].nw == 4 && P.cfg[i].tpw == 1 && P.G[i] > 1 && mgr_cluster_ks_supported(jobs[i].H / 4);
@@ -295,7 +327,7 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
       int unf = 0;
       for (int i = 0; i < njobs; ++i)
         if (P.cluster[i]) unf += P.G[i] * P.nbg[i];
-      fused = fused && unf > c->cu_count;
+      fused = fused && (fused_any || unf > c->cu_count);
     }
     auto members = [&](int i) { return fused ? (P.G[i] + 1) / 2 : P.G[i]; };   // workgroups per cluster
     bool xcd = c->tune[3] == 0 && ks_ok && P.exchange;
@@ -379,15 +411,16 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, voi
     L.cm.total_wgs = P.total;
     // (a launch without an exchange spins on nobody: it needs no place in the ledger and is never ordered behind one)
     if (P.exchange) {
-      r = mgr_persist_admit(c, live, waves, per_cu, &L.cm.seq);
+      r = mgr_persist_admit(c, live, waves, per_cu, L.fused, &L.cm.seq);
       if (r) return r;
+      if (seq_out) *seq_out = L.cm.seq;
     }
     // exchange slots + status must be zero at every launch (epochs count from 1 within the call)
     MGR_HIP(hipMemsetAsync(base, 0, (size_t)(w - base), mgr_stream(c)));
     r = mgr_cluster_launch(c, L, P.total, P.exchange);
     if (r) return r;
     if (P.exchange) {
-      r = mgr_persist_commit(c, live, waves, per_cu);
+      r = mgr_persist_commit(c, live, waves, per_cu, L.fused);
       if (r) return r;
     }
   }
@@ -420,7 +453,18 @@ int mgr_lstm_scan_fwd(mgr_ctx* c, const float* Z, const float* Up, float* Y, int
 }
 
 int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs, void* ws, size_t ws_bytes) {
+  return mgr_lstm_scan_bwd_multi_ex(c, njobs, jobs, ws, ws_bytes, nullptr);
+}
+
+int mgr_lstm_scan_bwd_multi_ex(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs, void* ws, size_t ws_bytes,
+                               const mgr_scan_launch_opts* opts) {
   MGR_REQUIRE(c && jobs && njobs > 0 && njobs <= MGR_MAX_SCAN_JOBS, "bad job list");
+  int form;
+  unsigned* seq_out;
+  read_opts(opts, &form, &seq_out);
+  MGR_REQUIRE(form >= MGR_BPTT_FORM_AUTO && form <= MGR_BPTT_FORM_DIRECT, "unknown BPTT form %d", form);
+  if (seq_out) *seq_out = MGR_SEQ_NONE;
+  const int key16 = form == MGR_BPTT_FORM_AUTO ? c->tune[16] : form - 1;   // 0 trimmed, 1 yielding, 2 direct gather
   MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_scan_bwd_multi_ws_bytes(njobs, jobs), "workspace too small");
   for (int i = 0; i < njobs; ++i) {
     const mgr_scan_bwd_job& j = jobs[i];
@@ -483,12 +527,13 @@ int mgr_lstm_scan_bwd_multi(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jobs,
     L.cm.sticky = mgr_status_block(c);
     L.cm.resident = c->sticky_status + 1;
     L.cm.total_wgs = grid;
-    r = mgr_persist_admit(c, grid, waves, per_cu, &L.cm.seq);
+    r = mgr_persist_admit(c, grid, waves, per_cu, 0, &L.cm.seq);
     if (r) return r;
+    if (seq_out) *seq_out = L.cm.seq;
     MGR_HIP(hipMemsetAsync(base, 0, (size_t)(w - base), mgr_stream(c)));
-    r = mgr_cluster_bwd_launch(c, L, grid, c->tune[16] == 0);
+    r = mgr_cluster_bwd_launch(c, L, grid, key16);
     if (r) return r;
-    r = mgr_persist_commit(c, grid, waves, per_cu);
+    r = mgr_persist_commit(c, grid, waves, per_cu, 0);
     if (r) return r;
   }
   // the single-CU kernel takes every job that is left in ONE launch when they share a shape (the two directions of a layer)
@@ -554,13 +599,13 @@ int mgr_lstm_scan_bwd(mgr_ctx* c, const float* dY, int lddy, const float* gates,
 // a CU holds two 4-wave or one 8-wave workgroup of these kernels (they use > 128 VGPRs); as soon as any launch needs a CU of its
 // own, every workgroup in flight is counted as a whole CU (4-wave workgroups are dealt one per CU first, so each may block one).
 // Kernels that are not persistent (GEMMs, ...) leave on their own and need no entry.
-int mgr_persist_admit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu, unsigned* seq_out) {
+int mgr_persist_admit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu, int fused, unsigned* seq_out) {
   (void)waves_per_wg;
   bool ordered[MGR_MAX_PERSIST] = {};   // launches this one has been put behind
   for (;;) {
     // launches of ONE stream run one after the other: a stream can hold at most its largest launch on the chip at a time
     int per_stream[MGR_NUM_STREAMS] = {}, cus_stream[MGR_NUM_STREAMS] = {};
-    int any_excl = per_cu == 1 ? 1 : 0, oldest = -1;
+    int any_excl = per_cu == 1 ? 1 : 0, any_fused = fused ? 1 : 0, oldest = -1;
     for (int i = 0; i < MGR_MAX_PERSIST; ++i) {
       mgr_ctx::Persist& e = c->persist[i];
       if (!e.active || ordered[i] || e.stream == c->cur) continue;   // (same stream: ordered before this launch anyway)
@@ -572,6 +617,7 @@ int mgr_persist_admit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu, unsigne
       const int cus = (e.wgs + e.per_cu - 1) / e.per_cu;
       cus_stream[e.stream] = cus > cus_stream[e.stream] ? cus : cus_stream[e.stream];
       any_excl |= e.per_cu == 1;
+      any_fused |= e.fused;
       if (oldest < 0 || e.seq < c->persist[oldest].seq) oldest = i;
     }
     int shared = wgs, cus = (wgs + per_cu - 1) / per_cu;
@@ -579,9 +625,10 @@ int mgr_persist_admit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu, unsigne
       shared += per_stream[s];
       cus += cus_stream[s];
     }
-    // tune key 4 = 3 (fused scans: 8-wave workgroups that fill a CU's register file): beside them the 4-wave launches are counted by the
-    // CUs they need two to a CU - their caller (the engine) starts them once the exclusive launch is resident, so that they do land there
-    const bool by_cus = any_excl && c->tune[4] == 3;
+    // fused scans (8-wave workgroups that fill a CU's register file - this launch, or one in flight): beside them the 4-wave launches are
+    // counted by the CUs they need two to a CU - their caller (the engine) starts them once the exclusive launch is resident, so that
+    // they do land there.  (A property of the LAUNCHES in the ledger since round 6, not of a tune key that happens to be set.)
+    const bool by_cus = any_excl && any_fused;
     const int capacity = any_excl ? c->cu_count : 2 * c->cu_count;
     if (oldest < 0 || (by_cus ? cus : shared) <= capacity) break;
     // does not fit beside what may still be running: run behind the oldest of them, then look again
@@ -593,7 +640,7 @@ int mgr_persist_admit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu, unsigne
   return 0;
 }
 
-int mgr_persist_commit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu) {
+int mgr_persist_commit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu, int fused) {
   int slot = -1;
   for (int i = 0; i < MGR_MAX_PERSIST && slot < 0; ++i)
     if (!c->persist[i].active) slot = i;
@@ -616,34 +663,71 @@ int mgr_persist_commit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu) {
   e.wgs = wgs;
   e.waves = waves_per_wg;
   e.per_cu = per_cu;
+  e.fused = fused ? 1 : 0;
   e.seq = c->persist_seq;
   return 0;
 }
 
 namespace {
-// one lane polls the context's "resident" word until the launch with sequence number `seq` has all its workgroups on the chip
-__global__ void k_wait_resident(const unsigned* resident, unsigned seq, unsigned timeout_us) {
+// One lane polls the context's residency words until the launch with sequence number `seq` has all its workgroups on the chip.
+// seq_word != nullptr: the number is not known yet when the wait is enqueued - it arrives in a word of page-locked host memory
+// that the launch's call fills in (mgr_scan_launch_opts.seq_out); MGR_SEQ_NONE there = no such launch: nothing to wait for.
+// counters[0] counts the waits that have ended, counters[1] those that ended by their timeout (mgr_resident_wait_stats).
+__global__ void k_wait_resident(const unsigned* resident, const unsigned* ring, const unsigned* seq_word, unsigned seq, unsigned timeout_us,
+                                unsigned* counters) {
   const unsigned long long t0 = wall_clock64();   // 100 MHz
-  while (__hip_atomic_load(resident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+  bool expired = false;
+  for (;;) {
+    if (seq_word && seq == 0u) seq = __hip_atomic_load(seq_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (seq == MGR_SEQ_NONE) break;
+    if (seq != 0u) {
+      const unsigned* w = ring ? ring + (seq & 15u) : resident;
+      if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seq) break;
+    }
     __builtin_amdgcn_s_sleep(32);
-    if (wall_clock64() - t0 > 100ull * timeout_us) break;   // placement hint only: never a correctness dependency
+    if (wall_clock64() - t0 > 100ull * timeout_us) {   // placement hint only: never a correctness dependency
+      expired = true;
+      break;
+    }
   }
+  __hip_atomic_fetch_add(counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (expired) __hip_atomic_fetch_add(counters + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+constexpr int kWaitCounters = 32;   // words [32, 34) of the context's own status block
 }  // namespace
 
 extern "C" {
 
 int mgr_stream_wait_next_resident(mgr_ctx* c, int timeout_us) {
   MGR_REQUIRE(c && timeout_us >= 0 && timeout_us <= 100000, "timeout_us must be in [0, 100000]");
-  hipLaunchKernelGGL(k_wait_resident, dim3(1), dim3(1), 0, mgr_stream(c), c->sticky_status + 1, c->persist_seq + 1, (unsigned)timeout_us);
+  hipLaunchKernelGGL(k_wait_resident, dim3(1), dim3(1), 0, mgr_stream(c), c->sticky_status + 1, nullptr, nullptr, c->persist_seq + 1,
+                     (unsigned)timeout_us, c->sticky_status + kWaitCounters);
   MGR_LAUNCH_CHECK();
   return 0;
 }
 
 int mgr_stream_wait_resident(mgr_ctx* c, unsigned seq, int timeout_us) {
   MGR_REQUIRE(c && timeout_us >= 0 && timeout_us <= 100000, "timeout_us must be in [0, 100000]");
-  hipLaunchKernelGGL(k_wait_resident, dim3(1), dim3(1), 0, mgr_stream(c), c->sticky_status + 16 + (seq & 15u), seq, (unsigned)timeout_us);
+  MGR_REQUIRE(seq != 0u, "launch numbers start at 1");
+  hipLaunchKernelGGL(k_wait_resident, dim3(1), dim3(1), 0, mgr_stream(c), c->sticky_status + 1, c->sticky_status + 16, nullptr, seq,
+                     (unsigned)timeout_us, c->sticky_status + kWaitCounters);
   MGR_LAUNCH_CHECK();
+  return 0;
+}
+
+int mgr_stream_wait_resident_word(mgr_ctx* c, const unsigned* seq_word, int timeout_us) {
+  MGR_REQUIRE(c && seq_word && timeout_us >= 0 && timeout_us <= 100000, "null word / timeout_us must be in [0, 100000]");
+  hipLaunchKernelGGL(k_wait_resident, dim3(1), dim3(1), 0, mgr_stream(c), c->sticky_status + 1, c->sticky_status + 16, seq_word, 0u,
+                     (unsigned)timeout_us, c->sticky_status + kWaitCounters);
+  MGR_LAUNCH_CHECK();
+  return 0;
+}
+
+int mgr_resident_wait_stats(mgr_ctx* c, unsigned out[4]) {
+  MGR_REQUIRE(c && out, "null argument");
+  MGR_HIP(hipMemcpyAsync(out, c->sticky_status + kWaitCounters, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, mgr_stream(c)));
+  MGR_HIP(hipStreamSynchronize(mgr_stream(c)));
+  out[2] = out[3] = 0;
   return 0;
 }
 

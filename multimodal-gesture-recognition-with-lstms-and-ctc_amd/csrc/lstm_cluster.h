@@ -96,11 +96,11 @@ struct ClusterBwdLaunch {
 bool mgr_cluster_bwd_supported(int H);
 size_t mgr_cluster_bwd_img_floats(int H);
 void mgr_cluster_bwd_geometry(const mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs, int* waves, int* per_cu);
-int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs, bool alone);
+int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs, int form16);   // form16: 0 trimmed, 1 yielding, 2 direct (mgr.h, tune key 16)
 
 // ---- admission of persistent launches (lstm.hip): co-residency by construction across the streams of a context
-int mgr_persist_admit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu, unsigned* seq_out);
-int mgr_persist_commit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu);
+int mgr_persist_admit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu, int fused, unsigned* seq_out);
+int mgr_persist_commit(mgr_ctx* c, int wgs, int waves_per_wg, int per_cu, int fused);
 
 #ifdef __HIPCC__
 // first thing a workgroup of a persistent kernel does: count itself in; the last arrival publishes the launch as resident

@@ -1497,10 +1497,9 @@ int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool a
   MGR_REQUIRE(!L.xcd_local || fused || ks_eligible(L, any_exchange, waves), "XCD-local layout is only understood by the K-split kernel");
   if (fused) {
     MGR_REQUIRE(L.xcd_local, "the fused form is laid out in octets");
-    static bool attr = false;
-    if (!attr) {
+    if (!(c->attr_done & 4u)) {   // (per device, hence per context - like the block above)
       MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_k16f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr = true;
+      c->attr_done |= 4u;
     }
     hipLaunchKernelGGL(k_scan_cluster_k16f, dim3(total_wgs), dim3(512), 2 * K16_LDS_FLOATS * sizeof(float), mgr_stream(c), L);
   } else if (ks_eligible(L, any_exchange, waves)) {

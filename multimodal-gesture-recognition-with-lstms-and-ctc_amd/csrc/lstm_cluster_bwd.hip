@@ -932,7 +932,8 @@ void mgr_cluster_bwd_geometry(const mgr_ctx* c, const ClusterBwdLaunch& L, int t
   *per_cu = split ? 1 : 2;
 }
 
-int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs, bool alone) {
+int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs, int form16) {
+  const bool alone = form16 == 0;
   MGR_REQUIRE(total_wgs <= 2 * c->cu_count, "cluster BPTT needs %d co-resident workgroups", total_wgs);
   if (!(c->attr_done & 2u)) {
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -956,7 +957,7 @@ int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs,
     size_t lds = (size_t)BW_LDS_FLOATS_A * sizeof(float);
     bool small = true;
     for (int i = 0; i < L.njobs; ++i) small = small && L.job[i].H <= 128;
-    if (small && f16 && c->tune[16] == 2)
+    if (small && f16 && form16 == 2)
       hipLaunchKernelGGL(k_scan_cluster_bwd16_sd, dim3(total_wgs), dim3(BW_WAVES * 64), (size_t)BW_LDS_FLOATS_B * sizeof(float), mgr_stream(c), L);
     else if (small && f16 && alone)
       hipLaunchKernelGGL(k_scan_cluster_bwd16_sl, dim3(total_wgs), dim3(BW_WAVES * 64), (size_t)BW_LDS_FLOATS_B * sizeof(float), mgr_stream(c), L);

@@ -96,10 +96,12 @@ class Schedule:
                         form (mgr.h, tune key 16 = 2: one barrier per step, the fastest form alone) - 16.64 - 16.72 against 16.60 - 16.61 ms
     fused_wide_tiles    (round 5) with fused encoder scans no GEMM shares a CU with a scan workgroup: the fusion layer's pre-split
                         products take the library's own tile choice instead of the 4-wave forms
-    fused_encoder_scans (round 5; needs encoders_two_ahead) the encoder scans take the FUSED form (mgr.h, tune key 4 = 3: 8-wave
+    fused_encoder_scans (round 5; needs encoders_two_ahead) the encoder scans take the FUSED form (mgr.h, MGR_SCAN_FORM_FUSED: 8-wave
                         workgroups that hold a CU each, 208 instead of 408) and leave 48 CUs to the fusion layer's recurrences, which
-                        are started once the encoder scan they run beside is resident (device-side waits for predicted launch numbers:
-                        a placement aid, bounded, never a correctness dependency)
+                        are started once the encoder scan they run beside is resident.  Round 6: the form is an argument of each
+                        launch and the launch number each wait is for is HANDED OVER by the launch itself (a page-locked word the
+                        wait kernel polls, mgr_stream_wait_resident_word) - no context-wide tune key, no predicted numbers; a wait
+                        that runs into its bound is counted (Engine.resident_wait_stats)
     split_rows          (round 5) the transposed copies are written in the split row format (f16 hi / lo pairs) and the wide products
                         run as loader / matrix pipelines on pre-split operands (gemm_split.hip); False: f32 rows, converted by
                         every product that reads them (round 4's kernels)
@@ -174,6 +176,11 @@ class Engine:
         self._pass_status = [dev.zeros((16,), np.uint32) for _ in range(2)]
         self.loss_host = dev.pinned((4,), np.float32)
         self.status_host = dev.pinned((4,), np.uint32)
+        # launch numbers handed from a persistent scan launch to the residency wait that was enqueued before it (page-locked: the
+        # wait kernel polls the word; mgr_stream_wait_resident_word).  A ring: two words per step, reused eight steps later.
+        self._seq_words = dev.pinned((16,), np.uint32)
+        self._seq_words[...] = 0
+        self._seq_next = 0
         # data parallel: [gate flag, sum over ranks of the local mean losses, -, -] of step s in slot s & 1, copied from behind the
         # all-reduced gradient buffer (apply_gradients); read by read_global_loss
         self.gloss_host = [dev.pinned((4,), np.float32) for _ in range(2)]
@@ -561,14 +568,17 @@ class Engine:
                 self.dev.stream(es)
                 self.dev.wait(es, hold_scans_for)
 
-    def _encoder_phases(self, train, rand, feat_buf, es, rng_step, first_stream=None, z_first=None):
+    def _encoder_phases(self, train, rand, feat_buf, es, rng_step, first_stream=None, z_first=None, seq_words=None):
         """Generator form of the encoder pass: yields ("projected", k) after the projection GEMMs of depth k are enqueued
         (before its scan) and ("scanned", k) after its multi-scan launch, so that a caller can interleave work of another
         stream at those points.  Re-selects stream `es` after every resume; self.rng_step is only switched to `rng_step`
         while the generator body runs.
         first_stream / z_first (pipelined inference): the noise kernels and the depth-1 projections are enqueued on stream
         `first_stream` instead, into the gate pre-activation buffers z_first[name] = (fwd, bwd) instead of the stream's shared
-        Zbuf - the caller orders `es` behind them before it resumes the generator."""
+        Zbuf - the caller orders `es` behind them before it resumes the generator.
+        seq_words: dict {depth k: address of a host word} - the scan launch of depth k hands its launch number to that word (looked
+        up when the launch is enqueued, so a caller may fill the dict while the generator is suspended).  The FORM of each scan
+        launch is self._enc_scan_form at the moment it is enqueued (MGR_SCAN_FORM_*: the schedule's choice for that launch)."""
         sp, dev, B, T = self.spec, self.dev, self.B, self.T
         W = sp.concat_width
         save = train and not self.inference_only
@@ -655,7 +665,7 @@ class Engine:
             self._fmt_train = bool(train)
             dev.stream(es)
             # all recurrences of this depth in ONE call (one persistent multi-CU launch when H is large)
-            self._scan_multi(jobs, "_ws_multi")
+            self._scan_multi(jobs, "_ws_multi", form=self._enc_scan_form, seq_word=(seq_words or {}).get(k, 0))
             self.rng_step = saved_step
             yield ("scanned", k)
             saved_step, self.rng_step = self.rng_step, rng_step
@@ -697,16 +707,17 @@ class Engine:
                 self._project_pair(feat_buf, W, pair, Ls_pair, B, T, W, Hf, XT=self._featT.get(feat_buf.ptr),
                                    xt_ready=self._featT_ready.get(feat_buf.ptr, False))
             dev.record(self.EV_FPROJ)   # (the next step's depth-1 scan is launched after these GEMMs, _enqueue_next_encoders)
-            if self._gate_seq[0] is not None:
+            if self._gate_words[0] is not None:
                 # (Schedule.fused_encoder_scans: the fusion scan's 56 workgroups must land on the CUs the next batch's deepest encoder
-                #  scan - 208 whole CUs, released by the same event - leaves free, not on 56 CUs of their own)
-                dev.call("mgr_stream_wait_resident", int(self._gate_seq[0]), int(self.schedule.resident_wait_us))
+                #  scan - 208 whole CUs, released by the same event - leaves free, not on 56 CUs of their own.  That scan is enqueued
+                #  LATER in this call: it hands its launch number to the word this wait polls)
+                dev.call("mgr_stream_wait_resident_word", int(self._gate_words[0]), int(self.schedule.resident_wait_us))
             for di, dname in enumerate(("fwd", "bwd")):
                 L = self.dirs["fusion/%s" % dname]
                 jobs.append(dict(Z=self.ZF[di], Up=L.Up, Y=self.YF.view(di * Hf, (1,)), ldy=2 * Hf, R=0, ldr=0,
                                  gates=L.gates if save else 0, cs=L.cs if save else 0, B=B, T=T, H=Hf,
                                  reverse=L.reverse))
-            self._scan_multi(jobs, "_ws_multi_f")
+            self._scan_multi(jobs, "_ws_multi_f", form=self._fusion_scan_form)
             feat, ldf = self.YF, 2 * Hf
         # head
         D, Cn = sp.head_width, sp.num_classes
@@ -730,7 +741,11 @@ class Engine:
         self.rng_step = saved_step
 
     _wide_ok = False          # probe: with fused encoder scans no GEMM shares a CU with a scan workgroup - the library's own tile choice
-    _gate_seq = (None, None)  # fused encoder scans: the launch numbers the fusion scan / the BPTT of the step being enqueued wait for
+    _gate_words = (None, None)  # fused encoder scans: the host words through which the launches the fusion scan / the BPTT of the step
+                                # being enqueued wait for hand over their launch numbers
+    _enc_scan_form = _capi.SCAN_FORM_AUTO      # form of the encoder scan launches enqueued NOW (AUTO: the context's tune key 4)
+    _fusion_scan_form = _capi.SCAN_FORM_AUTO   # form of the fusion layer's scan launch
+    _early_words = None      # seq_words dict of the generator in _early_gen
     _early_for = None        # the inputs the generator started last was announced for
     _early_gen = None        # _next_encoders_free generator of the batch after next, its first part already enqueued
     _beside_scans = False    # the fusion layer's GEMMs of the step being enqueued run beside encoder scans of the next batch
@@ -742,24 +757,44 @@ class Engine:
         class _Ctx:
             def __enter__(self_):
                 if on:
+                    v = C.c_int()
+                    eng.dev.call("mgr_tune_get", 12, C.byref(v))
+                    self_.old = v.value      # (a caller's own setting - bench.py --tune 12=... - comes back afterwards)
                     eng.dev.call("mgr_tune", 12, 1)
 
             def __exit__(self_, *exc):
                 if on:
-                    eng.dev.call("mgr_tune", 12, 0)
+                    eng.dev.call("mgr_tune", 12, self_.old)
                 return False
         return _Ctx()
 
-    def _scan_multi(self, jobs, wsname):
+    def _new_seq_word(self):
+        """Address of a zeroed page-locked word: a launch number on its way from the launch (mgr_scan_launch_opts.seq_out) to the
+        wait that was enqueued before it (mgr_stream_wait_resident_word)."""
+        i = self._seq_next
+        self._seq_next = (i + 1) % self._seq_words.size
+        self._seq_words[i] = 0
+        return self._seq_words.ctypes.data + 4 * i
+
+    def _scan_multi(self, jobs, wsname, form=_capi.SCAN_FORM_AUTO, seq_word=0):
         """One multi-scan call on the current stream; `wsname` keeps the encoder and fusion workspaces apart (they may
-        be in flight at the same time when steps are pipelined)."""
+        be in flight at the same time when steps are pipelined).  form: mgr.h MGR_SCAN_FORM_* (AUTO: the context's tune key 4);
+        seq_word: address of the host word that receives the launch number (0: not wanted)."""
         arr = _capi.make_scan_jobs(jobs)
         need = self.lib.mgr_lstm_scan_multi_ws_bytes(len(jobs), arr)
         ws = getattr(self, wsname, None)
         if ws is None or ws.nbytes < need:
             ws = self.mem.bytes(need)
             setattr(self, wsname, ws)
-        _capi.check(self.lib.mgr_lstm_scan_fwd_multi(self.dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes))
+        opts = _capi.make_launch_opts(form, seq_word)
+        _capi.check(self.lib.mgr_lstm_scan_fwd_multi_ex(self.dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes, C.byref(opts)))
+
+    def resident_wait_stats(self):
+        """(residency waits of this engine's context that have ended, those that ran into their bound) - mgr_resident_wait_stats.
+        A wait at its bound costs Schedule.resident_wait_us of its stream and means the schedule's hand-over failed."""
+        out = (C.c_uint * 4)()
+        self.dev.call("mgr_resident_wait_stats", out)
+        return int(out[0]), int(out[1])
 
     # ------------------------------------------------------------------------------------------ public
     def scan_health(self, snapshot=None):
@@ -924,7 +959,14 @@ class Engine:
                                       for s_ in sp.streams} for _ in range(2)])
 
         started = [0]
-        d1_seq = [0, 0]     # launch sequence number of the depth-1 scans of the batch in Z set 0 / 1 (its depth-2 scans: + 1)
+        # launch numbers of the depth-1 / depth-2 scan launches of the batch in Z set 0 / 1, as the launches themselves report them
+        # (mgr_scan_launch_opts.seq_out: round 5 predicted them from the context's counter, which another engine on the same Device or
+        # a launch that does not enter the ledger made wrong - and every wait then ran into its bound)
+        scan_seq = np.zeros((2, 2), np.uint32)
+
+        def wait_resident(seq, us):
+            if int(seq) not in (0, _capi.SEQ_NONE):     # (no persistent launch: nothing to wait for)
+                dev.call("mgr_stream_wait_resident", C.c_uint(int(seq)), int(us))
 
         def start_encoders(i, item):
             """Upload batch i and enqueue its noise / depth-1 projections on stream 0 (two_stage), or nothing yet; returns the
@@ -934,15 +976,17 @@ class Engine:
             first = 0 if two_stage else ES
             self._upload_inputs(inputs, None, train_phase, stream=first)
             self._xin_user[self._xin_slot] = 1 << 60       # (its readers are known by event, not by a loss read-back)
+            scan_seq[i & 1, :] = 0
             gen = self._encoder_phases(train_phase, None, ring[f], ES, self.rng_step + (i - started[0]),
-                                       first_stream=0 if two_stage else None, z_first=z1[i & 1] if two_stage else None)
+                                       first_stream=0 if two_stage else None, z_first=z1[i & 1] if two_stage else None,
+                                       seq_words={k: scan_seq.ctypes.data + 4 * (2 * (i & 1) + k) for k in range(2)})
             if two_stage:
                 dev.stream(0)
                 dev.wait_event(0, self.EV_D1S[i & 1])       # the depth-1 scans that read this Z set two batches ago
                 if i >= 1 and self.schedule.resident_wait_us > 0:
                     # ... and not beside the previous batch's depth-2 projection GEMMs on ES (GEMM beside GEMM: the sum of both), but
                     # beside its depth-2 SCANS, whose launch follows its depth-1 scan launch (bounded wait: placement only)
-                    dev.call("mgr_stream_wait_resident", C.c_uint(d1_seq[(i - 1) & 1] + 1), 5 * self.schedule.resident_wait_us)
+                    wait_resident(scan_seq[(i - 1) & 1, 1], 5 * self.schedule.resident_wait_us)
                 tag = next(gen)                             # noise + depth-1 projections -> stream 0
                 assert tag == ("projected", 0)
                 dev.stream(0)
@@ -957,9 +1001,6 @@ class Engine:
             self._begin_pass(i & 1)                         # zeroes it (stream ES) and reports into it from here on
             if two_stage:
                 dev.wait_event(ES, self.EV_D1P[i & 1])
-                nl, ns = C.c_int(), C.c_int()
-                dev.call("mgr_persist_stats", C.byref(nl), C.byref(ns))
-                d1_seq[i & 1] = nl.value + 1                # the sequence number the depth-1 scan launch of this batch will get
             for tag in gen:
                 if two_stage and tag == ("scanned", 0):
                     dev.stream(ES)
@@ -999,7 +1040,7 @@ class Engine:
                     # Batch i's encoder pass ends and batch i + 1's depth-1 scans start at the same instant on ES: fusion projection
                     # GEMMs released at that instant race the scan's workgroups for the CUs and the scan runs at half speed for its
                     # whole life (13.1 instead of 8.3 ms: profiles/r04_predict_timeline.txt) - they wait until it is resident
-                    dev.call("mgr_stream_wait_resident", C.c_uint(d1_seq[(i + 1) & 1]), self.schedule.resident_wait_us)
+                    wait_resident(scan_seq[(i + 1) & 1, 0], self.schedule.resident_wait_us)
                 dev.wait_event(0, self.EV_OUT[o])               # batch i - 2's decode / download read the P buffer this pass overwrites
                 if output == "loss":
                     self._upload_labels(item[1], item[2], item[3])
@@ -1172,6 +1213,22 @@ class Engine:
                 dev.wait(0, ES)
                 have = None
         self._prefetched = None
+        defer = pipelined and sch.defer_param_grads and sp.fusion is not None and depth >= 2
+        # (not in a call that ran its own encoder pass in line on stream 0: that pass uses the encoder buffers)
+        ahead = defer and sch.encoders_run_ahead and have is not None
+        any_tr_stream_ = any(s_["trainable"] for s_ in sp.streams)
+        free_ok = pipelined and ahead and sch.bptt_beside_deepest_scan and sp.fusion and not any_tr_stream_
+        # What the encoder stream was handed a call early (the first part of the pass of the batch after this one) is settled BEFORE
+        # this step's FEAT buffer is chosen: when the caller did not come back as announced - another batch, a predict /
+        # loss_on_batch in between that discarded the prefetched pass - the early generator is dropped and its claim on the other FEAT
+        # buffer with it; choosing `cur` first put the NEXT batch's deepest scan on top of the buffer this step's deferred dW GEMMs read.
+        early, self._early_gen = self._early_gen, None
+        early_words, self._early_words = self._early_words, None
+        if early is not None and not (free_ok and (not upload or next_inputs is self._early_for)):
+            dev.wait(0, ES)
+            self._feat_idx ^= 1        # (the generator toggled it when it was started; nothing of its pass has touched a FEAT buffer yet)
+            early.close()
+            early = None
         if have is None:
             if upload:
                 self._upload_inputs(inputs, rand, True)
@@ -1182,9 +1239,6 @@ class Engine:
             dev.wait(0, ES)          # this step's encoder pass (enqueued by the previous call) must be complete
         if upload:
             self._upload_labels(labels, input_length, label_length)
-        defer = pipelined and sch.defer_param_grads and sp.fusion is not None and depth >= 2
-        # (not in a call that ran its own encoder pass in line on stream 0: that pass uses the encoder buffers)
-        ahead = defer and sch.encoders_run_ahead and have is not None
         if pipelined:
             # the other FEAT buffer was last read by the previous step's fusion phase (its dW GEMMs, queued on stream 0)
             if ahead:
@@ -1195,64 +1249,70 @@ class Engine:
         # Free-running encoder stream (Schedule.bptt_beside_deepest_scan): the next batch's encoder pass up to its deepest projections
         # is handed to the encoder stream BEFORE this step's fusion work is enqueued - it depends on nothing of this step, and the
         # host needs ~1-2 ms to enqueue the fusion layer and the head, during which that stream would sit idle
-        any_tr_stream_ = any(s_["trainable"] for s_ in sp.streams)
         free_gen = None
-        free_ok = pipelined and ahead and sch.bptt_beside_deepest_scan and sp.fusion and not any_tr_stream_
-        early, self._early_gen = self._early_gen, None
-        if early is not None and not (free_ok and (not upload or next_inputs is self._early_for)):
-            # the caller did not come back as announced: what the encoder stream was handed early is dropped
-            dev.wait(0, ES)
-            self._feat_idx ^= 1
-            early = None
+        free_words = None
         if early is not None:
-            free_gen = early                   # (its first part was enqueued at the end of the previous call)
+            free_gen, free_words = early, early_words   # (its first part was enqueued at the end of the previous call)
         elif free_ok:
-            free_gen = self._next_encoders_free(next_inputs, depth, self.rng_step + 1, self._step_id + 1)
+            free_words = {}
+            free_gen = self._next_encoders_free(next_inputs, depth, self.rng_step + 1, self._step_id + 1, seq_words=free_words)
             next(free_gen)
         # ---- 2., 3. fusion layer, head, CTC, loss read-back point, backward
         # (not with a host-blocking all-reduce: HostComm holds the host inside finish(), the depth-1 scan the BPTT's wait is for would only
         #  be enqueued after it - the wait would always run into its bound; such runs share a GPU and use small per-rank batches anyway)
         fused = bool(sch.fused_encoder_scans and free_gen is not None and early is not None
                      and not getattr(self.comm, "host_blocking", False))
-        self._gate_seq = (None, None)
-        if fused:
-            # persistent launches from here on, in host order: fusion scan (+1), BPTT (+2), the next batch's deepest scan (+3), and - when
-            # the batch after next is announced - its depth-1 scan (+4)
-            nl = C.c_int()
-            dev.call("mgr_persist_stats", C.byref(nl), None)
-            self._gate_seq = (nl.value + 3, nl.value + 4 if (prefetch_after_next and sch.encoders_two_ahead) else None)
-            self._wide_ok = bool(sch.fused_wide_tiles)
-            dev.call("mgr_tune", 4, 3)
-        finish = self._enqueue_trainable_part(cur, rand, pipelined, defer, sch.bptt_beside_deepest_scan, have is None, apply_update)
+        two = bool(pipelined and free_gen is not None and prefetch_after_next and sch.encoders_two_ahead)
+        self._gate_words = (None, None)
+        new_words = None
+        try:
+            if fused:
+                # Persistent launches from here on, in host order: fusion scan, BPTT, the next batch's deepest scan and - when the batch
+                # after next is announced - its depth-1 scan.  The last two take the FUSED form (an argument of their launch), and each
+                # hands its launch number to the word the fusion scan's / the BPTT's residency wait polls: the waits are enqueued first.
+                self._enc_scan_form = _capi.SCAN_FORM_FUSED
+                wx = self._new_seq_word()
+                free_words[depth - 1] = wx
+                wy = None
+                if two and depth > 1:
+                    wy = self._new_seq_word()
+                    new_words = {0: wy}
+                self._gate_words = (wx, wy)
+                self._wide_ok = bool(sch.fused_wide_tiles)
+            finish = self._enqueue_trainable_part(cur, rand, pipelined, defer, sch.bptt_beside_deepest_scan, have is None, apply_update)
 
-        # ---- 4. parameter gradients + optimizer, and (pipelined) the next step's encoder pass
-        if not pipelined:
-            finish()
-        elif free_gen is not None:
-            two = prefetch_after_next and sch.encoders_two_ahead
-            if two and sch.depth1_proj_ahead and self.Z1buf and depth > 1:
-                # the batch AFTER the next one: its depth-1 projections in front of the next batch's deepest scan, the rest of its
-                # first part at the end of this call (rng_step / _step_id were advanced above)
-                def pre():
-                    self._early_gen = self._next_encoders_free(after_next_inputs, depth, self.rng_step + 1, self._step_id + 1,
-                                                               split_first=True)
+            # ---- 4. parameter gradients + optimizer, and (pipelined) the next step's encoder pass
+            if not pipelined:
+                finish()
+            elif free_gen is not None:
+                if new_words is None:
+                    new_words = {}
+                if two and sch.depth1_proj_ahead and self.Z1buf and depth > 1:
+                    # the batch AFTER the next one: its depth-1 projections in front of the next batch's deepest scan, the rest of its
+                    # first part at the end of this call (rng_step / _step_id were advanced above)
+                    def pre():
+                        self._early_gen = self._next_encoders_free(after_next_inputs, depth, self.rng_step + 1, self._step_id + 1,
+                                                                   split_first=True, seq_words=new_words)
+                        self._early_words = new_words
+                        next(self._early_gen)
+                    free_gen.send((finish, pre))
                     next(self._early_gen)
-                free_gen.send((finish, pre))
-                next(self._early_gen)
+                else:
+                    free_gen.send(finish)
+                    if two:
+                        # the first part of the pass of the batch AFTER the next one (rng_step / _step_id were advanced above)
+                        self._early_gen = self._next_encoders_free(after_next_inputs, depth, self.rng_step + 1, self._step_id + 1,
+                                                                   seq_words=new_words)
+                        self._early_words = new_words
+                        next(self._early_gen)
             else:
-                free_gen.send(finish)
-                if two:
-                    # the first part of the pass of the batch AFTER the next one (rng_step / _step_id were advanced above)
-                    self._early_gen = self._next_encoders_free(after_next_inputs, depth, self.rng_step + 1, self._step_id + 1)
-                    next(self._early_gen)
-        else:
-            self._enqueue_next_encoders(next_inputs, finish, defer, ahead, depth,
-                                        free_running=bool(defer and sch.bptt_beside_deepest_scan and sp.fusion and not any_tr_stream_))
-        self._beside_scans = False
-        if fused:
-            dev.call("mgr_tune", 4, 0)
-        self._wide_ok = False
-        self._gate_seq = (None, None)
+                self._enqueue_next_encoders(next_inputs, finish, defer, ahead, depth,
+                                            free_running=bool(defer and sch.bptt_beside_deepest_scan and sp.fusion and not any_tr_stream_))
+        finally:
+            self._beside_scans = False
+            self._enc_scan_form = _capi.SCAN_FORM_AUTO
+            self._wide_ok = False
+            self._gate_words = (None, None)
         dev.stream(0)
 
     def _enqueue_trainable_part(self, cur, rand, beside_scans, defer, late_ok, own_inputs, apply_update):
@@ -1317,7 +1377,7 @@ class Engine:
             dev.stream(0)
             dev.record(self.EV_IN[self._xin_slot])   # trainable first layers read the inputs again in their dW GEMMs
 
-        gate_b = self._gate_seq[1]
+        gate_b = self._gate_words[1]
 
         def finish(gate=None):
             """This step's (held-back) BPTT, its dW / dU / db GEMMs and the optimizer on stream 0.  gate: enqueues the device-side
@@ -1327,7 +1387,8 @@ class Engine:
             must not be placed before the scan's workgroups: recurrence beside recurrence starts at once, GEMMs wait."""
             dev.stream(0)
             if gate_b is not None and late_bptt is not None:
-                dev.call("mgr_stream_wait_resident", int(gate_b), int(self.schedule.resident_wait_us))   # (as for the fusion scan)
+                # (as for the fusion scan: the depth-1 scan of the batch after next, enqueued at the end of this call, fills the word)
+                dev.call("mgr_stream_wait_resident_word", int(gate_b), int(self.schedule.resident_wait_us))
             d = late_bptt() if late_bptt is not None else deferred
             if gate is not None:
                 gate()
@@ -1337,7 +1398,7 @@ class Engine:
                 self.apply_gradients()
         return finish
 
-    def _next_encoders_free(self, next_inputs, depth, rng_step, consumer_step, split_first=False):
+    def _next_encoders_free(self, next_inputs, depth, rng_step, consumer_step, split_first=False, seq_words=None):
         """Schedule.bptt_beside_deepest_scan, as a generator.  Part 1 (before this step's fusion work is enqueued): the next
         batch's encoder pass on stream ES up to and including its deepest projection GEMMs.  Part 2 (after the loss read-back point,
         resumed with send(finish) or send((finish, pre))): stream 0 waits for those GEMMs, then - once the deepest scan launched behind
@@ -1355,7 +1416,7 @@ class Engine:
             self._upload_inputs(next_inputs, None, True, stream=ES)
             self._xin_user[self._xin_slot] = consumer_step
         split_first = bool(split_first and self.Z1buf)
-        phases = self._encoder_phases(True, None, nxt, ES, rng_step, z_first=self.Z1buf if split_first else None)
+        phases = self._encoder_phases(True, None, nxt, ES, rng_step, z_first=self.Z1buf if split_first else None, seq_words=seq_words)
         for tag, k in phases:
             if tag == "projected" and k == 0 and split_first and depth > 1:
                 dev.stream(0)
@@ -1458,17 +1519,16 @@ class Engine:
             self._ws_bwd_multi = self.mem.bytes(need)
         beside_scans = self._beside_scans     # (the deferred GEMMs run beside the next batch's encoder scans as well)
         wide_ok = self._wide_ok
-        yielding = beside_scans and self.schedule.bptt_yields_beside_scans
-        if yielding:
-            # the form of the narrow-layer BPTT that yields to the encoder scans beside it - or, beside FUSED encoder scans (CUs of its
-            # own), the direct gather with one barrier per step (mgr.h, tune key 16)
-            dev.call("mgr_tune", 16, 2 if (self._wide_ok or self._gate_seq[1] is not None) and self.schedule.bptt_direct_when_alone else 1)
-        try:
-            _capi.check(self.lib.mgr_lstm_scan_bwd_multi(dev.ctx, len(jobs), arr, self._ws_bwd_multi.ptr,
-                                                         self._ws_bwd_multi.nbytes))
-        finally:
-            if yielding:
-                dev.call("mgr_tune", 16, 0)
+        # The form of the narrow-layer BPTT is an argument of the launch (mgr.h MGR_BPTT_FORM_*; AUTO = the context's tune key 16):
+        # beside the next batch's encoder scans the form that yields to them - or, beside FUSED encoder scans (CUs of its own) and if the
+        # schedule asks for it, the direct gather with one barrier per step; a launch that has the chip to itself takes the context's.
+        form = _capi.BPTT_FORM_AUTO
+        if beside_scans and self.schedule.bptt_yields_beside_scans:
+            direct = (self._wide_ok or self._gate_words[1] is not None) and self.schedule.bptt_direct_when_alone
+            form = _capi.BPTT_FORM_DIRECT if direct else _capi.BPTT_FORM_YIELDING
+        opts = _capi.make_launch_opts(form, 0)
+        _capi.check(self.lib.mgr_lstm_scan_bwd_multi_ex(dev.ctx, len(jobs), arr, self._ws_bwd_multi.ptr, self._ws_bwd_multi.nbytes,
+                                                        C.byref(opts)))
 
         def param_grads():
             for di, dname in enumerate(("fwd", "bwd")):

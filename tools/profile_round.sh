@@ -2,7 +2,8 @@
 # The per-round evidence set, all under gpurun_out/ (copy what is to be judged into profiles/ with tools/summarize_profile.py):
 #   <tag>_bench.json                     the default bench.py line (config F = BASELINE configs[2])
 #   <tag>_kernel_stats.csv, _kernel_trace.csv   rocprofv3 --kernel-trace --stats of the same command
-#   <tag>_pmc_*.csv                      separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ counters), bench.py --steps 2 --warmup 1
+#   <tag>_pmc_*.csv                      separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ counters), bench.py --steps 8 --warmup 3 (the fused schedule
+#                                        engages once a step was announced two calls ahead: a 2-step run never shows the shipped kernels)
 #   <tag>_cfg_<C>_bench.json, <tag>_cfg_<C>_kernel_stats.csv   the other BASELINE configurations (S, S_ref, A_ref, E): untruncated bench
 #                                        line + rocprof kernel stats each
 #   <tag>_decode.json, <tag>_decode_kernel_stats.csv          BASELINE configs[4]: tools/decode_bench.py + its kernel stats (k_beam, k_frame_argmax)
@@ -21,7 +22,7 @@ cp $R/gpurun_out/${TAG}_prof/*/*_kernel_trace.csv $R/gpurun_out/${TAG}_kernel_tr
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT"; do
   name=$(echo $pass | cut -d' ' -f1)
   rm -rf $R/gpurun_out/${TAG}_pmc_$name
-  timeout 400 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $R/gpurun_out/${TAG}_pmc_$name -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-parity --no-f32-leg > $R/gpurun_out/${TAG}_pmc_$name.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $R/gpurun_out/${TAG}_pmc_$name -- python3 $R/bench.py --steps 8 --warmup 3 --no-cpu --no-parity --no-f32-leg > $R/gpurun_out/${TAG}_pmc_$name.log 2>&1
   cp $R/gpurun_out/${TAG}_pmc_$name/*/*_counter_collection.csv $R/gpurun_out/${TAG}_pmc_$name.csv
 done
 if [ "$2" != "quick" ]; then
