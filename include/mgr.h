@@ -195,7 +195,11 @@ int mgr_lstm_scan_fwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, v
 enum { MGR_SCAN_FORM_AUTO = 0, MGR_SCAN_FORM_PLAIN = 1, MGR_SCAN_FORM_PAIR = 2, MGR_SCAN_FORM_FUSED = 3,
        MGR_SCAN_FORM_FUSED_ANY = 4 };   /* FUSED: launches that do not fit one workgroup per CU as they are; FUSED_ANY: every launch the
                                          * fused kernel can run (a narrow layer then holds ceil(G / 2) whole CUs per cluster) */
-enum { MGR_BPTT_FORM_AUTO = 0, MGR_BPTT_FORM_TRIMMED = 1, MGR_BPTT_FORM_YIELDING = 2, MGR_BPTT_FORM_DIRECT = 3 };   /* tune key 16 = 0 / 1 / 2 */
+enum { MGR_BPTT_FORM_AUTO = 0, MGR_BPTT_FORM_TRIMMED = 1, MGR_BPTT_FORM_YIELDING = 2, MGR_BPTT_FORM_DIRECT = 3,   /* tune key 16 = 0 / 1 / 2 */
+       /* round 6, narrow layers (16 < H <= 128) with an exchange: 8-wave workgroups that run TWO unit groups of their cluster, a CU each
+        * (H = 100: 32 workgroups instead of 56), with the trimmed step / the direct gather inside; the same bits as every other form.  A
+        * launch that does not qualify takes the trimmed / direct form. */
+       MGR_BPTT_FORM_FUSED = 4, MGR_BPTT_FORM_FUSED_DIRECT = 5 };
 #define MGR_SEQ_NONE 0xFFFFFFFFu
 typedef struct mgr_scan_launch_opts {
   unsigned struct_size;

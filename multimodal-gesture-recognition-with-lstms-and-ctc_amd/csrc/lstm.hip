@@ -462,9 +462,11 @@ int mgr_lstm_scan_bwd_multi_ex(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jo
   int form;
   unsigned* seq_out;
   read_opts(opts, &form, &seq_out);
-  MGR_REQUIRE(form >= MGR_BPTT_FORM_AUTO && form <= MGR_BPTT_FORM_DIRECT, "unknown BPTT form %d", form);
+  MGR_REQUIRE(form >= MGR_BPTT_FORM_AUTO && form <= MGR_BPTT_FORM_FUSED_DIRECT, "unknown BPTT form %d", form);
   if (seq_out) *seq_out = MGR_SEQ_NONE;
-  const int key16 = form == MGR_BPTT_FORM_AUTO ? c->tune[16] : form - 1;   // 0 trimmed, 1 yielding, 2 direct gather
+  const bool want_fused = form == MGR_BPTT_FORM_FUSED || form == MGR_BPTT_FORM_FUSED_DIRECT;
+  // 0 trimmed, 1 yielding, 2 direct gather (the fused forms: the trimmed step / the direct gather)
+  const int key16 = form == MGR_BPTT_FORM_AUTO ? c->tune[16] : form == MGR_BPTT_FORM_FUSED ? 0 : form == MGR_BPTT_FORM_FUSED_DIRECT ? 2 : form - 1;
   MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_scan_bwd_multi_ws_bytes(njobs, jobs), "workspace too small");
   for (int i = 0; i < njobs; ++i) {
     const mgr_scan_bwd_job& j = jobs[i];
@@ -509,7 +511,22 @@ int mgr_lstm_scan_bwd_multi_ex(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jo
     xcd = false;
     grid = layout_classes(njobs, use_cluster, same_h, g_of, nbg, cb, cn, c0, false, cr);
   }
+  // Fused form (lstm_cluster_bwd.hip, k_scan_cluster_bwd16_f): asked for by the caller, taken when every job of the launch qualifies -
+  // the same clusters with ceil(G / 2) eight-wave members, a CU each
+  bool fused = want_fused && xcd;
+  for (int i = 0; i < njobs && fused; ++i) fused = use_cluster[i] && jobs[i].H > 16 && jobs[i].H <= 128 && c->tune[14] == 0;
+  if (fused) {
+    auto gr_of = [&](int a) { return (g_of(a) + 1) / 2; };
+    const int gridf = layout_classes(njobs, use_cluster, same_h, gr_of, nbg, cb, cn, c0, true, cr);
+    if (gridf <= c->cu_count && (size_t)gridf * sizeof(unsigned) <= kScanHdrBytes - 256)
+      grid = gridf;
+    else {
+      fused = false;
+      grid = layout_classes(njobs, use_cluster, same_h, g_of, nbg, cb, cn, c0, true, cr);
+    }
+  }
   L.xcd_local = xcd;
+  L.fused = fused ? 1 : 0;
   for (int i = 0; i < njobs; ++i) {
     if (!use_cluster[i]) continue;
     const mgr_scan_bwd_job& j = jobs[i];
@@ -527,13 +544,13 @@ int mgr_lstm_scan_bwd_multi_ex(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jo
     L.cm.sticky = mgr_status_block(c);
     L.cm.resident = c->sticky_status + 1;
     L.cm.total_wgs = grid;
-    r = mgr_persist_admit(c, grid, waves, per_cu, 0, &L.cm.seq);
+    r = mgr_persist_admit(c, grid, waves, per_cu, L.fused, &L.cm.seq);
     if (r) return r;
     if (seq_out) *seq_out = L.cm.seq;
     MGR_HIP(hipMemsetAsync(base, 0, (size_t)(w - base), mgr_stream(c)));
     r = mgr_cluster_bwd_launch(c, L, grid, key16);
     if (r) return r;
-    r = mgr_persist_commit(c, grid, waves, per_cu, 0);
+    r = mgr_persist_commit(c, grid, waves, per_cu, L.fused);
     if (r) return r;
   }
   // the single-CU kernel takes every job that is left in ONE launch when they share a shape (the two directions of a layer)

@@ -91,9 +91,12 @@ struct ClusterBwdLaunch {
   ClusterCommon cm;
   int njobs;
   int xcd_local;   // clusters laid out on workgroup ids congruent mod 8; plain-store exchange where a cluster finds itself on one XCD
+  int fused;       // narrow split-f16 layers: 8-wave workgroups that run TWO unit groups of their cluster, a CU each; the job table's
+                   // cls_* fields then count ceil(G_ / 2) members per cluster (k_scan_cluster_bwd16_f / _fd)
   ClusterBwdJob job[MGR_MAX_SCAN_JOBS];
 };
 bool mgr_cluster_bwd_supported(int H);
+bool mgr_cluster_bwd_fusable(const mgr_ctx* c, const ClusterBwdLaunch& L);   // L.xcd_local, the jobs' H / G_ filled in
 size_t mgr_cluster_bwd_img_floats(int H);
 void mgr_cluster_bwd_geometry(const mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs, int* waves, int* per_cu);
 int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs, int form16);   // form16: 0 trimmed, 1 yielding, 2 direct (mgr.h, tune key 16)

@@ -471,13 +471,18 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
 // same order - no partial sums through LDS, ONE barrier per step.  1.58 us per step alone at H = 100 (1.77 without), and 28 KiB per
 // workgroup and step through the texture path instead of 6: it lost 1 - 2 ms per step while encoder-scan workgroups shared its CUs,
 // and is the form the engine asks for (tune key 16 = 2) once the fused encoder scans leave the fusion layer CUs of its own.
-template <int H, bool DIRECT = false>
+// FUSED (round 6, k_scan_cluster_bwd16_f): the workgroup has 512 threads and runs TWO unit groups of one cluster - threads 0..255 the
+// member 2 j, threads 256..511 the member 2 j + 1 - each through this function with its own half of the LDS; they share the CU and
+// the barriers (the same count in both halves: two in the prologue, per step one in front of the reduction unless DIRECT, one behind the
+// image), nothing else: the tiles the two halves owe each other travel through the exchange like every other tile.  H = 100: 4
+// workgroups per cluster, 32 per launch, a CU each - instead of 56 four-wave workgroups on the 48 CUs the fused encoder scans leave.
+template <int H, bool DIRECT = false, bool FUSED = false>
 __device__ __forceinline__ void cluster_bwd_run16(const ClusterBwdJob& jb, int bg, int ug, float* smem, unsigned* status, bool fast) {
   constexpr int N = 4 * H;
   constexpr int GT = (H + 15) / 16;
   constexpr int TPW = (GT + BW_WAVES - 1) / BW_WAVES;
   static_assert(GT >= 2 && GT <= 8, "narrow layers with an exchange");
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = FUSED ? (int)(threadIdx.x & 255u) : (int)threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, uq = lane >> 4;
   const int B = jb.B, T = jb.T, reverse = jb.reverse;
@@ -887,6 +892,52 @@ __global__ __launch_bounds__(BW_WAVES * 64) void k_scan_cluster_bwd16_sd(Cluster
   extern __shared__ __attribute__((aligned(16))) float smem[];
   scan_cluster_bwd_body<false, true, true, 2>(L, smem);
 }
+// the fused form of the narrow layers (cluster_bwd_run16<H, DIRECT, true>): one 8-wave workgroup per CU = two unit groups (2 j, 2 j + 1) of
+// one cluster; the launch lays out ceil(G / 2) members per cluster in XCD-local octets; a unit group beyond G (odd G) only keeps the
+// barrier count of the step
+template <bool DIRECT>
+__device__ __forceinline__ void scan_cluster_bwd_fused_body(const ClusterBwdLaunch& L, float* smem) {
+  mgr_cluster_enter(L.cm);
+  const int tg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  for (int k_ = 0; k_ < L.njobs; ++k_) {
+    const ClusterBwdJob& jb = L.job[k_];
+    const int G = jb.G_, Gr = (G + 1) / 2;
+    const int w = (int)blockIdx.x - jb.cls_begin;
+    if (w < 0 || w >= (jb.cls_nclusters + 7) / 8 * 8 * Gr) continue;
+    int cl, ugr;
+    const bool fast = mgr_cluster_octet(L.cm, jb.cls_begin, Gr, jb.cls_rot, w, cl, ugr);
+    if (cl >= jb.cls_nclusters) continue;
+    const int bg = cl - jb.cls_cluster0;
+    if (bg < 0 || bg >= jb.nbg) continue;
+    const int ug = 2 * ugr + tg;
+    float* sm = smem + tg * BW_LDS_FLOATS_B;
+    if (ug >= G) {   // (odd G: the last workgroup's second half keeps the barrier count of cluster_bwd_run16)
+      __syncthreads();
+      __syncthreads();
+      for (int k = 0; k < jb.T; ++k) {
+        if (!DIRECT && k > 0) __syncthreads();
+        if (k < jb.T - 1) __syncthreads();
+      }
+      return mgr_cluster_exit(L.cm);
+    }
+#define BWF_CASE(HH)                                                              \
+  if (jb.H == HH) {                                                               \
+    if constexpr ((HH) > 16) cluster_bwd_run16<HH, DIRECT, true>(jb, bg, ug, sm, L.cm.status, fast); \
+    return mgr_cluster_exit(L.cm);                                                \
+  }
+    BW_SMALL(BWF_CASE)
+#undef BWF_CASE
+    return;
+  }
+}
+__global__ __launch_bounds__(2 * BW_WAVES * 64, 1) void k_scan_cluster_bwd16_f(ClusterBwdLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  scan_cluster_bwd_fused_body<false>(L, smem);
+}
+__global__ __launch_bounds__(2 * BW_WAVES * 64, 1) void k_scan_cluster_bwd16_fd(ClusterBwdLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  scan_cluster_bwd_fused_body<true>(L, smem);
+}
 __global__ __launch_bounds__(BW_WAVES * 64, 2) void k_scan_cluster_bwd16(ClusterBwdLaunch L) {   // (two workgroups per CU: <= 256 VGPRs)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   scan_cluster_bwd_body<false, false, true>(L, smem);
@@ -926,7 +977,19 @@ static bool bwd_split(const mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs
   return exchange && (maxH >= 200 || c->tune[8] == 2) && total_wgs <= c->cu_count && c->tune[8] != 1;
 }
 
+// the fused form runs narrow layers (16 < H <= 128) on the split-f16 path, laid out in XCD-local octets
+bool mgr_cluster_bwd_fusable(const mgr_ctx* c, const ClusterBwdLaunch& L) {
+  bool ok = c->tune[14] == 0 && L.xcd_local && L.njobs > 0;
+  for (int i = 0; i < L.njobs; ++i) ok = ok && L.job[i].H > 16 && L.job[i].H <= 128 && L.job[i].G_ >= 2;
+  return ok;
+}
+
 void mgr_cluster_bwd_geometry(const mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs, int* waves, int* per_cu) {
+  if (L.fused) {
+    *waves = 2 * BW_WAVES;
+    *per_cu = 1;
+    return;
+  }
   const bool split = bwd_split(c, L, total_wgs);
   *waves = split ? 2 * BW_WAVES : BW_WAVES;
   *per_cu = split ? 1 : 2;
@@ -944,10 +1007,21 @@ int mgr_cluster_bwd_launch(mgr_ctx* c, const ClusterBwdLaunch& L, int total_wgs,
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd16_s), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd16_sl), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd16_sd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd16_f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_bwd16_fd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     c->attr_done |= 2u;
   }
   const bool f16 = c->tune[14] == 0;   // split-f16 operands (tune key 14 = 1: f32 MFMA)
-  if (bwd_split(c, L, total_wgs)) {
+  if (L.fused) {
+    MGR_REQUIRE(mgr_cluster_bwd_fusable(c, L) && total_wgs <= c->cu_count, "the fused BPTT form needs narrow split-f16 layers in octets, one workgroup per CU");
+    // (>= 84 KiB requested: the workgroup sits alone on its CU whatever its registers would allow)
+    size_t lds = 2 * (size_t)BW_LDS_FLOATS_B * sizeof(float);
+    lds = lds < 84 * 1024 ? 84 * 1024 : lds;
+    if (form16 == 2)
+      hipLaunchKernelGGL(k_scan_cluster_bwd16_fd, dim3(total_wgs), dim3(2 * BW_WAVES * 64), lds, mgr_stream(c), L);
+    else
+      hipLaunchKernelGGL(k_scan_cluster_bwd16_f, dim3(total_wgs), dim3(2 * BW_WAVES * 64), lds, mgr_stream(c), L);
+  } else if (bwd_split(c, L, total_wgs)) {
     size_t lds = 84 * 1024;
     if (f16)
       hipLaunchKernelGGL(k_scan_cluster_bwd16_split, dim3(total_wgs), dim3(2 * BW_WAVES * 64), lds, mgr_stream(c), L);

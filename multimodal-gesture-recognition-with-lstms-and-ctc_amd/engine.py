@@ -102,6 +102,11 @@ class Schedule:
                         launch and the launch number each wait is for is HANDED OVER by the launch itself (a page-locked word the
                         wait kernel polls, mgr_stream_wait_resident_word) - no context-wide tune key, no predicted numbers; a wait
                         that runs into its bound is counted (Engine.resident_wait_stats)
+    fusion_scan_fused   (round 6; with fused_encoder_scans) the fusion layer's own forward scan takes the fused form as well
+                        (MGR_SCAN_FORM_FUSED_ANY: H = 100 -> 4 eight-wave workgroups per cluster, 32 workgroups that hold a CU each,
+                        instead of 56 four-wave workgroups on the 48 CUs the encoder scans leave, eight of which carry two)
+    bptt_fused          (round 6; with fused_encoder_scans) the fusion layer's BPTT takes the fused form too (MGR_BPTT_FORM_FUSED /
+                        _FUSED_DIRECT with bptt_direct_when_alone: 32 eight-wave workgroups, a CU each, instead of 56 four-wave ones)
     split_rows          (round 5) the transposed copies are written in the split row format (f16 hi / lo pairs) and the wide products
                         run as loader / matrix pipelines on pre-split operands (gemm_split.hip); False: f32 rows, converted by
                         every product that reads them (round 4's kernels)
@@ -114,7 +119,10 @@ class Schedule:
     def __init__(self, pipeline=True, defer_param_grads=True, encoders_run_ahead=True, resident_wait_us=2000,
                  transposed_inputs=True, bptt_beside_deepest_scan=True, split_rows=True, encoders_two_ahead=True,
                  deepest_scan_after_fusion_proj=True, depth1_proj_ahead=True, bptt_yields_beside_scans=True,
-                 fused_encoder_scans=True, fused_wide_tiles=True, bptt_direct_when_alone=False):
+                 fused_encoder_scans=True, fused_wide_tiles=True, bptt_direct_when_alone=False, fusion_scan_fused=False,
+                 bptt_fused=False):
+        self.bptt_fused = bool(bptt_fused)
+        self.fusion_scan_fused = bool(fusion_scan_fused)
         self.bptt_direct_when_alone = bool(bptt_direct_when_alone)
         self.fused_wide_tiles = bool(fused_wide_tiles)
         self.fused_encoder_scans = bool(fused_encoder_scans)
@@ -1279,6 +1287,8 @@ class Engine:
                     new_words = {0: wy}
                 self._gate_words = (wx, wy)
                 self._wide_ok = bool(sch.fused_wide_tiles)
+                if sch.fusion_scan_fused:
+                    self._fusion_scan_form = _capi.SCAN_FORM_FUSED_ANY
             finish = self._enqueue_trainable_part(cur, rand, pipelined, defer, sch.bptt_beside_deepest_scan, have is None, apply_update)
 
             # ---- 4. parameter gradients + optimizer, and (pipelined) the next step's encoder pass
@@ -1311,6 +1321,7 @@ class Engine:
         finally:
             self._beside_scans = False
             self._enc_scan_form = _capi.SCAN_FORM_AUTO
+            self._fusion_scan_form = _capi.SCAN_FORM_AUTO
             self._wide_ok = False
             self._gate_words = (None, None)
         dev.stream(0)
@@ -1526,6 +1537,8 @@ class Engine:
         if beside_scans and self.schedule.bptt_yields_beside_scans:
             direct = (self._wide_ok or self._gate_words[1] is not None) and self.schedule.bptt_direct_when_alone
             form = _capi.BPTT_FORM_DIRECT if direct else _capi.BPTT_FORM_YIELDING
+            if self._gate_words[0] is not None and self.schedule.bptt_fused:     # (a step of the fused schedule)
+                form = _capi.BPTT_FORM_FUSED_DIRECT if direct else _capi.BPTT_FORM_FUSED
         opts = _capi.make_launch_opts(form, 0)
         _capi.check(self.lib.mgr_lstm_scan_bwd_multi_ex(dev.ctx, len(jobs), arr, self._ws_bwd_multi.ptr, self._ws_bwd_multi.nbytes,
                                                         C.byref(opts)))

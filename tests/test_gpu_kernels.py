@@ -449,6 +449,22 @@ def test_bwd_multi_matches_oracle(device, B, T, H, path, f32_mfma):
                 _capi.check(dev.lib.mgr_lstm_scan_bwd_multi(dev.ctx, 2, arr, ws.ptr, ws.nbytes))
                 for (dz0, zm0), o, j in zip(lean, outs, jobs):
                     assert np.array_equal(o[2].download(), dz0) and np.array_equal(j["dzmax"].download(), zm0), form
+            dev.call("mgr_tune", 16, 0)
+            # round 6: the form as an ARGUMENT of the launch (mgr_scan_launch_opts) - every named form, and the FUSED forms (8-wave
+            # workgroups that run two unit groups of their cluster, a CU each; an odd group count leaves a half that only keeps the
+            # barrier count): the same bits again
+            import ctypes
+            n0 = ctypes.c_int()
+            for form in (_capi.BPTT_FORM_TRIMMED, _capi.BPTT_FORM_YIELDING, _capi.BPTT_FORM_DIRECT, _capi.BPTT_FORM_FUSED, _capi.BPTT_FORM_FUSED_DIRECT):
+                for o in outs:
+                    o[2].zero()
+                seq = ctypes.c_uint(0)
+                opts = _capi.make_launch_opts(form, ctypes.addressof(seq))
+                _capi.check(dev.lib.mgr_lstm_scan_bwd_multi_ex(dev.ctx, 2, arr, ws.ptr, ws.nbytes, ctypes.byref(opts)))
+                dev.call("mgr_persist_stats", ctypes.byref(n0), None)
+                assert seq.value == n0.value          # (the launch number the call reports is the context's newest)
+                for (dz0, zm0), o, j in zip(lean, outs, jobs):
+                    assert np.array_equal(o[2].download(), dz0) and np.array_equal(j["dzmax"].download(), zm0), form
     finally:
         dev.call("mgr_tune", 16, 0)
         dev.call("mgr_tune", 14, 0)

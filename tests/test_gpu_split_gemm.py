@@ -222,3 +222,61 @@ def test_fused_form_of_the_encoder_scans_is_bit_identical(device, B, T):
     assert np.isfinite(y0).all() and np.abs(y0).max() > 0.1
     assert np.array_equal(y0, y1) and np.array_equal(yt0.view(np.uint32), yt1.view(np.uint32))
     assert all(np.array_equal(a, b) for a, b in zip(o0, o1))
+
+
+@pytest.mark.parametrize("H,B,T", [(100, 64, 40), (128, 20, 9), (64, 33, 17), (100, 16, 1)])
+def test_fused_form_of_a_narrow_layer_by_launch_option(device, H, B, T):
+    """Round 6: MGR_SCAN_FORM_FUSED_ANY as an argument of the launch (mgr_scan_launch_opts) gives a NARROW layer the fused form too - the
+    fusion layer of config F: H = 100, 7 unit groups -> 4 eight-wave workgroups per cluster (the last one's second half only keeps the
+    barriers), 32 workgroups that hold a CU each instead of 56 four-wave ones.  Y, gates and c bit for bit those of the plain form; the
+    launch reports its number."""
+    import ctypes
+    from mgr_amd import _capi
+    dev = device
+    rng = np.random.default_rng(H + B + T)
+    keep, jobs_of = [], []
+    Zs, Ups = [], []
+    for d in range(2):
+        Z = dev.array((rng.standard_normal((B, T, 4 * H)) * 0.5).astype(f32))
+        U = dev.array((rng.standard_normal((H, 4 * H)) / np.sqrt(H)).astype(f32))
+        Up = dev.empty((H, 4 * H))
+        dev.call("mgr_lstm_pack", U, Up, H, H, 0)
+        Zs.append(Z)
+        Ups.append(Up)
+        keep += [Z, U, Up]
+
+    def run(form):
+        Y = dev.zeros((B, T, 2 * H))
+        outs, jobs = [], []
+        for d in range(2):
+            G, Cs = dev.zeros((B, T, H, 4)), dev.zeros((B, T, H))
+            outs += [G, Cs]
+            jobs.append(dict(Z=Zs[d], Up=Ups[d], Y=Y.view(d * H, (1,)), ldy=2 * H, gates=G, cs=Cs, B=B, T=T, H=H, reverse=d))
+        arr = _capi.make_scan_jobs(jobs)
+        ws = dev.bytes(dev.lib.mgr_lstm_scan_multi_ws_bytes(len(jobs), arr))
+        seq = ctypes.c_uint(0)
+        opts = _capi.make_launch_opts(form, ctypes.addressof(seq))
+        dev.call("mgr_tune", 1, 1)
+        try:
+            _capi.check(dev.lib.mgr_lstm_scan_fwd_multi_ex(dev.ctx, len(jobs), arr, ws.ptr, ws.nbytes, ctypes.byref(opts)))
+        finally:
+            dev.call("mgr_tune", 1, 0)
+        n = ctypes.c_int()
+        dev.call("mgr_persist_stats", ctypes.byref(n), None)
+        # (the launch number the call reports is the context's newest - or none: a layer the planner keeps on ONE CU per batch group
+        #  has no exchange and enters no launch into the residency ledger)
+        assert seq.value in (n.value, _capi.SEQ_NONE)
+        res = (Y.download(), [o.download() for o in outs])
+        for a in [Y, ws] + outs:
+            a.free()
+        return res
+
+    y0, o0 = run(_capi.SCAN_FORM_PLAIN)
+    y1, o1 = run(_capi.SCAN_FORM_FUSED_ANY)
+    y2, o2 = run(_capi.SCAN_FORM_FUSED)          # (fits one workgroup per CU as it is: FUSED leaves it plain)
+    assert np.isfinite(y0).all() and np.abs(y0).max() > 0.05
+    for y, o in ((y1, o1), (y2, o2)):
+        assert np.array_equal(y0, y)
+        assert all(np.array_equal(a, b) for a, b in zip(o0, o))
+    for a in keep:
+        a.free()
