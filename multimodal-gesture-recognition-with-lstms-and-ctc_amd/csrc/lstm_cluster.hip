@@ -644,9 +644,22 @@ extern "C" int mgr_debug_stamps(unsigned long long* out) {
 // FUSED (round 5, k_scan_cluster_k16f): the workgroup has 512 threads and runs TWO unit groups of one cluster - threads 0..255 the
 // member 2 j, threads 256..511 the member 2 j + 1 - each through this function with its own half of the LDS; they share the CU and
 // the barriers (the same count in both: one in the prologue, one per step), nothing else.
-template <int NBW, bool FUSED = false>   // K-blocks (of 32 units) per wave: H <= 128 * NBW
-__device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const ClusterCommon& cm, int bg, int ug, float* smem, bool fast) {
+// SHARE_TG >= 0 (round 6, k_scan_cluster_k16fs; FUSED only): the two halves of the workgroup belong to the SAME cluster, so wave w of
+// half 0 and wave w of half 1 need the same K-blocks of the same h image - and used to fetch and verify them twice, 64 KiB per CU and
+// step through the L2.  Now half 0 fetches and verifies the first ceil(NBW / 2) K-blocks of the wave's range, half 1 the rest; both
+// leave what they verified in a shared LDS image (xs: [wave][K-block][hi | lo][64 lanes] 16 bytes), ONE more workgroup barrier, and
+// each reads the other's blocks from there: half the L2 gather traffic and half the verification chain per wave.  Same operands, same
+// MFMA order: bit-identical.  The image is single-buffered: a wave writes step s + 1's blocks behind the step-s barrier, which its
+// partner reaches only after its MFMAs consumed step s's.  A unit group beyond G (odd G) runs as a member WITHOUT valid cells - it
+// still owes its partner half of the image.
+template <int NBW, bool FUSED = false, int SHARE_TG = -1>   // K-blocks (of 32 units) per wave: H <= 128 * NBW
+__device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const ClusterCommon& cm, int bg, int ug, float* smem, bool fast,
+                                                float* xs = nullptr) {
   static_assert(NBW >= 1 && NBW <= 4, "1..4 K-blocks per wave (H <= 512)");
+  static_assert(SHARE_TG < 0 || FUSED, "the shared gather is a property of the fused form");
+  constexpr bool SHARE = SHARE_TG >= 0;
+  constexpr int NA = (NBW + 1) / 2;                       // K-blocks half 0 fetches; half 1: the other NBW - NA
+  constexpr int MLO = !SHARE ? 0 : (SHARE_TG == 0 ? 0 : NA), MHI = !SHARE ? NBW : (SHARE_TG == 0 ? NA : NBW);   // this wave fetches [MLO, MHI)
   unsigned* status = cm.status;
   const int tid = FUSED ? (int)(threadIdx.x & 255u) : (int)threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..3
@@ -792,7 +805,7 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
       const unsigned par = ((((unsigned)(step - 1)) >> 1) & 1u) ^ 1u;
       for (;;) {
 #pragma unroll
-        for (int i = 0; i < NBW; ++i) {
+        for (int i = MLO; i < MHI; ++i) {
           v[2 * i] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i], sbase, 16);              // sc1
           v[2 * i + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i] + 1024u, sbase, 16);   // sc1
         }
@@ -801,7 +814,7 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
         //  them for the Z prefetch issued in between - inside the MFMA chain: +240 cycles per step, measured)
         unsigned a_and = 0xFFFFFFFFu, a_or = 0u;
 #pragma unroll
-        for (int i = 0; i < 2 * NBW; ++i) {
+        for (int i = 2 * MLO; i < 2 * MHI; ++i) {
           a_and &= v[i].x & v[i].y & v[i].z & v[i].w;
           a_or |= v[i].x | v[i].y | v[i].z | v[i].w;
         }
@@ -809,6 +822,17 @@ __device__ __forceinline__ void cluster_run_k16(const ClusterJob& jb, const Clus
         if (__builtin_amdgcn_readfirstlane((int)(__all(lane_fresh) || failed))) break;
         tick();
         if (failed) break;
+      }
+    }
+    if constexpr (SHARE) {
+      if (step > 0) {   // (workgroup-uniform: every wave of both halves takes the barrier, whatever its own gather did)
+        u32x4* ximg = reinterpret_cast<u32x4*>(xs) + wave * (NBW * 2 * 64) + lane;
+#pragma unroll
+        for (int i = 2 * MLO; i < 2 * MHI; ++i) ximg[i * 64] = v[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2 * NBW; ++i)
+          if (i < 2 * MLO || i >= 2 * MHI) v[i] = ximg[i * 64];
       }
     }
     KSTAMP(0, v[0].x);
@@ -1411,6 +1435,38 @@ __global__ __launch_bounds__(512, 1) void k_scan_cluster_k16f(ClusterLaunch L) {
   }
 }
 
+// the fused form with the SHARED gather (cluster_run_k16<.., true, half>): as k_scan_cluster_k16f, plus 2 KiB of LDS per wave and K-block
+// for the image the two halves exchange; a unit group beyond G (odd G) runs as a member without valid cells
+__global__ __launch_bounds__(512, 1) void k_scan_cluster_k16fs(ClusterLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  mgr_cluster_enter(L.cm);
+  const int tg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  for (int k_ = 0; k_ < L.njobs; ++k_) {
+    const ClusterJob& jb = L.job[k_];
+    const int G = jb.G_, Gr = (G + 1) / 2;
+    const int w_ = (int)blockIdx.x - jb.cls_begin;
+    if (w_ < 0 || w_ >= (jb.cls_nclusters + 7) / 8 * 8 * Gr) continue;
+    int cl, ugr;
+    const bool same = mgr_cluster_octet(L.cm, jb.cls_begin, Gr, jb.cls_rot, w_, cl, ugr);
+    const int bg = cl - jb.cls_cluster0;
+    if (cl >= jb.cls_nclusters || bg < 0 || bg >= jb.nbg) continue;
+    const int ug = 2 * ugr + tg;
+    float* sm = smem + tg * K16_LDS_FLOATS;
+    float* xs = smem + 2 * K16_LDS_FLOATS;
+    const int nbw = (((jb.H + 31) >> 5) + 3) >> 2;
+#define K16FS_RUN(NBW)                                                        \
+  if (nbw == NBW) {                                                           \
+    if (tg == 0) cluster_run_k16<NBW, true, 0>(jb, L.cm, bg, ug, sm, same, xs); \
+    else cluster_run_k16<NBW, true, 1>(jb, L.cm, bg, ug, sm, same, xs);       \
+    return mgr_cluster_exit(L.cm);                                            \
+  }
+    K16FS_RUN(1) K16FS_RUN(2) K16FS_RUN(3) K16FS_RUN(4)
+#undef K16FS_RUN
+    return;
+  }
+}
+constexpr size_t K16FS_LDS_BYTES = (2 * (size_t)K16_LDS_FLOATS + 4 * 4 * 2 * 256) * sizeof(float);
+
 }  // namespace
 
 bool mgr_cluster_supported(int ks, int tpw) {
@@ -1501,7 +1557,15 @@ int mgr_cluster_launch(mgr_ctx* c, const ClusterLaunch& L, int total_wgs, bool a
       MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_k16f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       c->attr_done |= 4u;
     }
-    hipLaunchKernelGGL(k_scan_cluster_k16f, dim3(total_wgs), dim3(512), 2 * K16_LDS_FLOATS * sizeof(float), mgr_stream(c), L);
+    if (!(c->attr_done & 64u)) {
+      MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_cluster_k16fs), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      c->attr_done |= 64u;
+    }
+    // tune key 17: 1 = the two halves of a fused workgroup each fetch the whole h image themselves (round 5's form)
+    if (c->tune[17] == 0)
+      hipLaunchKernelGGL(k_scan_cluster_k16fs, dim3(total_wgs), dim3(512), K16FS_LDS_BYTES, mgr_stream(c), L);
+    else
+      hipLaunchKernelGGL(k_scan_cluster_k16f, dim3(total_wgs), dim3(512), 2 * K16_LDS_FLOATS * sizeof(float), mgr_stream(c), L);
   } else if (ks_eligible(L, any_exchange, waves)) {
     // partial-sum exchange, staging tiles of the transposed output, Z / R rings (no h image): 50 KiB, two workgroups per CU
     bool small = true;

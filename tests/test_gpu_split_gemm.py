@@ -196,7 +196,7 @@ def test_fused_form_of_the_encoder_scans_is_bit_identical(device, B, T):
             base_jobs.append(dict(Z=Z, Up=Up, H=H, reverse=d, col=col))
             col += H
 
-    def run(fused):
+    def run(fused, own_gather=0):
         Y = dev.zeros((B, T, W))
         YT = dev.array(np.full((B, W, ldt), 7.0, f32))
         jobs, outs = [], []
@@ -208,6 +208,7 @@ def test_fused_form_of_the_encoder_scans_is_bit_identical(device, B, T):
                              reverse=j["reverse"], YT=YT.ptr + c0 * ldt * 4, ytb=W * ldt, ldt=ldt, yt_split=1))
         dev.call("mgr_tune", 1, 1)
         dev.call("mgr_tune", 4, 3 if fused else 0)
+        dev.call("mgr_tune", 17, own_gather)
         try:
             arr = _capi.make_scan_jobs(jobs)
             ws = dev.bytes(dev.lib.mgr_lstm_scan_multi_ws_bytes(len(jobs), arr))
@@ -215,13 +216,17 @@ def test_fused_form_of_the_encoder_scans_is_bit_identical(device, B, T):
         finally:
             dev.call("mgr_tune", 1, 0)
             dev.call("mgr_tune", 4, 0)
+            dev.call("mgr_tune", 17, 0)
         return Y.download(), YT.download(), [o.download() for o in outs]
 
     y0, yt0, o0 = run(False)
-    y1, yt1, o1 = run(True)
     assert np.isfinite(y0).all() and np.abs(y0).max() > 0.1
-    assert np.array_equal(y0, y1) and np.array_equal(yt0.view(np.uint32), yt1.view(np.uint32))
-    assert all(np.array_equal(a, b) for a, b in zip(o0, o1))
+    # round 6: the two halves of a fused workgroup SHARE one gather of the h image through LDS (k_scan_cluster_k16fs, the default);
+    # tune key 17 = 1: each half fetches the whole image itself (round 5's k_scan_cluster_k16f) - all three the same bits
+    for own_gather in (0, 1):
+        y1, yt1, o1 = run(True, own_gather)
+        assert np.array_equal(y0, y1) and np.array_equal(yt0.view(np.uint32), yt1.view(np.uint32)), own_gather
+        assert all(np.array_equal(a, b) for a, b in zip(o0, o1)), own_gather
 
 
 @pytest.mark.parametrize("H,B,T", [(100, 64, 40), (128, 20, 9), (64, 33, 17), (100, 16, 1)])
