@@ -145,7 +145,8 @@ def main():
     ap.add_argument("--no-two-ahead", action="store_true", help="the encoder stream is handed a batch's pass one call ahead only (round 4)")
     ap.add_argument("--no-d1-ahead", action="store_true", help="Schedule.depth1_proj_ahead off: the depth-1 projections behind the previous batch's deepest scan (round 4)")
     ap.add_argument("--no-fused-scans", action="store_true", help="Schedule.fused_encoder_scans off: 408 four-wave encoder scan workgroups, two per CU where needed")
-    ap.add_argument("--fusion-scan-fused", action="store_true", help="Schedule.fusion_scan_fused: the fusion layer's forward scan as 32 eight-wave workgroups, a CU each")
+    ap.add_argument("--no-fusion-scan-fused", action="store_true", help="Schedule.fusion_scan_fused off: the fusion layer's forward scan as 56 four-wave workgroups (round 5)")
+    ap.add_argument("--chain-priority", type=int, default=0, help="Schedule.chain_stream_priority: 1 = stream 0 high, -1 = the encoder stream low")
     ap.add_argument("--bptt-fused", action="store_true", help="Schedule.bptt_fused: the fusion layer's BPTT as 32 eight-wave workgroups, a CU each")
     ap.add_argument("--bptt-direct", action="store_true", help="beside fused encoder scans the fusion layer's BPTT takes the direct-gather form (one barrier per step)")
     ap.add_argument("--no-fused-wide", action="store_true", help="with fused encoder scans the fusion layer's GEMMs keep their 4-wave tiles")
@@ -214,7 +215,7 @@ def main():
     eng = Engine(spec, B, T, Lmax, device=dev, seed=1000 + rank, comm=comm, world=world,
                  schedule=Schedule(transposed_inputs=not args.no_transposed, split_rows=not args.no_split_rows,
                                    deepest_scan_after_fusion_proj=not args.scan_with_fproj, depth1_proj_ahead=not args.no_d1_ahead,
-                                   bptt_yields_beside_scans=not args.bptt_lean, fused_encoder_scans=not args.no_fused_scans, fused_wide_tiles=not args.no_fused_wide, bptt_direct_when_alone=args.bptt_direct, fusion_scan_fused=args.fusion_scan_fused, bptt_fused=args.bptt_fused))
+                                   bptt_yields_beside_scans=not args.bptt_lean, fused_encoder_scans=not args.no_fused_scans, fused_wide_tiles=not args.no_fused_wide, bptt_direct_when_alone=args.bptt_direct, fusion_scan_fused=not args.no_fusion_scan_fused, bptt_fused=args.bptt_fused, chain_stream_priority=args.chain_priority))
     eng.set_weights(synthetic_weights(spec, 20131900 + 3))
     xs, labels, il, ll = synthetic_arrays(spec, B, T, Lmax, 20131900 + 3 + 17 * rank)
     eng._upload_inputs(xs, None, True)

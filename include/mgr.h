@@ -65,6 +65,12 @@ int mgr_d2d(mgr_ctx* ctx, void* dst, const void* src, size_t n);
 int mgr_sync(mgr_ctx* ctx);
 int mgr_stream_set(mgr_ctx* ctx, int idx);
 int mgr_stream_wait(mgr_ctx* ctx, int waiter, int waited); /* waiter waits for everything queued on waited */
+/* Dispatch priority of stream idx: level 1 high, 0 default, -1 low (hipStreamCreateWithPriority).  The stream is recreated: it must be
+ * idle (the call waits for it) and is best set before first use.  What it buys: when two streams have chip-filling GEMMs ready at the same
+ * time, the workgroups of the higher-priority stream are placed first - the engine gives the stream that carries a training step's
+ * dependent chain (fusion projections -> scan -> CTC -> BPTT -> dW -> Adam) the chip when the encoder stream has slack
+ * (Schedule.chain_stream_priority). */
+int mgr_stream_set_priority(mgr_ctx* ctx, int idx, int level);
 int mgr_event_record(mgr_ctx* ctx, int ev);               /* on the current stream */
 int mgr_stream_wait_event(mgr_ctx* ctx, int waiter, int ev); /* stream `waiter` waits for event ev as last recorded */
 int mgr_event_elapsed_ms(mgr_ctx* ctx, int ev0, int ev1, float* ms);

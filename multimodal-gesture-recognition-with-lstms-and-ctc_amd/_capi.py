@@ -33,6 +33,7 @@ SIGNATURES = {
     "mgr_sync": (i32, [vp]),
     "mgr_stream_set": (i32, [vp, i32]),
     "mgr_stream_wait": (i32, [vp, i32, i32]),
+    "mgr_stream_set_priority": (i32, [vp, i32, i32]),
     "mgr_event_record": (i32, [vp, i32]),
     "mgr_stream_wait_event": (i32, [vp, i32, i32]),
     "mgr_event_elapsed_ms": (i32, [vp, i32, i32, C.POINTER(C.c_float)]),

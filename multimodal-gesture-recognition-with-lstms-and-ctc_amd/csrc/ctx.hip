@@ -205,6 +205,20 @@ int mgr_stream_set(mgr_ctx* c, int idx) {
   return 0;
 }
 
+int mgr_stream_set_priority(mgr_ctx* c, int idx, int level) {
+  MGR_REQUIRE(c && idx >= 0 && idx < MGR_NUM_STREAMS && level >= -1 && level <= 1, "bad stream index / level (-1 low, 0 default, 1 high)");
+  MGR_HIP(hipSetDevice(c->device));
+  int least = 0, greatest = 0;   // (numerically: least >= greatest; lower numbers are higher priorities)
+  MGR_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  const int prio = level > 0 ? greatest : level < 0 ? least : (least + greatest) / 2;
+  MGR_HIP(hipStreamSynchronize(c->streams[idx]));
+  hipStream_t s;
+  MGR_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
+  MGR_HIP(hipStreamDestroy(c->streams[idx]));
+  c->streams[idx] = s;
+  return 0;
+}
+
 int mgr_stream_wait(mgr_ctx* c, int waiter, int waited) {
   MGR_REQUIRE(c, "null ctx");
   MGR_REQUIRE(waiter >= 0 && waiter < MGR_NUM_STREAMS && waited >= 0 && waited < MGR_NUM_STREAMS, "bad stream index");

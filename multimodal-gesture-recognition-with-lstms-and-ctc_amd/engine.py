@@ -104,9 +104,14 @@ class Schedule:
                         that runs into its bound is counted (Engine.resident_wait_stats)
     fusion_scan_fused   (round 6; with fused_encoder_scans) the fusion layer's own forward scan takes the fused form as well
                         (MGR_SCAN_FORM_FUSED_ANY: H = 100 -> 4 eight-wave workgroups per cluster, 32 workgroups that hold a CU each,
-                        instead of 56 four-wave workgroups on the 48 CUs the encoder scans leave, eight of which carry two)
+                        instead of 56 four-wave workgroups on the 48 CUs the encoder scans leave, eight of which carry two).  The scan
+                        itself is no faster (3.6 against 3.4 ms in the step); the 16 CUs it leaves free are what the head's Dense
+                        kernels get (dense_bwd 0.85 -> 0.21 ms): 16.2 - 16.3 -> 15.9 - 16.0 ms per step (profiles/r06_schedule_probes.txt)
     bptt_fused          (round 6; with fused_encoder_scans) the fusion layer's BPTT takes the fused form too (MGR_BPTT_FORM_FUSED /
                         _FUSED_DIRECT with bptt_direct_when_alone: 32 eight-wave workgroups, a CU each, instead of 56 four-wave ones)
+    chain_stream_priority  (round 6) dispatch priority of stream 0 against the encoder stream: 1 = stream 0 (the step's dependent chain)
+                        high, -1 = the encoder stream low, 0 = equal (rounds 1 - 5).  Round 5 measured it zero-sum while both streams were
+                        equally long; with the shared gather the encoder stream has slack
     split_rows          (round 5) the transposed copies are written in the split row format (f16 hi / lo pairs) and the wide products
                         run as loader / matrix pipelines on pre-split operands (gemm_split.hip); False: f32 rows, converted by
                         every product that reads them (round 4's kernels)
@@ -119,8 +124,9 @@ class Schedule:
     def __init__(self, pipeline=True, defer_param_grads=True, encoders_run_ahead=True, resident_wait_us=2000,
                  transposed_inputs=True, bptt_beside_deepest_scan=True, split_rows=True, encoders_two_ahead=True,
                  deepest_scan_after_fusion_proj=True, depth1_proj_ahead=True, bptt_yields_beside_scans=True,
-                 fused_encoder_scans=True, fused_wide_tiles=True, bptt_direct_when_alone=False, fusion_scan_fused=False,
-                 bptt_fused=False):
+                 fused_encoder_scans=True, fused_wide_tiles=True, bptt_direct_when_alone=False, fusion_scan_fused=True,
+                 bptt_fused=False, chain_stream_priority=0):
+        self.chain_stream_priority = int(chain_stream_priority)
         self.bptt_fused = bool(bptt_fused)
         self.fusion_scan_fused = bool(fusion_scan_fused)
         self.bptt_direct_when_alone = bool(bptt_direct_when_alone)
@@ -159,6 +165,12 @@ class Engine:
         self.comm = comm
         self.world = int(world)
         self.inference_only = inference_only
+        if self.schedule.chain_stream_priority:
+            # (a property of the CONTEXT's streams: engines that share a Device share it; the call waits for the stream to be idle)
+            if self.schedule.chain_stream_priority > 0:
+                self.dev.call("mgr_stream_set_priority", 0, 1)
+            else:
+                self.dev.call("mgr_stream_set_priority", self.ES, -1)
         self._adam_calls = 0  # optimizer steps enqueued; `iterations` (Keras) = those the update gate did not skip
         self.rng_step = 0     # advances per forward pass that draws randomness
         self._build()
