@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--no-fused-scans", action="store_true", help="Schedule.fused_encoder_scans off: 408 four-wave encoder scan workgroups, two per CU where needed")
     ap.add_argument("--no-fusion-scan-fused", action="store_true", help="Schedule.fusion_scan_fused off: the fusion layer's forward scan as 56 four-wave workgroups (round 5)")
     ap.add_argument("--chain-priority", type=int, default=0, help="Schedule.chain_stream_priority: 1 = stream 0 high, -1 = the encoder stream low")
+    ap.add_argument("--pg-two-streams", action="store_true", help="Schedule.param_grads_two_streams: the two directions' dW / dU / db chains on two streams")
+    ap.add_argument("--first-pass-inline", action="store_true", help="Schedule.first_pass_on_encoder_stream off: a step without a prefetched pass runs it in line on stream 0 (round 5)")
     ap.add_argument("--bptt-fused", action="store_true", help="Schedule.bptt_fused: the fusion layer's BPTT as 32 eight-wave workgroups, a CU each")
     ap.add_argument("--bptt-direct", action="store_true", help="beside fused encoder scans the fusion layer's BPTT takes the direct-gather form (one barrier per step)")
     ap.add_argument("--no-fused-wide", action="store_true", help="with fused encoder scans the fusion layer's GEMMs keep their 4-wave tiles")
@@ -215,7 +217,7 @@ def main():
     eng = Engine(spec, B, T, Lmax, device=dev, seed=1000 + rank, comm=comm, world=world,
                  schedule=Schedule(transposed_inputs=not args.no_transposed, split_rows=not args.no_split_rows,
                                    deepest_scan_after_fusion_proj=not args.scan_with_fproj, depth1_proj_ahead=not args.no_d1_ahead,
-                                   bptt_yields_beside_scans=not args.bptt_lean, fused_encoder_scans=not args.no_fused_scans, fused_wide_tiles=not args.no_fused_wide, bptt_direct_when_alone=args.bptt_direct, fusion_scan_fused=not args.no_fusion_scan_fused, bptt_fused=args.bptt_fused, chain_stream_priority=args.chain_priority))
+                                   bptt_yields_beside_scans=not args.bptt_lean, fused_encoder_scans=not args.no_fused_scans, fused_wide_tiles=not args.no_fused_wide, bptt_direct_when_alone=args.bptt_direct, fusion_scan_fused=not args.no_fusion_scan_fused, bptt_fused=args.bptt_fused, chain_stream_priority=args.chain_priority, param_grads_two_streams=args.pg_two_streams, first_pass_on_encoder_stream=not args.first_pass_inline))
     eng.set_weights(synthetic_weights(spec, 20131900 + 3))
     xs, labels, il, ll = synthetic_arrays(spec, B, T, Lmax, 20131900 + 3 + 17 * rank)
     eng._upload_inputs(xs, None, True)
@@ -320,14 +322,20 @@ def main():
         # ---- roofline of the dominant kernel family (device time from HIP events on the launch streams) ----
         dom = max(fam, key=lambda k: fam[k]["ms"])
         flops_family = {}
-        gemm_nn = scan_fwd = scan_bwd = gemm_tn = gemm_nt = 0
+        gemm_nn = scan_fwd = scan_fwd_narrow = scan_bwd = gemm_tn = gemm_nt = 0
+        # (a multi-scan call is counted as scan_fwd when its widest layer has H > 128 - the encoder depths of config F - and as
+        #  scan_fwd_narrow otherwise: include/mgr.h.  Every call of the reference networks holds layers of one depth: widths of one class)
         for prefix, fin, H, _, tr in spec.lstm_layers():
             gemm_nn += 2 * 2 * fin * 4 * H
-            scan_fwd += 2 * 2 * H * 4 * H
+            if H > 128:
+                scan_fwd += 2 * 2 * H * 4 * H
+            else:
+                scan_fwd_narrow += 2 * 2 * H * 4 * H
             if tr:
                 scan_bwd += 2 * 2 * H * 4 * H
                 gemm_tn += 2 * 2 * (fin * 4 * H + H * 4 * H)
-        flops_family = {"gemm_nn": gemm_nn, "scan_fwd": scan_fwd, "scan_bwd": scan_bwd, "gemm_tn": gemm_tn, "gemm_nt": gemm_nt}
+        flops_family = {"gemm_nn": gemm_nn, "scan_fwd": scan_fwd, "scan_fwd_narrow": scan_fwd_narrow, "scan_bwd": scan_bwd, "gemm_tn": gemm_tn,
+                        "gemm_nt": gemm_nt}
         roof = None
         if dom in flops_family and fam[dom]["ms"] > 0:
             fl = flops_family[dom] * B * T * args.steps
@@ -335,21 +343,22 @@ def main():
             # HBM bytes per launch of that family from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
             # their own runs, tools/profile_round.sh + summarize_profile.py) - only if that pass was taken on THIS tree
             # (hash of the device sources + engine schedule); null otherwise
-            traffic = None
+            traffic = traffic_kernel = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if args.config == "F" and world == 1 and os.path.exists(tpath):
                 from mgr_amd._build import source_hash
                 with open(tpath) as fh:
                     rec = json.load(fh)
                 if rec.get("src_sha") == source_hash():
-                    traffic = rec.get("bytes_per_launch", {}).get(dom)
+                    traffic = rec.get("bytes_per_launch", {}).get(dom)       # (the family's dominant KERNEL in the profiled run)
                     traffic = round(traffic) if traffic else None
+                    traffic_kernel = rec.get("family_kernel", {}).get(dom)
             tuned = dict(kv.split("=") for kv in args.tune)
-            split16 = {"scan_fwd": tuned.get("14", "0") == "0", "gemm_nn": tuned.get("15", "0") == "0",
+            split16 = {"scan_fwd": tuned.get("14", "0") == "0", "scan_fwd_narrow": tuned.get("14", "0") == "0", "gemm_nn": tuned.get("15", "0") == "0",
                        "gemm_tn": tuned.get("15", "0") == "0"}.get(dom, False)
             peak = MFMA_SPLIT16_PEAK_TFLOPS if split16 else MFMA_F32_PEAK_TFLOPS
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 5), "traffic": traffic,
+                    "frac": round(ach / peak, 5), "traffic": traffic, "traffic_kernel": traffic_kernel,
                     "avg_launch_ms": round(fam[dom]["ms"] / max(1, fam[dom]["launches"]), 4),
                     # achieved = algorithmic f32 FLOP / device time.  peak: the instruction mix that kernel issues - f16 MFMA
                     # (2516.8 TF dense) at three f16 products per f32 product, or the f32 MFMA rate; both fractions are given

@@ -78,7 +78,10 @@ int mgr_event_elapsed_ms(mgr_ctx* ctx, int ev0, int ev1, float* ms);
  * family ids: MGR_K_*.  mgr_prof_get syncs the device and returns accumulated launches / milliseconds. */
 enum {
   MGR_K_GEMM_NN = 0, MGR_K_GEMM_TN = 1, MGR_K_GEMM_NT = 2, MGR_K_SCAN_FWD = 3, MGR_K_SCAN_BWD = 4,
-  MGR_K_DENSE_FWD = 5, MGR_K_DENSE_BWD = 6, MGR_K_CTC = 7, MGR_K_ADAM = 8, MGR_K_MISC = 9, MGR_K_ALLREDUCE = 10, MGR_K_COUNT = 11
+  MGR_K_DENSE_FWD = 5, MGR_K_DENSE_BWD = 6, MGR_K_CTC = 7, MGR_K_ADAM = 8, MGR_K_MISC = 9, MGR_K_ALLREDUCE = 10,
+  /* (round 6) multi-scan calls whose widest layer has H <= 128 - the fusion layer's own scan - are counted apart from the encoder
+   * depths (MGR_K_SCAN_FWD): a roofline figure of the dominant kernel must not average it with a launch of 3 % of its FLOP */
+  MGR_K_SCAN_FWD_NARROW = 11, MGR_K_COUNT = 12
 };
 int mgr_prof_enable(mgr_ctx* ctx, int family_mask);
 int mgr_prof_get(mgr_ctx* ctx, int family, int* launches, float* ms);
@@ -154,6 +157,12 @@ int mgr_lstm_input_proj_dropout_ts(mgr_ctx* ctx, const float* XS, int ldt, const
                                    size_t ws_bytes);
 /* XS[b][f] = the split row (above) of X[b][0..T)[f], zero for t in [T, ldt); ldt % 8 == 0. */
 int mgr_transpose_bt_split(mgr_ctx* ctx, const float* X, int ldx, float* XS, int ldt, int B, int T, int F);
+/* Frozen weights: frozen != 0 promises that the contents of Wp (a packed input-weight matrix passed to mgr_lstm_input_proj_dropout_ts) do
+ * not change until the next call of this function for the same pointer; the (hi, lo) weight planes and the largest |W| that
+ * mgr_lstm_input_proj_dropout_ts leaves in its workspace are then reused by later calls with the same (Wp, workspace, F, H) instead of
+ * being rebuilt (the frozen encoders of the fusion network, multimodal_fusion/multimodal.py:118-130: 4 of the 6 conversions of a step).
+ * Every call (either value) drops what was kept for Wp - call it again after rewriting the weights.  Host-side state only. */
+int mgr_weight_planes_cache(mgr_ctx* ctx, const float* Wp, int frozen);
 /* Recurrence. reverse=1 walks t = T-1..0 and writes outputs at their original t (Bidirectional backward
  * sub-layer).  Y[b,t,0:H] with row stride ldy gets h_t (+ R[b,t,0:H] with stride ldr when R != NULL: the
  * residual add / concat fusion of multimodal.py:111,117,155).  gates [B,T,H,4] (i,f,g,o after activation) and

@@ -53,6 +53,7 @@ SIGNATURES = {
     "mgr_lstm_input_proj_dropout_ts_ws_bytes": (sz, [i32, i32, i32]),
     "mgr_lstm_input_proj_dropout_ts": (i32, [vp, vp, i32, vp, C.c_float, vp, vp, vp, i32, i32, i32, i32, vp, sz]),
     "mgr_transpose_bt_split": (i32, [vp, vp, i32, vp, i32, i32, i32, i32]),
+    "mgr_weight_planes_cache": (i32, [vp, vp, i32]),
     "mgr_lstm_input_proj_pair": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
     "mgr_lstm_scan_ws_bytes": (sz, [i32, i32, i32]),
     "mgr_lstm_scan_fwd": (i32, [vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, sz]),
@@ -120,8 +121,9 @@ SIGNATURES = {
 
 SCAN_GAVE_UP, SCAN_NONFINITE = 1, 8   # enum in include/mgr.h (mgr_scan_status)
 
-(K_GEMM_NN, K_GEMM_TN, K_GEMM_NT, K_SCAN_FWD, K_SCAN_BWD, K_DENSE_FWD, K_DENSE_BWD, K_CTC, K_ADAM, K_MISC, K_ALLREDUCE) = range(11)
-KERNEL_FAMILIES = ["gemm_nn", "gemm_tn", "gemm_nt", "scan_fwd", "scan_bwd", "dense_fwd", "dense_bwd", "ctc", "adam", "misc", "allreduce"]
+(K_GEMM_NN, K_GEMM_TN, K_GEMM_NT, K_SCAN_FWD, K_SCAN_BWD, K_DENSE_FWD, K_DENSE_BWD, K_CTC, K_ADAM, K_MISC, K_ALLREDUCE, K_SCAN_FWD_NARROW) = range(12)
+KERNEL_FAMILIES = ["gemm_nn", "gemm_tn", "gemm_nt", "scan_fwd", "scan_bwd", "dense_fwd", "dense_bwd", "ctc", "adam", "misc", "allreduce",
+                   "scan_fwd_narrow"]
 
 
 

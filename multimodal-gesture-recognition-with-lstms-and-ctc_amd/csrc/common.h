@@ -9,6 +9,7 @@
 #include "../../include/mgr.h"
 
 constexpr int MGR_MAX_PERSIST = 8;
+constexpr int MGR_MAX_FROZEN = 32;
 
 constexpr size_t MGR_SMALL_D2H = 4096;
 
@@ -48,9 +49,25 @@ struct mgr_ctx {
   unsigned persist_seq;     // sequence number of the last persistent launch of this context
   int persist_serialised;   // launches that had to be ordered behind another stream's persistent launch
   unsigned attr_done;       // bit k: function attributes of kernel family k have been set on this context's device
+  // split weight planes of FROZEN weights (gemm_split.hip, mgr_weight_planes_cache): weights the caller promised not to rewrite, and
+  // the workspaces that hold their planes as of that promise
+  struct PlaneEntry {
+    const void* Wp;
+    const void* ws;
+    int F, H;
+  };
+  const void* frozen_w[MGR_MAX_FROZEN];
+  PlaneEntry planes[MGR_MAX_FROZEN];
 };
 
 int mgr_fail(int code, const char* fmt, ...);
+
+// cached split weight planes (gemm_split.hip, mgr_weight_planes_cache) live in a projection workspace: any OTHER use of that workspace
+// forgets them
+static inline void mgr_planes_forget_ws(mgr_ctx* c, const void* ws) {
+  for (int i = 0; i < MGR_MAX_FROZEN; ++i)
+    if (c->planes[i].ws == ws) c->planes[i] = mgr_ctx::PlaneEntry{nullptr, nullptr, 0, 0};
+}
 
 #define MGR_HIP(expr)                                                                      \
   do {                                                                                     \

@@ -95,6 +95,10 @@ int mgr_free(mgr_ctx* c, void* dptr) {
   MGR_HIP(hipSetDevice(c->device));
   if (dptr == c->status_bound) c->status_bound = nullptr;   // a freed status block is not reported into any more
   if (dptr == c->gate_flag) c->gate_flag = nullptr;
+  for (int i = 0; i < MGR_MAX_FROZEN; ++i) {   // (cached weight planes: neither the weights nor the workspace outlive their buffer)
+    if (c->frozen_w[i] == dptr) c->frozen_w[i] = nullptr;
+    if (c->planes[i].Wp == dptr || c->planes[i].ws == dptr) c->planes[i] = mgr_ctx::PlaneEntry{nullptr, nullptr, 0, 0};
+  }
   MGR_HIP(hipFree(dptr));
   return 0;
 }

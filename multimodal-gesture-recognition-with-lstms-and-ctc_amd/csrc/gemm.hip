@@ -1531,6 +1531,7 @@ int mgr_lstm_input_proj_dropout(mgr_ctx* c, const float* X, int ldx, const float
                       aligned16(Wp);
   if (!sparse) return mgr_lstm_input_proj(c, X, ldx, mask4, Wp, bp, Z, B, T, F, H);
   MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_input_proj_dropout_ws_bytes(B, F, H), "workspace too small");
+  mgr_planes_forget_ws(c, ws);   // (this call writes its own lists / weight copies into the workspace: cached split planes in it are gone)
   return input_proj_dropout_impl(c, X, ldx, false, mask4, drop_rate, Wp, bp, Z, B, T, F, H, ws, ws_bytes);
 }
 
@@ -1545,6 +1546,7 @@ int mgr_lstm_input_proj_dropout_t(mgr_ctx* c, const float* XT, int ldt, const fl
   MGR_REQUIRE(aligned16(XT) && aligned16(bp) && aligned16(Z) && aligned16(Wp), "XT / bp / Z / Wp must be 16-byte aligned");
   MGR_REQUIRE((size_t)F * ldt < (1u << 31), "sample block too large");
   MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_input_proj_dropout_ws_bytes(B, F, H), "workspace too small");
+  mgr_planes_forget_ws(c, ws);   // (this call writes its own lists / weight copies into the workspace: cached split planes in it are gone)
   return input_proj_dropout_impl(c, XT, ldt, true, mask4, drop_rate, Wp, bp, Z, B, T, F, H, ws, ws_bytes, x_absmax);
 }
 

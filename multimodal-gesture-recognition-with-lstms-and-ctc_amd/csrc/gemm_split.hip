@@ -654,13 +654,26 @@ int mgr_lstm_input_proj_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const f
     c->attr_done |= 16u;
   }
   mgr_prof_begin(c, MGR_K_GEMM_NN);
-  MGR_HIP(hipMemsetAsync(words, 0, 2 * sizeof(unsigned), s));
+  // Frozen weights (mgr_weight_planes_cache): the planes this workspace holds from an earlier call are still those of Wp - the largest
+  // |W| (words[0]) and the (hi, lo) planes are not rebuilt, only the mask factor word is reset (4 of the 6 conversions of a config-F step)
+  bool frozen = false, cached = false;
+  int free_slot = -1;
+  for (int i = 0; i < MGR_MAX_FROZEN; ++i) frozen = frozen || (c->frozen_w[i] == Wp);
+  if (frozen) {
+    for (int i = 0; i < MGR_MAX_FROZEN; ++i) {
+      const mgr_ctx::PlaneEntry& e = c->planes[i];
+      if (e.Wp == Wp && e.ws == ws && e.F == F && e.H == H) cached = true;
+      if (!e.Wp && free_slot < 0) free_slot = i;
+    }
+  }
+  MGR_HIP(hipMemsetAsync(words + (cached ? 1 : 0), 0, (cached ? 1 : 2) * sizeof(unsigned), s));
   hipLaunchKernelGGL(k_lists32, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp32, lists, kcnt, (int*)nullptr, words + 1);
-  {
+  if (!cached) {
     const size_t n4 = (size_t)F * H;
     hipLaunchKernelGGL(k_wmax, dim3((int)((n4 + 255) / 256 < 256 ? (n4 + 255) / 256 : 256)), dim3(256), 0, s, Wp, n4, words);
     const size_t n = (size_t)(F + 1) * Hp;
     hipLaunchKernelGGL(k_wplanes, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, Wp, WSp, F, H, Hp, words);
+    if (frozen && free_slot >= 0) c->planes[free_slot] = mgr_ctx::PlaneEntry{Wp, ws, F, H};
   }
   // 128-unit tiles (8 waves, one workgroup per CU) where they waste little of their width; tune key 12: 1 = always 64, 2 = always 128
   const int waste128 = (H + 127) / 128 * 128 - H, waste64 = (H + 63) / 64 * 64 - H;
@@ -741,6 +754,22 @@ int mgr_lstm_param_grads_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const 
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_GEMM_TN);
   return 0;
+}
+
+int mgr_weight_planes_cache(mgr_ctx* c, const float* Wp, int frozen) {
+  MGR_REQUIRE(c && Wp, "null argument");
+  // whatever planes were kept for Wp are dropped: the call marks a point where the weights may have been rewritten
+  for (int i = 0; i < MGR_MAX_FROZEN; ++i) {
+    if (c->planes[i].Wp == Wp) c->planes[i] = mgr_ctx::PlaneEntry{nullptr, nullptr, 0, 0};
+    if (c->frozen_w[i] == Wp) c->frozen_w[i] = nullptr;
+  }
+  if (!frozen) return 0;
+  for (int i = 0; i < MGR_MAX_FROZEN; ++i)
+    if (!c->frozen_w[i]) {
+      c->frozen_w[i] = Wp;
+      return 0;
+    }
+  return 0;   // (table full: the weights are simply not cached)
 }
 
 int mgr_transpose_bt_split(mgr_ctx* c, const float* X, int ldx, float* XS, int ldt, int B, int T, int F) {

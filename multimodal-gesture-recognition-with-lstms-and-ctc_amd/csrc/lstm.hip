@@ -265,7 +265,10 @@ int mgr_lstm_scan_fwd_multi_ex(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, 
                 "job %d: transposed output needs a 16-byte aligned YT, ldt %% 4 == 0, ldt >= T rounded up to 32, ytb >= H * ldt", i);
     MGR_REQUIRE(!j.YT || !j.yt_split || j.ldt % 8 == 0, "job %d: split rows need ldt %% 8 == 0", i);
   }
-  int r = mgr_prof_begin(c, MGR_K_SCAN_FWD);
+  int hmax = 0;
+  for (int i = 0; i < njobs; ++i) hmax = jobs[i].H > hmax ? jobs[i].H : hmax;
+  const int family = hmax > 128 ? MGR_K_SCAN_FWD : MGR_K_SCAN_FWD_NARROW;
+  int r = mgr_prof_begin(c, family);
   if (r) return r;
   Plan P;
   make_plan(c, njobs, jobs, P);
@@ -437,7 +440,7 @@ int mgr_lstm_scan_fwd_multi_ex(mgr_ctx* c, int njobs, const mgr_scan_job* jobs, 
                    : mgr_transpose_bt_strided(c, j.Y, j.ldy, j.YT, j.ldt, j.ytb, j.ldt, j.B, j.T, j.H);
     if (r) return r;
   }
-  r = mgr_prof_end(c, MGR_K_SCAN_FWD);
+  r = mgr_prof_end(c, family);
   if (r) return r;
   if (status && c->tune[1]) return check_launch_status(c, status, "cluster scan");
   return 0;

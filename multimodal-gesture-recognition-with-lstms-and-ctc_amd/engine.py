@@ -112,6 +112,14 @@ class Schedule:
     chain_stream_priority  (round 6) dispatch priority of stream 0 against the encoder stream: 1 = stream 0 (the step's dependent chain)
                         high, -1 = the encoder stream low, 0 = equal (rounds 1 - 5).  Round 5 measured it zero-sum while both streams were
                         equally long; with the shared gather the encoder stream has slack
+    param_grads_two_streams  (round 6) the dW / dU / db chains of the two directions of a Bidirectional layer run on two streams (the
+                        second one: PG_STREAM) instead of one behind the other: the short kernels of one chain (lists, row maxima,
+                        transposes, reductions) run under the long ones of the other
+    first_pass_on_encoder_stream  (round 6; with fused_encoder_scans) a pipelined step that finds no prefetched encoder pass - the first step
+                        of a run, the step after a validation pass - runs its own pass on the ENCODER stream in the fused forms and is a
+                        steady-state call from there on (the next batch's pass follows at once, fused, its scans paired with this step's
+                        recurrences through their launch numbers); round 5: in line on stream 0 in the plain forms, the next pass behind
+                        a stream-wide wait, the fused forms only from the third step of a run on
     split_rows          (round 5) the transposed copies are written in the split row format (f16 hi / lo pairs) and the wide products
                         run as loader / matrix pipelines on pre-split operands (gemm_split.hip); False: f32 rows, converted by
                         every product that reads them (round 4's kernels)
@@ -125,7 +133,9 @@ class Schedule:
                  transposed_inputs=True, bptt_beside_deepest_scan=True, split_rows=True, encoders_two_ahead=True,
                  deepest_scan_after_fusion_proj=True, depth1_proj_ahead=True, bptt_yields_beside_scans=True,
                  fused_encoder_scans=True, fused_wide_tiles=True, bptt_direct_when_alone=False, fusion_scan_fused=True,
-                 bptt_fused=False, chain_stream_priority=0):
+                 bptt_fused=False, chain_stream_priority=0, param_grads_two_streams=False, first_pass_on_encoder_stream=True):
+        self.first_pass_on_encoder_stream = bool(first_pass_on_encoder_stream)
+        self.param_grads_two_streams = bool(param_grads_two_streams)
         self.chain_stream_priority = int(chain_stream_priority)
         self.bptt_fused = bool(bptt_fused)
         self.fusion_scan_fused = bool(fusion_scan_fused)
@@ -268,6 +278,8 @@ class Engine:
         self._xin_slot = 0
         self._xin_pin = None
         self._xin_user = [-1, -1]      # id of the last step that reads input set 0 / 1 (see _upload_inputs)
+        self._xin_copied = [False, False]   # EV_XIN_COPIED / EV_LAB_COPIED of set 0 / 1 have been recorded
+        self._lab_copied = [False, False]
         self._lab_user = [-1, -1]
         self._step_id = 0              # training steps enqueued so far
         self._synced_step = -1         # the host has seen the loss of this step (everything before its CTC is complete)
@@ -415,6 +427,15 @@ class Engine:
             else:
                 dst.view(0, (w.size,)).upload(w.reshape(-1))
         dev.sync()
+        self._freeze_planes()
+
+    def _freeze_planes(self):
+        """The input weights of FROZEN layers (the encoders of the fusion network) are rewritten by set_weights only: the library may
+        keep their split (hi, lo) planes in the projection workspaces from call to call (mgr_weight_planes_cache; every call drops
+        what was kept, so this runs after every rewrite)."""
+        for L in self.dirs.values():
+            if L.ws_sp is not None and (L.prefix + "/" + L.d + "/W") in self.frozen:
+                self.dev.call("mgr_weight_planes_cache", L.Wp, 1)
 
     def get_weights(self):
         dev = self.dev
@@ -465,6 +486,8 @@ class Engine:
     COPY_STREAM = 7
     EV_IN = (41, 42)     # last reader of input buffer set 0 / 1
     EV_LAB = (43, 44)    # last reader of label buffer set 0 / 1
+    EV_XIN_COPIED = (59, 60)   # the host-to-device copies out of input staging set 0 / 1 are done (the HOST waits for it before it
+    EV_LAB_COPIED = (61, 62)   # refills that page-locked set; ... label staging set 0 / 1)
 
     def _upload_inputs(self, inputs, rand, train, stream=0):
         """Host batch -> the input buffer set that is NOT the one read last, on the copy stream; `stream` (where the
@@ -479,6 +502,12 @@ class Engine:
         if self._xin_pin is None:   # page-locked staging, allocated at the first host batch (resident-input runs never need it)
             self._xin_pin = [{s["name"]: dev.pinned((self.B, self.T, s["F"]), np.float32) for s in self.spec.streams}
                              for _ in range(2)]
+        # The page-locked staging set is refilled by the HOST: the copies enqueued out of it last time must be done.  (Round 6: a call
+        # of the two-calls-ahead schedule that also runs its own encoder pass uploads THREE batches - its own, the next, the one after
+        # next - and the third refill met the first copy still in flight: a few input values of the step changed, a loss moved by 1e-6,
+        # one run in three.  Found by tests/test_gpu_schedule_contract.py.)
+        if self._xin_copied[slot]:
+            dev.event_sync(self.EV_XIN_COPIED[slot])
         for s in self.spec.streams:
             x = np.asarray(inputs[s["name"]])
             if x.shape != (self.B, self.T, s["F"]):
@@ -489,6 +518,8 @@ class Engine:
             if train and nz is not None:
                 stage += np.asarray(nz, dtype=np.float32)
             dev.h2d_async(self._xin_ring[slot][s["name"]], stage)   # the host does not wait for the copy
+        dev.record(self.EV_XIN_COPIED[slot])
+        self._xin_copied[slot] = True
         dev.wait(stream, self.COPY_STREAM)
         self._xin_slot = slot
         self._xin_user[slot] = 1 << 60     # set by the step that consumes it (enqueue_train_step)
@@ -1121,12 +1152,16 @@ class Engine:
             dev.wait_event(self.COPY_STREAM, self.EV_LAB[slot])
         labels_d, ilen_d, llen_d = self._lab_ring[slot]
         plab, pil, pll = self._lab_pin[slot]    # (the staging set is reused together with the device set: same ordering)
+        if self._lab_copied[slot]:              # (... and refilled by the host only once its last copies are done: _upload_inputs)
+            dev.event_sync(self.EV_LAB_COPIED[slot])
         plab[...] = lab
         pil[...] = np.asarray(input_length).reshape(self.B)
         pll[...] = np.asarray(label_length).reshape(self.B)
         dev.h2d_async(labels_d, plab)
         dev.h2d_async(ilen_d, pil)
         dev.h2d_async(llen_d, pll)
+        dev.record(self.EV_LAB_COPIED[slot])
+        self._lab_copied[slot] = True
         dev.wait(0, self.COPY_STREAM)          # the CTC kernel runs on stream 0
         self._lab_slot = slot
         self._lab_user[slot] = 1 << 60
@@ -1159,6 +1194,7 @@ class Engine:
         return self.read_loss()
 
     LOSS_STREAM = 6   # (pipelined inference: decode / result copies)
+    PG_STREAM = 4     # (Schedule.param_grads_two_streams: the second direction's parameter-gradient chain)
     EV_LOSS = 52      # the loss and the scan status of the step enqueued last have reached their page-locked host words
 
     def read_loss(self, local=False):
@@ -1234,29 +1270,57 @@ class Engine:
                 have = None
         self._prefetched = None
         defer = pipelined and sch.defer_param_grads and sp.fusion is not None and depth >= 2
-        # (not in a call that ran its own encoder pass in line on stream 0: that pass uses the encoder buffers)
-        ahead = defer and sch.encoders_run_ahead and have is not None
         any_tr_stream_ = any(s_["trainable"] for s_ in sp.streams)
-        free_ok = pipelined and ahead and sch.bptt_beside_deepest_scan and sp.fusion and not any_tr_stream_
+        host_blocking = bool(getattr(self.comm, "host_blocking", False))
         # What the encoder stream was handed a call early (the first part of the pass of the batch after this one) is settled BEFORE
         # this step's FEAT buffer is chosen: when the caller did not come back as announced - another batch, a predict /
         # loss_on_batch in between that discarded the prefetched pass - the early generator is dropped and its claim on the other FEAT
         # buffer with it; choosing `cur` first put the NEXT batch's deepest scan on top of the buffer this step's deferred dW GEMMs read.
+        # (A step without a prefetched pass always drops it: its own pass uses the encoder buffers the early part has written.)
         early, self._early_gen = self._early_gen, None
         early_words, self._early_words = self._early_words, None
-        if early is not None and not (free_ok and (not upload or next_inputs is self._early_for)):
+        keep_early = (have is not None and pipelined and defer and sch.encoders_run_ahead and sch.bptt_beside_deepest_scan and sp.fusion
+                      and not any_tr_stream_ and (not upload or next_inputs is self._early_for))
+        if early is not None and not keep_early:
             dev.wait(0, ES)
             self._feat_idx ^= 1        # (the generator toggled it when it was started; nothing of its pass has touched a FEAT buffer yet)
             early.close()
             early = None
+        # The fused forms of the encoder scans belong to every pass the encoder stream runs for a pipelined step (round 6: also the
+        # passes of the first steps of a run, which round 5 ran in the plain form until a step had been announced two calls ahead)
+        fused_ok = bool(pipelined and defer and sch.fused_encoder_scans and sch.encoders_run_ahead and sch.bptt_beside_deepest_scan
+                        and sp.fusion and not any_tr_stream_ and not host_blocking)
+        own_on_es = False
         if have is None:
-            if upload:
-                self._upload_inputs(inputs, rand, True)
-            cur = self._feat_ring[self._feat_idx]
-            self._enqueue_encoders(True, rand, cur, 0, self.rng_step)
+            if fused_ok and sch.first_pass_on_encoder_stream:
+                # Round 6: a pipelined step WITHOUT a prefetched pass (the first step of a run, the step after a validation pass) runs
+                # its own encoder pass on the ENCODER stream, in the fused forms - nothing of this step can run beside it anyway, and
+                # from here on the call is a steady-state call: the next batch's pass follows on that stream at once, beside this
+                # step's trainable part, instead of behind a whole in-line pass in the plain forms and a stream-wide wait.  The step
+                # itself is what it was: same kernels' results, same order of randomness.
+                dev.wait(ES, 0)        # (the encoder buffers / this FEAT buffer may still be read by what stream 0 has queued)
+                if upload:
+                    self._upload_inputs(inputs, None, True, stream=ES)
+                    self._xin_user[self._xin_slot] = self._step_id     # (this step reads them; frozen encoders: in this pass only)
+                cur = self._feat_ring[self._feat_idx]
+                self._enc_scan_form = _capi.SCAN_FORM_FUSED
+                try:
+                    self._enqueue_encoders(True, None, cur, ES, self.rng_step)
+                finally:
+                    self._enc_scan_form = _capi.SCAN_FORM_AUTO
+                dev.wait(0, ES)
+                own_on_es = True
+            else:
+                if upload:
+                    self._upload_inputs(inputs, rand, True)
+                cur = self._feat_ring[self._feat_idx]
+                self._enqueue_encoders(True, rand, cur, 0, self.rng_step)
         else:
             cur = have
             dev.wait(0, ES)          # this step's encoder pass (enqueued by the previous call) must be complete
+        # (not in a call that ran its own encoder pass in line on stream 0: that pass uses the encoder buffers)
+        ahead = defer and sch.encoders_run_ahead and (have is not None or own_on_es)
+        free_ok = pipelined and ahead and sch.bptt_beside_deepest_scan and sp.fusion and not any_tr_stream_
         if upload:
             self._upload_labels(labels, input_length, label_length)
         if pipelined:
@@ -1271,37 +1335,46 @@ class Engine:
         # host needs ~1-2 ms to enqueue the fusion layer and the head, during which that stream would sit idle
         free_gen = None
         free_words = None
-        if early is not None:
-            free_gen, free_words = early, early_words   # (its first part was enqueued at the end of the previous call)
-        elif free_ok:
-            free_words = {}
-            free_gen = self._next_encoders_free(next_inputs, depth, self.rng_step + 1, self._step_id + 1, seq_words=free_words)
-            next(free_gen)
-        # ---- 2., 3. fusion layer, head, CTC, loss read-back point, backward
-        # (not with a host-blocking all-reduce: HostComm holds the host inside finish(), the depth-1 scan the BPTT's wait is for would only
-        #  be enqueued after it - the wait would always run into its bound; such runs share a GPU and use small per-rank batches anyway)
-        fused = bool(sch.fused_encoder_scans and free_gen is not None and early is not None
-                     and not getattr(self.comm, "host_blocking", False))
-        two = bool(pipelined and free_gen is not None and prefetch_after_next and sch.encoders_two_ahead)
+        fused = bool(fused_ok and free_ok)
+        fresh = False
         self._gate_words = (None, None)
         new_words = None
         try:
             if fused:
+                self._enc_scan_form = _capi.SCAN_FORM_FUSED     # every encoder scan launch enqueued from here to the end of this call
+            if early is not None:
+                free_gen, free_words = early, early_words   # (its first part was enqueued at the end of the previous call)
+            elif free_ok:
+                fresh = True
+                free_words = {}
+                if fused:
+                    free_words[0] = self._new_seq_word()
+                free_gen = self._next_encoders_free(next_inputs, depth, self.rng_step + 1, self._step_id + 1, seq_words=free_words)
+                next(free_gen)
+            # ---- 2., 3. fusion layer, head, CTC, loss read-back point, backward
+            # (fused: not with a host-blocking all-reduce - HostComm holds the host inside finish(), the depth-1 scan the BPTT's wait is
+            #  for would only be enqueued after it, the wait would always run into its bound; such runs share a GPU and use small per-rank
+            #  batches anyway)
+            two = bool(pipelined and free_gen is not None and prefetch_after_next and sch.encoders_two_ahead)
+            if fused:
                 # Persistent launches from here on, in host order: fusion scan, BPTT, the next batch's deepest scan and - when the batch
-                # after next is announced - its depth-1 scan.  The last two take the FUSED form (an argument of their launch), and each
-                # hands its launch number to the word the fusion scan's / the BPTT's residency wait polls: the waits are enqueued first.
-                self._enc_scan_form = _capi.SCAN_FORM_FUSED
+                # after next is announced - its depth-1 scan.  The encoder scans take the FUSED form (an argument of their launch), and
+                # each hands its launch number to the word the residency wait of the recurrence that runs BESIDE it polls (the waits are
+                # enqueued first).  Steady state: the fusion scan beside the next batch's deepest scan, the BPTT beside the depth-1 scan
+                # of the batch after next.  A call that starts the next batch's pass itself (fresh: the first steps of a run): the
+                # fusion scan beside that pass's depth-1 scan (already enqueued: its word is filled), the BPTT beside its deepest scan.
                 wx = self._new_seq_word()
                 free_words[depth - 1] = wx
                 wy = None
                 if two and depth > 1:
                     wy = self._new_seq_word()
                     new_words = {0: wy}
-                self._gate_words = (wx, wy)
+                self._gate_words = (free_words.get(0), wx) if fresh else (wx, wy)
                 self._wide_ok = bool(sch.fused_wide_tiles)
                 if sch.fusion_scan_fused:
                     self._fusion_scan_form = _capi.SCAN_FORM_FUSED_ANY
-            finish = self._enqueue_trainable_part(cur, rand, pipelined, defer, sch.bptt_beside_deepest_scan, have is None, apply_update)
+            finish = self._enqueue_trainable_part(cur, rand, pipelined, defer, sch.bptt_beside_deepest_scan, have is None and not own_on_es,
+                                                  apply_update)
 
             # ---- 4. parameter gradients + optimizer, and (pipelined) the next step's encoder pass
             if not pipelined:
@@ -1555,11 +1628,18 @@ class Engine:
         _capi.check(self.lib.mgr_lstm_scan_bwd_multi_ex(dev.ctx, len(jobs), arr, self._ws_bwd_multi.ptr, self._ws_bwd_multi.nbytes,
                                                         C.byref(opts)))
 
+        two = self.schedule.param_grads_two_streams
+
         def param_grads():
+            if two:
+                dev.stream(0)
+                dev.wait(self.PG_STREAM, 0)     # (everything queued on stream 0 so far: the BPTT, the previous step's optimizer)
             for di, dname in enumerate(("fwd", "bwd")):
                 L = self.dirs["%s/%s" % (prefix, dname)]
                 H = L.H
                 mptr = self._masks.get((L.prefix, L.d), 0)
+                if two:
+                    dev.stream(self.PG_STREAM if di == 1 else 0)
                 if mptr and XinT is not None and self._xt_split.get(XinT.ptr, False):
                     with self._narrow_tiles(beside_scans and not wide_ok):
                         dev.call("mgr_lstm_param_grads_dropout_ts", XinT, self.ldt, mptr, float(L.p), Hbuf.view(di * H, (1,)), ldh, L.dZ,
@@ -1577,6 +1657,9 @@ class Engine:
                 else:
                     dev.call("mgr_lstm_param_grads", Xin, ldx, mptr, Hbuf.view(di * H, (1,)), ldh, L.dZ, L.gWp, L.gUp,
                              L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes)
+            if two:
+                dev.stream(0)
+                dev.wait(0, self.PG_STREAM)     # (the optimizer / the input-gradient GEMMs behind this need both chains)
         if not defer_param_grads:
             param_grads()
         if dX is not None:

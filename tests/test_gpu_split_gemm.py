@@ -285,3 +285,58 @@ def test_fused_form_of_a_narrow_layer_by_launch_option(device, H, B, T):
         assert all(np.array_equal(a, b) for a, b in zip(o0, o))
     for a in keep:
         a.free()
+
+
+def test_frozen_weight_planes_are_kept_and_dropped(device):
+    """mgr_weight_planes_cache (round 6): for weights the caller declares frozen, mgr_lstm_input_proj_dropout_ts keeps the (hi, lo) planes
+    and the largest |W| it left in its workspace - the same bits as a call that rebuilds them; weights rewritten BEHIND the library's
+    back show that the planes really were reused (the result is the old weights'), and declaring them again drops the planes."""
+    dev = device
+    B, T, F, H, p = 2, 150, 600, 300, 0.5
+    rng = np.random.default_rng(4)
+    N = 4 * H
+    X = rng.uniform(-2, 2, (B, T, F)).astype(f32)
+    W1 = (rng.standard_normal((F, N)) * 0.1).astype(f32)
+    W2 = (rng.standard_normal((F, N)) * 0.3).astype(f32)
+    bias = rng.standard_normal(N).astype(f32)
+    M = ((rng.random((4, B, F)) >= p) * f32(2.0)).astype(f32)
+    ldt = (T + 127) // 128 * 128
+    dX, dW, db, dM = dev.array(X), dev.array(W1), dev.array(bias), dev.array(M)
+    XS = dev.zeros((B, F, ldt))
+    dev.call("mgr_transpose_bt_split", dX, F, XS, ldt, B, T, F)
+    ws = dev.bytes(dev.lib.mgr_lstm_input_proj_dropout_ts_ws_bytes(B, F, H))
+    Z = dev.empty((B, T, N))
+
+    def proj(mask=dM):
+        Z.upload(np.full((B, T, N), np.nan, f32))
+        dev.call("mgr_lstm_input_proj_dropout_ts", XS, ldt, mask, p, dW, db, Z, B, T, F, H, ws, ws.nbytes)
+        return Z.download()
+
+    z1 = proj()                                       # not frozen: planes rebuilt by every call
+    dev.call("mgr_weight_planes_cache", dW, 1)
+    assert np.array_equal(proj(), z1)                 # builds and keeps the planes
+    assert np.array_equal(proj(), z1)                 # ... reuses them: the same bits
+    M2 = ((rng.random((4, B, F)) >= p) * f32(2.0)).astype(f32)
+    zm = proj(dev.array(M2))                          # another mask with kept planes (the mask factor word is reset per call)
+    dev.call("mgr_weight_planes_cache", dW, 0)
+    assert np.array_equal(proj(dev.array(M2)), zm)
+    dev.call("mgr_weight_planes_cache", dW, 1)
+    assert np.array_equal(proj(), z1)
+    # the workspace is shared with the f32-row entry points (inference passes of the same layer): a call of one of them overwrites
+    # the kept planes - the library must notice (it did not at first: a predict between two training steps poisoned the next step)
+    XT = dev.zeros((B, F, ldt))
+    dev.call("mgr_transpose_bt", dX, F, XT, ldt, B, T, F)
+    Zt = dev.empty((B, T, N))
+    wst = dev.lib.mgr_lstm_input_proj_dropout_ws_bytes(B, F, H)
+    assert wst <= ws.nbytes
+    dev.call("mgr_lstm_input_proj_dropout_t", XT, ldt, dM, p, dW, db, Zt, B, T, F, H, ws, ws.nbytes, 2.0)
+    assert np.array_equal(proj(), z1)
+    dW.upload(W2)                                     # rewritten behind the promise: the kept planes are still W1's
+    assert np.array_equal(proj(), z1)
+    dev.call("mgr_weight_planes_cache", dW, 1)        # declared again = "rewritten": dropped, rebuilt from W2
+    z2 = proj()
+    assert not np.array_equal(z2, z1)
+    dev.call("mgr_weight_planes_cache", dW, 0)
+    assert np.array_equal(proj(), z2)
+    for a in (dX, dW, db, dM, XS, ws, Z):
+        a.free()

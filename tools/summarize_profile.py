@@ -24,7 +24,7 @@ j = json.loads(open("%s/%s_bench.json" % (G, tag)).read())
 out.append("## bench.py line\n```json\n%s\n```\n" % json.dumps(j, indent=1))
 shutil.copy("%s/%s_kernel_stats.csv" % (G, tag), "profiles/%s_kernel_stats.csv" % tag)
 rows = list(csv.DictReader(open("%s/%s_kernel_stats.csv" % (G, tag))))
-out.append("## rocprofv3 --kernel-trace --stats (3 timed steps + 1 warm-up)\n")
+out.append("## rocprofv3 --kernel-trace --stats (the default bench.py run: 50 timed steps + 3 warm-up)\n")
 out.append("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
 for r in rows[:14]:
     out.append("| %s | %s | %.2f | %.1f | %s |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
@@ -49,38 +49,46 @@ def pmc(name):
 
 f, fc = pmc("FETCH_SIZE")
 w, wc = pmc("WRITE_SIZE")
-out.append("\n## HBM traffic per launch (PMC, separate passes; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md)\n")
+out.append("\n## HBM traffic per launch (PMC, separate passes of bench.py --steps 8 --warmup 3 - the fused schedule engages from the second step on; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md)\n")
 out.append("| kernel | launches | fetch MB/launch (x2-corrected) | write MB/launch |\n|---|---|---|---|")
 for k in sorted(f, key=lambda k: -f[k]["FETCH_SIZE"]):
     if fc[k] == 0:
         continue
     out.append("| %s | %d | %.1f | %.1f |" % (k, fc[k], 2 * f[k]["FETCH_SIZE"] / fc[k] / 1024,
                                            w[k]["WRITE_SIZE"] / max(1, wc[k]) / 1024))
-# per-family HBM bytes per launch for bench.py's roofline.traffic (read + write, FETCH_SIZE x2-corrected, KB -> bytes)
-FAMILY = {"k_scan_cluster_ks": "scan_fwd", "k_scan_cluster_ks_s": "scan_fwd", "k_scan_cluster_bwd_s": "scan_bwd", "k_scan_cluster_bwd_split": "scan_bwd", "k_scan_cluster": "scan_fwd", "k_scan_simple": "scan_fwd",
-          "k_scan_fwd_mfma": "scan_fwd", "k_scan_cluster_bwd": "scan_bwd", "k_scan_bwd_mfma": "scan_bwd", "k_gemm_nn": "gemm_nn",
-          "k_gemm_tn": "gemm_tn", "k_gemm_nt": "gemm_nt"}
-fam_bytes, fam_n = collections.defaultdict(float), collections.Counter()
-def family_of(k):   # (kernel names carry variant suffixes: _ks, _k16, _s, 16_split, ...)
-    if k in FAMILY:
-        return FAMILY[k]
-    for prefix, fam in (("k_scan_cluster_bwd", "scan_bwd"), ("k_scan_cluster", "scan_fwd"), ("k_gemm_nn", "gemm_nn"),
-                        ("k_gemm_tn", "gemm_tn"), ("k_proj_split", "gemm_nn"), ("k_dw_split", "gemm_tn")):
+# per-family HBM bytes per launch for bench.py's roofline.traffic (read + write, FETCH_SIZE x2-corrected, KB -> bytes): the figure
+# of the family's DOMINANT KERNEL in the full run's kernel trace - never a mix of forms (round 5's passes were too short for the fused
+# schedule to engage and described a kernel that was no longer on the hot path: VERDICT r05)
+def family_of(k):   # (kernel names carry variant suffixes: _ks, _k16, _k16f, _k16fs, _s, 16_split, ...)
+    if k.startswith("k_scan_cluster_bwd") or k.startswith("k_scan_bwd"):
+        return "scan_bwd"
+    if k.startswith("k_scan_cluster") or k.startswith("k_scan_"):
+        return "scan_fwd_narrow" if (k.endswith("_s") or k.endswith("k16_s")) else "scan_fwd"
+    for prefix, fam in (("k_gemm_nn", "gemm_nn"), ("k_gemm_tn", "gemm_tn"), ("k_proj_split", "gemm_nn"), ("k_dw_split", "gemm_tn"),
+                        ("k_gemm_nt", "gemm_nt")):
         if k.startswith(prefix):
             return fam
     return None
 
 
-for k in f:
+run_ns = collections.defaultdict(float)         # total time per (short) kernel name in the FULL run (rocprofv3 --stats)
+for r in rows:
+    run_ns[short(r["Name"])] += float(r["TotalDurationNs"])
+dom_of = {}                                     # family -> its kernel with the largest total time in the full run
+for k, ns in run_ns.items():
     fam = family_of(k)
-    if fam and fc[k]:
-        fam_bytes[fam] += (2 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"]) * 1024.0
-        fam_n[fam] += fc[k]
-if fam_n:
+    if fam and ns > run_ns.get(dom_of.get(fam), 0.0):
+        dom_of[fam] = k
+kernel_bytes = {k: (2 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"]) * 1024.0 / fc[k] for k in f if fc[k]}
+if kernel_bytes:
     import subprocess
     sys.path.insert(0, ".")
     import mgr_amd  # noqa: F401
     from mgr_amd._build import source_hash
+    dominant = max((k for k in run_ns if family_of(k)), key=lambda k: run_ns[k])
+    if dominant not in kernel_bytes:
+        sys.exit("summarize_profile: the PMC passes hold no dispatch of %s, the dominant kernel of the full run (they hold %s): "
+                 "NOT writing profiles/pmc_traffic.json - take the passes on the schedule the product runs" % (dominant, sorted(kernel_bytes)))
     try:
         head = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
     except OSError:
@@ -89,9 +97,15 @@ if fam_n:
     # `traffic` only when its own tree hashes the same
     sha_file = "%s/%s_src_sha.txt" % (G, tag)
     src_sha = open(sha_file).read().strip() if os.path.exists(sha_file) else source_hash()
-    json.dump({"tag": tag, "src_sha": src_sha, "head_at_summary": head, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1",
-               "bytes_per_launch": {k: fam_bytes[k] / fam_n[k] for k in fam_n}},
+    json.dump({"tag": tag, "src_sha": src_sha, "head_at_summary": head,
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 8 --warmup 3; per family: the family's dominant kernel of the full run",
+               "dominant_kernel": dominant, "family_kernel": {fam: k for fam, k in dom_of.items() if k in kernel_bytes},
+               "pmc_dispatches": {k: fc[k] for k in kernel_bytes if family_of(k)},
+               "bytes_per_launch": {fam: kernel_bytes[k] for fam, k in dom_of.items() if k in kernel_bytes},
+               "kernel_bytes_per_launch": {k: v for k, v in kernel_bytes.items() if family_of(k)}},
               open("profiles/pmc_traffic.json", "w"), indent=1)
+    out.append("\nDominant kernel of the full run: `%s` (%d PMC dispatches); per family: %s\n" % (
+        dominant, fc[dominant], ", ".join("%s = %s" % (fam, k) for fam, k in sorted(dom_of.items()))))
 s, sc = pmc("SQ_VALU_MFMA_BUSY_CYCLES")
 out.append("\n## SQ counters per kernel (sums over launches)\n")
 out.append("| kernel | launches | MFMA busy / (1024 SIMD x GUI_ACTIVE/8) | WAIT_INST_ANY/WAVE_CYCLES | WAIT_ANY/WAVE_CYCLES | ACTIVE/WAVE_CYCLES | LDS bank conflict cycles |\n|---|---|---|---|---|---|---|")
