@@ -309,7 +309,8 @@ int mgr_stream_wait_resident_word(mgr_ctx* ctx, const unsigned* seq_word, int ti
 /* Counters of the residency waits of this context since it was created (read on the current stream, a 16-byte read-back):
  * out[0] = waits enqueued that have finished, out[1] = those that ran into their timeout (a wait whose launch never came, came too
  * late, or could not become resident while the wait held its stream: each costs its full bound - silently, which is why this exists),
- * out[2] = out[3] = 0. */
+ * out[2], out[3] = diagnostics of the LAST wait that expired: the launch number it was for (0: its word was never filled) and the low
+ * 32 bits of the address of the word it polled (0: a wait for a known number). */
 int mgr_resident_wait_stats(mgr_ctx* ctx, unsigned out[4]);
 /* Persistent launches on different streams are admitted against the chip's workgroup slots; one that would not fit beside the
  * launches still in flight is ordered behind them (co-residency by construction).  Counters: launches so far, and how many of

@@ -711,7 +711,11 @@ __global__ void k_wait_resident(const unsigned* resident, const unsigned* ring, 
     }
   }
   __hip_atomic_fetch_add(counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (expired) __hip_atomic_fetch_add(counters + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (expired) {
+    __hip_atomic_fetch_add(counters + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    counters[2] = seq;                                             // diagnostics of the LAST expired wait: the launch number it was for (0: never
+    counters[3] = (unsigned)reinterpret_cast<uintptr_t>(seq_word); // learnt) and the low 32 bits of the word it polled (0: a known-number wait)
+  }
 }
 constexpr int kWaitCounters = 32;   // words [32, 34) of the context's own status block
 }  // namespace
@@ -745,9 +749,8 @@ int mgr_stream_wait_resident_word(mgr_ctx* c, const unsigned* seq_word, int time
 
 int mgr_resident_wait_stats(mgr_ctx* c, unsigned out[4]) {
   MGR_REQUIRE(c && out, "null argument");
-  MGR_HIP(hipMemcpyAsync(out, c->sticky_status + kWaitCounters, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, mgr_stream(c)));
+  MGR_HIP(hipMemcpyAsync(out, c->sticky_status + kWaitCounters, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, mgr_stream(c)));
   MGR_HIP(hipStreamSynchronize(mgr_stream(c)));
-  out[2] = out[3] = 0;
   return 0;
 }
 

@@ -797,6 +797,8 @@ class Engine:
     _enc_scan_form = _capi.SCAN_FORM_AUTO      # form of the encoder scan launches enqueued NOW (AUTO: the context's tune key 4)
     _fusion_scan_form = _capi.SCAN_FORM_AUTO   # form of the fusion layer's scan launch
     _early_words = None      # seq_words dict of the generator in _early_gen
+    _since_fresh = 0         # pipelined calls since the last one that started the next batch's pass itself (0 in such a call)
+    _gate_log = []           # (diagnostic) per fused step: (step id, kind, the words its two residency waits poll)
     _early_for = None        # the inputs the generator started last was announced for
     _early_gen = None        # _next_encoders_free generator of the batch after next, its first part already enqueued
     _beside_scans = False    # the fusion layer's GEMMs of the step being enqueued run beside encoder scans of the next batch
@@ -1317,7 +1319,11 @@ class Engine:
                 self._enqueue_encoders(True, rand, cur, 0, self.rng_step)
         else:
             cur = have
-            dev.wait(0, ES)          # this step's encoder pass (enqueued by the previous call) must be complete
+            # this step's encoder pass (enqueued by the previous call) must be complete: the event behind its deepest scan - not
+            # everything the encoder stream has been handed since (round 5 waited for the whole stream: in steady state the first part of
+            # the NEXT batch's pass, queued behind it, is done by then anyway; in the first steps of a run it is not, and the second step
+            # started 7 ms late)
+            dev.wait_event(0, self.EV_ENC[self._feat_ring.index(cur)])
         # (not in a call that ran its own encoder pass in line on stream 0: that pass uses the encoder buffers)
         ahead = defer and sch.encoders_run_ahead and (have is not None or own_on_es)
         free_ok = pipelined and ahead and sch.bptt_beside_deepest_scan and sp.fusion and not any_tr_stream_
@@ -1356,6 +1362,7 @@ class Engine:
             #  for would only be enqueued after it, the wait would always run into its bound; such runs share a GPU and use small per-rank
             #  batches anyway)
             two = bool(pipelined and free_gen is not None and prefetch_after_next and sch.encoders_two_ahead)
+            self._since_fresh = 0 if (fresh or free_gen is None) else self._since_fresh + 1
             if fused:
                 # Persistent launches from here on, in host order: fusion scan, BPTT, the next batch's deepest scan and - when the batch
                 # after next is announced - its depth-1 scan.  The encoder scans take the FUSED form (an argument of their launch), and
@@ -1369,7 +1376,11 @@ class Engine:
                 if two and depth > 1:
                     wy = self._new_seq_word()
                     new_words = {0: wy}
-                self._gate_words = (free_words.get(0), wx) if fresh else (wx, wy)
+                # (the call right after a fresh one: the encoder stream is still a phase behind - the deepest scan this call enqueues
+                #  starts milliseconds after the fusion scan is ready, and the wait for it ran into its bound, once per run: no wait)
+                late = (not fresh) and self._since_fresh == 1
+                self._gate_words = (free_words.get(0), wx) if fresh else ((None, wy) if late else (wx, wy))
+                self._gate_log.append((self._step_id, "fresh" if fresh else "steady", self._gate_words))
                 self._wide_ok = bool(sch.fused_wide_tiles)
                 if sch.fusion_scan_fused:
                     self._fusion_scan_form = _capi.SCAN_FORM_FUSED_ANY
@@ -1538,6 +1549,8 @@ class Engine:
             dev.wait_event(ES, self.EV_FPROJ)
         for _ in phases:
             pass
+        dev.stream(ES)
+        dev.record(self.EV_ENC[self._feat_ring.index(nxt)])     # this pass is complete (what the step that consumes it waits for)
         self._prefetched = nxt
         self._prefetched_for = next_inputs
         dev.stream(0)
@@ -1593,6 +1606,8 @@ class Engine:
                     finish(self._resident_gate())
                     if ahead:
                         dev.wait_event(ES, self.EV_PREV)
+        dev.stream(ES)
+        dev.record(self.EV_ENC[self._feat_ring.index(nxt)])
         self._prefetched = nxt
 
     def _bilstm_backward(self, prefix, dY, lddy, Xin, ldx, fin, Hbuf, ldh, dX, lddx, defer_param_grads=False, XinT=None):
