@@ -224,8 +224,12 @@ def test_scan_speed_cannot_be_halved_by_launch_order(device):
 
 
 def test_a_collective_shaped_guest_starts_beside_the_resident_encoder_scans(device):
-    """for N > 1 the RCCL all-reduce kernel is one more guest on stream 0 beside the deepest encoder scan of the
-    next step (408 resident workgroups at config F, two per CU on 152 CUs).  HostComm replaces that kernel with two copies, so
+    """The UNFUSED layout (Schedule.fused_encoder_scans = False, and every launch the fused form does not take): 408 four-wave
+    workgroups resident, two per CU on 152 CUs.  The shipped layout of config F - 208 eight-wave workgroups that hold a CU each + the
+    fusion layer's recurrences on the 48 CUs they leave - has its own guest test: tests/test_gpu_schedule_contract.py::
+    test_a_collective_shaped_guest_starts_beside_the_fused_layout.
+    DESIGN 6 / 8: for N > 1 the RCCL all-reduce kernel is one more guest on stream 0 beside the deepest encoder scan of the
+    next step.  HostComm replaces that kernel with two copies, so
     the claim that it "needs no ledger entry" had no measurement.  Here a guest of its shape - 8 workgroups x 256 threads, 64 KiB
     of LDS each, busy for ~100 us - is launched on another stream the moment the four encoder scans are resident.  It must START
     within 200 us (it finds room on the CUs that hold a single scan workgroup), not when the scan ends, and the scan must still be

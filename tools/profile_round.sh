@@ -6,6 +6,7 @@
 #                                        engages once a step was announced two calls ahead: a 2-step run never shows the shipped kernels)
 #   <tag>_cfg_<C>_bench.json, <tag>_cfg_<C>_kernel_stats.csv   the other BASELINE configurations (S, S_ref, A_ref, E): untruncated bench
 #                                        line + rocprof kernel stats each
+#   <tag>_cfg_<C>_b64_bench.json         the all-trainable configurations (E, S_ref, A_ref) once more at B = 64 (a batch that fills the chip)
 #   <tag>_decode.json, <tag>_decode_kernel_stats.csv          BASELINE configs[4]: tools/decode_bench.py + its kernel stats (k_beam, k_frame_argmax)
 #   <tag>_fit.txt, <tag>_dp2_host.json   fit_generator with host batches; bench.py --gpus 2 --comm host
 TAG=${1:-r01}
@@ -32,6 +33,10 @@ if [ "$2" != "quick" ]; then
     cd /tmp; rm -rf $R/gpurun_out/${TAG}_cfgprof
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_cfgprof -- python3 $R/bench.py --config $C --steps 5 --warmup 2 --no-cpu --no-parity --no-f32-leg > /dev/null 2>&1
     cp $R/gpurun_out/${TAG}_cfgprof/*/*_kernel_stats.csv $R/gpurun_out/${TAG}_cfg_${C}_kernel_stats.csv
+  done
+  # the all-trainable configurations at a batch that fills the chip (B = 64: 4 batch groups x 2 directions of 32 / 19 clusters' workgroups)
+  for C in E S_ref A_ref; do
+    cd $R && timeout 300 python bench.py --config $C --batch 64 --steps 10 --no-cpu --no-parity 2> /dev/null | tail -1 > gpurun_out/${TAG}_cfg_${C}_b64_bench.json
   done
   cd $R && timeout 600 python tools/decode_bench.py > gpurun_out/${TAG}_decode.json 2> gpurun_out/${TAG}_decode.err
   cd /tmp; rm -rf $R/gpurun_out/${TAG}_cfgprof

@@ -120,7 +120,7 @@ for k in sorted(s, key=lambda k: -s[k]["SQ_VALU_MFMA_BUSY_CYCLES"]):
 import glob
 extra = []
 for f in sorted(glob.glob("%s/%s_cfg_*_bench.json" % (G, tag))):
-    cfg = os.path.basename(f)[len(tag) + 5:-len("_bench.json")]
+    cfg = os.path.basename(f)[len(tag) + 5:-len("_bench.json")]    # ("E", "S_ref", ... and "E_b64", ...: the same network at B = 64)
     try:
         d = json.loads(open(f).read())
     except ValueError:
@@ -133,7 +133,7 @@ for f in sorted(glob.glob("%s/%s_cfg_*_bench.json" % (G, tag))):
         rr = list(csv.DictReader(open(ks)))[:3]
         top = "; ".join("%s %.2f ms avg x %s" % (short(r["Name"]), float(r["AverageNs"]) / 1e6, r["Calls"]) for r in rr)
     roof = d.get("roofline") or {}
-    extra.append("| %s | %.3f | %.0f | %s %.3f | %s | %s |" % (cfg, d["ms_per_step"], d["value"], roof.get("kernel"), roof.get("frac") or 0.0,
+    extra.append("| %s (B = %s) | %.3f | %.0f | %s %.3f | %s | %s |" % (cfg, d["config"].get("per_gpu_batch"), d["ms_per_step"], d["value"], roof.get("kernel"), roof.get("frac") or 0.0,
                                                        (d.get("ctc_loss_parity") or {}).get("rel_delta"), top))
 if extra:
     out.append("\n## Other BASELINE configurations (bench.py --config, 10 steps; parity cases, not the headline)\n")
