@@ -249,6 +249,9 @@ int mgr_abi_struct_sizes(unsigned out[4]);
  * key 14: K-split scan step: 0 = recurrent product on the f16 matrix pipe with every f32 operand split into an f16 (hi, lo) pair and
  *        f32 accumulation (22+ significant bits per operand; lstm_cluster.hip cluster_run_k16), 1 = v_mfma_f32_16x16x4_f32.
  * key 15: 1 = the transposed-input projection / parameter-gradient GEMMs keep their f32 MFMA kernels whatever bound the caller states.
+ * key 18: 1 = mgr_ctc_loss_grad runs one sample per workgroup (rounds 1 - 5); 0 = two (from B = 2 on: the alpha / beta chains of a
+ *         workgroup's two samples on its four SIMDs - 32 workgroups for config F's 64 samples, which the 48 CUs beside fused encoder scans
+ *         hold one per CU); the same bits.
  * key 17: 1 = the two halves of a FUSED scan workgroup each fetch and verify the whole h image of the step themselves (round 5's
  *         k_scan_cluster_k16f); 0 = they share ONE gather through LDS (k_scan_cluster_k16fs: half the L2 traffic); the same bits.
  * key 16: 1 = the BPTT of narrow layers (H <= 128) launched next runs BESIDE persistent scans of another stream: it takes the form that

@@ -69,33 +69,22 @@ __host__ __device__ inline size_t ctc_ts(int To) { return ((size_t)To + 24 + 3) 
 // alpha / beta rows, two time steps per block: element (t, state 2p + e) at  (t >> 1) * 2 S2 + 4 p + 2 (t & 1) + e
 __device__ __forceinline__ size_t ab_off(int t, int S2) { return (size_t)(t >> 1) * (2 * S2) + 2 * (t & 1); }
 
-template <int PPL>
-__global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const int32_t* __restrict__ labels,
-                                             const int32_t* __restrict__ input_len,
-                                             const int32_t* __restrict__ label_len, int B, int T, int C, int Lmax,
-                                             int skip, int blank, float eps, float gscale, float* __restrict__ loss,
-                                             float* __restrict__ dLogits, float* __restrict__ LY,
-                                             float* __restrict__ AL, float* __restrict__ BE) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [256][C+1] occupancy rows, then labels
-  constexpr int CH = Chunk<PPL>::CH;
-  const int b = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int To = T - skip;
-  int Tp = input_len[b];
-  Tp = Tp < 0 ? 0 : (Tp > To ? To : Tp);
-  int L = label_len[b];
-  L = L < 0 ? 0 : (L > Lmax ? Lmax : L);
-  const int S2 = 2 * (Lmax + 1);
-  const size_t TS = ctc_ts(To);
-  float* LYTb = LY + (size_t)b * 2 * C * TS;       // [C][TS]: y(t, c) at c * TS + t + 3
-  float* LYRb = LYTb + (size_t)C * TS;             // [C][TS]: y(Tp - 1 - r, c) at c * TS + r
-  float* ALb = AL + (size_t)b * (To + 1) * S2;
-  float* BEb = BE + (size_t)b * (To + 1) * S2;
-  int* s_lab = reinterpret_cast<int*>(smem + 256 * (C + 1));
-  float* s_logp = reinterpret_cast<float*>(s_lab + Lmax + 1);
+// One sample's three phases as functions (round 6): the kernel runs ONE or TWO samples per workgroup.
+// Per-sample state of a workgroup: which sample, its clipped lengths, its slices of the workspace, its labels in LDS.
+struct CtcSample {
+  int b, Tp, L;
+  float *LYTb, *LYRb, *ALb, *BEb;
+  int* s_lab;
+  float* s_logp;
+};
 
+// ---- phase 0 (all 256 threads): labels into LDS; emissions log y(t,c) = log(P+eps) - log(sum_c (P+eps)), class-major, forward and
+// reversed in time
+__device__ __forceinline__ void ctc_phase0(const CtcSample& cs_, int tid, const float* __restrict__ P, const int32_t* __restrict__ labels, int T,
+                                           int C, int Lmax, int skip, float eps, size_t TS) {
+  const int b = cs_.b, Tp = cs_.Tp, L = cs_.L;
+  float *LYTb = cs_.LYTb, *LYRb = cs_.LYRb;
+  int* s_lab = cs_.s_lab;
   for (int i = tid; i < Lmax; i += 256) {
     int v = (i < L) ? labels[(size_t)b * Lmax + i] : -1;
     v = v < 0 ? 0 : (v >= C ? C - 1 : v);
@@ -121,10 +110,18 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
     LYTb[(size_t)c * TS + Tp + 3 + k] = 0.f;
     LYRb[(size_t)c * TS + Tp + k] = 0.f;
   }
-  __syncthreads();
+}
 
-  // ---- phase 1: alpha (wave 0) / beta (wave 1) --------------------------------------------------------
-  if (wave < 2 && Tp > 0) {
+// ---- phase 1 (one wave per role): role 0 runs alpha forward in time, role 1 beta backward
+template <int PPL>
+__device__ __forceinline__ void ctc_phase1(const CtcSample& cs_, int role, int lane, int blank, int Lmax, int S2, size_t TS,
+                                           float* __restrict__ loss) {
+  constexpr int CH = Chunk<PPL>::CH;
+  const int b = cs_.b, Tp = cs_.Tp, L = cs_.L;
+  float *LYTb = cs_.LYTb, *LYRb = cs_.LYRb, *ALb = cs_.ALb, *BEb = cs_.BEb;
+  int* s_lab = cs_.s_lab;
+  float* s_logp = cs_.s_logp;
+  if (role < 2 && Tp > 0) {
     int lab[PPL];
     bool vl[PPL], vb[PPL], cs[PPL];
 #pragma unroll
@@ -145,7 +142,7 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
         cs[j] = vl[j] && p >= 1 && pv && lab[j] != blank && lab[j] != pl;
       }
     }
-    if (wave == 0) {
+    if (role == 0) {
       float ab[PPL], al[PPL];
       float hb[PPL], hl[PPL];   // the even step of the pair in flight (rows are stored two steps at a time)
 #pragma unroll
@@ -334,13 +331,15 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
       }
     }
   }
-  if (Tp == 0 && tid == 0) {
-    loss[b] = __builtin_huge_valf();
-    *s_logp = kNegInf;
-  }
-  __syncthreads();
-  if (dLogits == nullptr) return;
+}
 
+// ---- phase 2 (all 256 threads): gradient w.r.t. the Dense logits
+__device__ __forceinline__ void ctc_phase2(const CtcSample& cs_, int tid, float* smem, const float* __restrict__ P, int T, int C, int skip,
+                                           int blank, float eps, float gscale, int S2, float* __restrict__ dLogits) {
+  const int b = cs_.b, Tp = cs_.Tp, L = cs_.L;
+  float *ALb = cs_.ALb, *BEb = cs_.BEb;
+  int* s_lab = cs_.s_lab;
+  float* s_logp = cs_.s_logp;
   // ---- phase 2: gradient ------------------------------------------------------------------------------
   const float logp = *s_logp;
   float* occ = smem + (size_t)tid * (C + 1);
@@ -390,6 +389,71 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
   }
 }
 
+// SPW = samples per workgroup.  1: wave 0 = alpha, wave 1 = beta of the workgroup's sample (waves 2, 3 idle in phase 1).  2 (round 6):
+// waves 0, 1 run the chains of sample 2 j, waves 2, 3 those of sample 2 j + 1 - one chain per SIMD.  In the training step the kernel runs
+// on the 48 CUs the fused encoder scans leave: 64 one-sample workgroups there put two on 16 CUs, whose alpha (beta) waves then SHARE a
+// SIMD, and every chain of the launch waits for those (0.97 ms in the step for 0.55 alone); 32 two-sample workgroups have a CU each.
+// Phases 0 and 2 run the workgroup's samples one after the other (microseconds against the chains' half millisecond).
+template <int PPL, int SPW>
+__global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const int32_t* __restrict__ labels,
+                                             const int32_t* __restrict__ input_len,
+                                             const int32_t* __restrict__ label_len, int B, int T, int C, int Lmax,
+                                             int skip, int blank, float eps, float gscale, float* __restrict__ loss,
+                                             float* __restrict__ dLogits, float* __restrict__ LY,
+                                             float* __restrict__ AL, float* __restrict__ BE) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [256][C+1] occupancy rows, then SPW label rows, then SPW words
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int To = T - skip;
+  const int S2 = 2 * (Lmax + 1);
+  const size_t TS = ctc_ts(To);
+  auto sample = [&](int si) {
+    CtcSample s_;
+    const int b = (int)blockIdx.x * SPW + si;
+    s_.b = b < B ? b : -1;
+    const int bc = b < B ? b : B - 1;
+    int Tp = input_len[bc];
+    s_.Tp = Tp < 0 ? 0 : (Tp > To ? To : Tp);
+    int L = label_len[bc];
+    s_.L = L < 0 ? 0 : (L > Lmax ? Lmax : L);
+    s_.LYTb = LY + (size_t)bc * 2 * C * TS;           // [C][TS]: y(t, c) at c * TS + t + 3
+    s_.LYRb = s_.LYTb + (size_t)C * TS;               // [C][TS]: y(Tp - 1 - r, c) at c * TS + r
+    s_.ALb = AL + (size_t)bc * (To + 1) * S2;
+    s_.BEb = BE + (size_t)bc * (To + 1) * S2;
+    s_.s_lab = reinterpret_cast<int*>(smem + 256 * (C + 1)) + si * (Lmax + 1);
+    s_.s_logp = reinterpret_cast<float*>(reinterpret_cast<int*>(smem + 256 * (C + 1)) + SPW * (Lmax + 1)) + si;
+    return s_;
+  };
+#pragma unroll
+  for (int si = 0; si < SPW; ++si) {
+    const CtcSample s_ = sample(si);
+    if (s_.b >= 0) ctc_phase0(s_, tid, P, labels, T, C, Lmax, skip, eps, TS);
+  }
+  __syncthreads();
+  {
+    const int si = SPW == 2 ? wave >> 1 : 0, role = SPW == 2 ? (wave & 1) : wave;
+    const CtcSample s_ = sample(si);
+    if (s_.b >= 0) ctc_phase1<PPL>(s_, role, lane, blank, Lmax, S2, TS, loss);
+  }
+#pragma unroll
+  for (int si = 0; si < SPW; ++si) {
+    const CtcSample s_ = sample(si);
+    if (s_.b >= 0 && s_.Tp == 0 && tid == 0) {
+      loss[s_.b] = __builtin_huge_valf();
+      *s_.s_logp = kNegInf;
+    }
+  }
+  __syncthreads();
+  if (dLogits == nullptr) return;
+#pragma unroll
+  for (int si = 0; si < SPW; ++si) {
+    const CtcSample s_ = sample(si);
+    if (s_.b >= 0) ctc_phase2(s_, tid, smem, P, T, C, skip, blank, eps, gscale, S2, dLogits);
+    if (SPW == 2) __syncthreads();   // (the occupancy rows of the next sample reuse the same LDS)
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -415,14 +479,22 @@ int mgr_ctc_loss_grad(mgr_ctx* c, const float* P, const int32_t* labels, const i
   float* LY = reinterpret_cast<float*>(ws);
   float* AL = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ly);
   float* BE = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ly + ab);
-  size_t lds = (size_t)256 * (C + 1) * sizeof(float) + (size_t)(Lmax + 1) * sizeof(int) + 16;
+  // two samples per workgroup (one chain per SIMD) from B = 2 on; tune key 18 = 1: one sample per workgroup (rounds 1 - 5)
+  const int spw = (B >= 2 && c->tune[18] == 0) ? 2 : 1;
+  size_t lds = (size_t)256 * (C + 1) * sizeof(float) + (size_t)spw * (Lmax + 1) * sizeof(int) + 16;
   MGR_REQUIRE(lds <= 160 * 1024, "C=%d too large for the LDS occupancy tile", C);
   int npairs = Lmax + 1;
   int ppl = (npairs + 63) / 64;
   mgr_prof_begin(c, MGR_K_CTC);
-#define MGR_CTC_LAUNCH(N)                                                                                          \
-  hipLaunchKernelGGL(k_ctc<N>, dim3(B), dim3(256), lds, mgr_stream(c), P, labels, input_len, label_len, B, T, C, \
-                     Lmax, skip, blank, eps, gscale, loss, dLogits, LY, AL, BE)
+#define MGR_CTC_LAUNCH(N)                                                                                                            \
+  do {                                                                                                                               \
+    if (spw == 2)                                                                                                                    \
+      hipLaunchKernelGGL((k_ctc<N, 2>), dim3((B + 1) / 2), dim3(256), lds, mgr_stream(c), P, labels, input_len, label_len, B, T, C,  \
+                         Lmax, skip, blank, eps, gscale, loss, dLogits, LY, AL, BE);                                                 \
+    else                                                                                                                             \
+      hipLaunchKernelGGL((k_ctc<N, 1>), dim3(B), dim3(256), lds, mgr_stream(c), P, labels, input_len, label_len, B, T, C, Lmax,      \
+                         skip, blank, eps, gscale, loss, dLogits, LY, AL, BE);                                                       \
+  } while (0)
   switch (ppl) {
     case 1: MGR_CTC_LAUNCH(1); break;
     case 2: MGR_CTC_LAUNCH(2); break;

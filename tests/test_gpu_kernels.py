@@ -64,6 +64,14 @@ def test_ctc_random(device, B, T, Cn, Lmax, lo, hi):
     assert rel_err(dz, ref_dz) < 5e-4
     loss2, _ = _run_ctc(device, P, labels, il, ll, need_grad=False)
     assert np.array_equal(loss, loss2)
+    # round 6: two samples per workgroup (one alpha / beta chain per SIMD; an odd batch leaves the last workgroup one sample) - tune key
+    # 18 = 1 brings the one-sample workgroups back: the same arithmetic per sample, the same bits
+    device.call("mgr_tune", 18, 1)
+    try:
+        loss1, dz1 = _run_ctc(device, P, labels, il, ll)
+    finally:
+        device.call("mgr_tune", 18, 0)
+    assert np.array_equal(loss, loss1) and np.array_equal(dz, dz1)
 
 
 def test_ctc_empty_label_sequence(device):
