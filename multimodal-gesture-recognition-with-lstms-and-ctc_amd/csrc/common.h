@@ -58,6 +58,7 @@ struct mgr_ctx {
   };
   const void* frozen_w[MGR_MAX_FROZEN];
   PlaneEntry planes[MGR_MAX_FROZEN];
+  unsigned planes_evict, frozen_evict;   // round-robin victims when a table is full
 };
 
 int mgr_fail(int code, const char* fmt, ...);

@@ -673,7 +673,10 @@ int mgr_lstm_input_proj_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const f
     hipLaunchKernelGGL(k_wmax, dim3((int)((n4 + 255) / 256 < 256 ? (n4 + 255) / 256 : 256)), dim3(256), 0, s, Wp, n4, words);
     const size_t n = (size_t)(F + 1) * Hp;
     hipLaunchKernelGGL(k_wplanes, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, Wp, WSp, F, H, Hp, words);
-    if (frozen && free_slot >= 0) c->planes[free_slot] = mgr_ctx::PlaneEntry{Wp, ws, F, H};
+    if (frozen) {   // (a full table forgets its oldest entry: forgetting is always safe)
+      if (free_slot < 0) free_slot = (int)(c->planes_evict++ % MGR_MAX_FROZEN);
+      c->planes[free_slot] = mgr_ctx::PlaneEntry{Wp, ws, F, H};
+    }
   }
   // 128-unit tiles (8 waves, one workgroup per CU) where they waste little of their width; tune key 12: 1 = always 64, 2 = always 128
   const int waste128 = (H + 127) / 128 * 128 - H, waste64 = (H + 63) / 64 * 64 - H;
@@ -769,7 +772,12 @@ int mgr_weight_planes_cache(mgr_ctx* c, const float* Wp, int frozen) {
       c->frozen_w[i] = Wp;
       return 0;
     }
-  return 0;   // (table full: the weights are simply not cached)
+  // table full (engines that were never closed): the oldest promise is forgotten - its weights are simply rebuilt per call again
+  const int victim = (int)(c->frozen_evict++ % MGR_MAX_FROZEN);
+  for (int i = 0; i < MGR_MAX_FROZEN; ++i)
+    if (c->planes[i].Wp == c->frozen_w[victim]) c->planes[i] = mgr_ctx::PlaneEntry{nullptr, nullptr, 0, 0};
+  c->frozen_w[victim] = Wp;
+  return 0;
 }
 
 int mgr_transpose_bt_split(mgr_ctx* c, const float* X, int ldx, float* XS, int ldt, int B, int T, int F) {
