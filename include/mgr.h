@@ -214,7 +214,13 @@ enum { MGR_BPTT_FORM_AUTO = 0, MGR_BPTT_FORM_TRIMMED = 1, MGR_BPTT_FORM_YIELDING
        /* round 6, narrow layers (16 < H <= 128) with an exchange: 8-wave workgroups that run TWO unit groups of their cluster, a CU each
         * (H = 100: 32 workgroups instead of 56), with the trimmed step / the direct gather inside; the same bits as every other form.  A
         * launch that does not qualify takes the trimmed / direct form. */
-       MGR_BPTT_FORM_FUSED = 4, MGR_BPTT_FORM_FUSED_DIRECT = 5 };
+       MGR_BPTT_FORM_FUSED = 4, MGR_BPTT_FORM_FUSED_DIRECT = 5,
+       /* round 6, the directions of ONE narrow layer (same shape, H in {32, 64, 100}): one 8-wave workgroup per (direction, 16-sample
+        * group) that holds the whole recurrent matrix as f16 (hi, lo) fragments and keeps dh in registers - NO inter-CU exchange, so its
+        * step does not depend on what the rest of the chip does to the L2 / fabric (lstm_cu_bwd.hip).  Same arithmetic as the multi-CU
+        * forms with another summation order: equal to them to rounding, not bit for bit.  A call that does not qualify takes the
+        * trimmed multi-CU form.  mgr_scan_bwd_job.dzmax is filled by a reduction pass behind the kernel. */
+       MGR_BPTT_FORM_SINGLE_CU = 6 };
 #define MGR_SEQ_NONE 0xFFFFFFFFu
 typedef struct mgr_scan_launch_opts {
   unsigned struct_size;
@@ -249,6 +255,7 @@ int mgr_abi_struct_sizes(unsigned out[4]);
  * key 14: K-split scan step: 0 = recurrent product on the f16 matrix pipe with every f32 operand split into an f16 (hi, lo) pair and
  *        f32 accumulation (22+ significant bits per operand; lstm_cluster.hip cluster_run_k16), 1 = v_mfma_f32_16x16x4_f32.
  * key 15: 1 = the transposed-input projection / parameter-gradient GEMMs keep their f32 MFMA kernels whatever bound the caller states.
+ * key 19: 1 = mgr_lstm_scan_bwd_multi[_ex] with form AUTO takes MGR_BPTT_FORM_SINGLE_CU where it qualifies (A/B of whole runs).
  * key 18: 1 = mgr_ctc_loss_grad runs one sample per workgroup (rounds 1 - 5); 0 = two (from B = 2 on: the alpha / beta chains of a
  *         workgroup's two samples on its four SIMDs - 32 workgroups for config F's 64 samples, which the 48 CUs beside fused encoder scans
  *         hold one per CU); the same bits.

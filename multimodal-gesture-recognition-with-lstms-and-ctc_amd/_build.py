@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, "libmgr.so")
 OBJDIR = os.path.join(HERE, "build")
 MGR_H = os.path.join(HERE, "..", "include", "mgr.h")
 SOURCES = ["ctx.hip", "elementwise.hip", "ctc.hip", "dense.hip", "gemm.hip", "gemm_split.hip", "lstm_simple.hip", "lstm_mfma.hip",
-           "lstm_cluster.hip", "lstm_cluster_bwd.hip", "lstm.hip", "comm.hip", "beam.hip", "skeletal.hip"]
+           "lstm_cluster.hip", "lstm_cluster_bwd.hip", "lstm_cu_bwd.hip", "lstm.hip", "comm.hip", "beam.hip", "skeletal.hip"]
 ARCH = "gfx950"
 
 

@@ -147,7 +147,7 @@ class ScanLaunchOpts(C.Structure):
 
 # enums of include/mgr.h (mgr_scan_launch_opts.form)
 SCAN_FORM_AUTO, SCAN_FORM_PLAIN, SCAN_FORM_PAIR, SCAN_FORM_FUSED, SCAN_FORM_FUSED_ANY = range(5)
-BPTT_FORM_AUTO, BPTT_FORM_TRIMMED, BPTT_FORM_YIELDING, BPTT_FORM_DIRECT, BPTT_FORM_FUSED, BPTT_FORM_FUSED_DIRECT = range(6)
+BPTT_FORM_AUTO, BPTT_FORM_TRIMMED, BPTT_FORM_YIELDING, BPTT_FORM_DIRECT, BPTT_FORM_FUSED, BPTT_FORM_FUSED_DIRECT, BPTT_FORM_SINGLE_CU = range(7)
 SEQ_NONE = 0xFFFFFFFF
 ABI_REVISION = 6
 

@@ -12,6 +12,7 @@
 int mgr_scan_fwd_simple(mgr_ctx*, const float*, const float*, float*, int, const float*, int, float*, float*, int, int, int, int);
 int mgr_scan_bwd_simple(mgr_ctx*, const float*, int, const float*, const float*, const float*, float*, int, int, int, int);
 int mgr_scan_bwd_mfma_multi(mgr_ctx*, int, const mgr_scan_bwd_job*);
+int mgr_scan_bwd_cu16_multi(mgr_ctx*, int, const mgr_scan_bwd_job*);   // lstm_cu_bwd.hip: one CU per (direction, 16-sample group), split-f16
 
 namespace {
 
@@ -465,11 +466,12 @@ int mgr_lstm_scan_bwd_multi_ex(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jo
   int form;
   unsigned* seq_out;
   read_opts(opts, &form, &seq_out);
-  MGR_REQUIRE(form >= MGR_BPTT_FORM_AUTO && form <= MGR_BPTT_FORM_FUSED_DIRECT, "unknown BPTT form %d", form);
+  MGR_REQUIRE(form >= MGR_BPTT_FORM_AUTO && form <= MGR_BPTT_FORM_SINGLE_CU, "unknown BPTT form %d", form);
   if (seq_out) *seq_out = MGR_SEQ_NONE;
   const bool want_fused = form == MGR_BPTT_FORM_FUSED || form == MGR_BPTT_FORM_FUSED_DIRECT;
   // 0 trimmed, 1 yielding, 2 direct gather (the fused forms: the trimmed step / the direct gather)
-  const int key16 = form == MGR_BPTT_FORM_AUTO ? c->tune[16] : form == MGR_BPTT_FORM_FUSED ? 0 : form == MGR_BPTT_FORM_FUSED_DIRECT ? 2 : form - 1;
+  const int key16 = form == MGR_BPTT_FORM_AUTO ? c->tune[16]
+                    : (form == MGR_BPTT_FORM_FUSED || form == MGR_BPTT_FORM_SINGLE_CU) ? 0 : form == MGR_BPTT_FORM_FUSED_DIRECT ? 2 : form - 1;
   MGR_REQUIRE(ws && ws_bytes >= mgr_lstm_scan_bwd_multi_ws_bytes(njobs, jobs), "workspace too small");
   for (int i = 0; i < njobs; ++i) {
     const mgr_scan_bwd_job& j = jobs[i];
@@ -480,6 +482,21 @@ int mgr_lstm_scan_bwd_multi_ex(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jo
   int r = mgr_prof_begin(c, MGR_K_SCAN_BWD);
   if (r) return r;
   const int path = c->tune[MGR_TUNE_SCAN_PATH];
+  // The single-CU split-f16 form (lstm_cu_bwd.hip): asked for by the caller (or tune key 19 = 1), taken when the jobs are the directions
+  // of ONE narrow layer (same shape, 16 < H <= 128) and the f16 matrix pipe is in use; no inter-CU exchange, no ledger entry
+  if ((form == MGR_BPTT_FORM_SINGLE_CU || (form == MGR_BPTT_FORM_AUTO && c->tune[19] == 1)) && c->tune[14] == 0 && (path == 0 || path == 3)) {
+    r = mgr_scan_bwd_cu16_multi(c, njobs, jobs);
+    if (r < 0) return r;
+    if (r == 1) {
+      for (int i = 0; i < njobs; ++i) {   // (the row maxima of dZ: a reduction pass, as behind every kernel that does not keep them itself)
+        const mgr_scan_bwd_job& j = jobs[i];
+        if (!j.dzmax) continue;
+        r = mgr_rowmax_bt(c, j.dZ, 4 * j.H, j.T, j.B, j.dzmax);
+        if (r) return r;
+      }
+      return mgr_prof_end(c, MGR_K_SCAN_BWD);
+    }
+  }
   char* w = reinterpret_cast<char*>(ws);
   char* base = w;
   unsigned* status = reinterpret_cast<unsigned*>(w);

@@ -120,6 +120,9 @@ class Schedule:
                         steady-state call from there on (the next batch's pass follows at once, fused, its scans paired with this step's
                         recurrences through their launch numbers); round 5: in line on stream 0 in the plain forms, the next pass behind
                         a stream-wide wait, the fused forms only from the third step of a run on
+    bptt_single_cu      (round 6; measured, not the default) narrow trainable layers (H in {32, 64, 100}) run their BPTT on ONE CU per
+                        (direction, 16-sample group) without an inter-CU exchange (MGR_BPTT_FORM_SINGLE_CU, lstm_cu_bwd.hip) - in every
+                        schedule (its results equal the multi-CU forms' to rounding, not bit for bit)
     split_rows          (round 5) the transposed copies are written in the split row format (f16 hi / lo pairs) and the wide products
                         run as loader / matrix pipelines on pre-split operands (gemm_split.hip); False: f32 rows, converted by
                         every product that reads them (round 4's kernels)
@@ -133,7 +136,9 @@ class Schedule:
                  transposed_inputs=True, bptt_beside_deepest_scan=True, split_rows=True, encoders_two_ahead=True,
                  deepest_scan_after_fusion_proj=True, depth1_proj_ahead=True, bptt_yields_beside_scans=True,
                  fused_encoder_scans=True, fused_wide_tiles=True, bptt_direct_when_alone=False, fusion_scan_fused=True,
-                 bptt_fused=False, chain_stream_priority=0, param_grads_two_streams=False, first_pass_on_encoder_stream=True):
+                 bptt_fused=False, chain_stream_priority=0, param_grads_two_streams=False, first_pass_on_encoder_stream=True,
+                 bptt_single_cu=False):
+        self.bptt_single_cu = bool(bptt_single_cu)
         self.first_pass_on_encoder_stream = bool(first_pass_on_encoder_stream)
         self.param_grads_two_streams = bool(param_grads_two_streams)
         self.chain_stream_priority = int(chain_stream_priority)
@@ -1639,6 +1644,8 @@ class Engine:
             form = _capi.BPTT_FORM_DIRECT if direct else _capi.BPTT_FORM_YIELDING
             if self._gate_words[0] is not None and self.schedule.bptt_fused:     # (a step of the fused schedule)
                 form = _capi.BPTT_FORM_FUSED_DIRECT if direct else _capi.BPTT_FORM_FUSED
+        if self.schedule.bptt_single_cu and jobs[0]["H"] in (32, 64, 100):
+            form = _capi.BPTT_FORM_SINGLE_CU       # (whatever the schedule puts beside it: the choice must not depend on the layout)
         opts = _capi.make_launch_opts(form, 0)
         _capi.check(self.lib.mgr_lstm_scan_bwd_multi_ex(dev.ctx, len(jobs), arr, self._ws_bwd_multi.ptr, self._ws_bwd_multi.nbytes,
                                                         C.byref(opts)))

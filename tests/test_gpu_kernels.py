@@ -473,6 +473,19 @@ def test_bwd_multi_matches_oracle(device, B, T, H, path, f32_mfma):
                 assert seq.value == n0.value          # (the launch number the call reports is the context's newest)
                 for (dz0, zm0), o, j in zip(lean, outs, jobs):
                     assert np.array_equal(o[2].download(), dz0) and np.array_equal(j["dzmax"].download(), zm0), form
+            # the SINGLE-CU form (lstm_cu_bwd.hip: one workgroup per (direction, 16-sample group), no inter-CU exchange): the same
+            # arithmetic in another summation order - equal to the multi-CU forms to rounding, its row maxima exact for ITS dZ
+            if H in (32, 64, 100):
+                for o in outs:
+                    o[2].zero()
+                seq = ctypes.c_uint(0)
+                opts = _capi.make_launch_opts(_capi.BPTT_FORM_SINGLE_CU, ctypes.addressof(seq))
+                _capi.check(dev.lib.mgr_lstm_scan_bwd_multi_ex(dev.ctx, 2, arr, ws.ptr, ws.nbytes, ctypes.byref(opts)))
+                assert seq.value == _capi.SEQ_NONE          # (no exchange: nothing enters the residency ledger)
+                for (dz0, zm0), o, j in zip(lean, outs, jobs):
+                    dz1 = o[2].download()
+                    assert np.isfinite(dz1).all() and rel_err(dz1, dz0) < 2e-5, rel_err(dz1, dz0)
+                    assert np.array_equal(j["dzmax"].download().view(np.float32), np.abs(dz1).max(axis=1))
     finally:
         dev.call("mgr_tune", 16, 0)
         dev.call("mgr_tune", 14, 0)
