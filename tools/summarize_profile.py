@@ -40,6 +40,10 @@ def pmc(name):
     seen = set()
     for r in csv.DictReader(open(path)):
         k = short(r["Kernel_Name"])
+        if k.startswith("k_scan_cluster_k16f"):
+            # (the fused scan kernel runs the encoder depths - 208 workgroups - AND, since round 6, the fusion layer's own scan - 32: two
+            #  different launches under one name; a per-launch average over both would describe neither)
+            k += "@%d" % (int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])))
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if (r["Dispatch_Id"]) not in seen:
             seen.add(r["Dispatch_Id"])
@@ -63,6 +67,8 @@ def family_of(k):   # (kernel names carry variant suffixes: _ks, _k16, _k16f, _k
     if k.startswith("k_scan_cluster_bwd") or k.startswith("k_scan_bwd"):
         return "scan_bwd"
     if k.startswith("k_scan_cluster") or k.startswith("k_scan_"):
+        if "@" in k:
+            return "scan_fwd" if int(k.split("@")[1]) > 64 else "scan_fwd_narrow"
         return "scan_fwd_narrow" if (k.endswith("_s") or k.endswith("k16_s")) else "scan_fwd"
     for prefix, fam in (("k_gemm_nn", "gemm_nn"), ("k_gemm_tn", "gemm_tn"), ("k_proj_split", "gemm_nn"), ("k_dw_split", "gemm_tn"),
                         ("k_gemm_nt", "gemm_nt")):
@@ -80,13 +86,20 @@ for k, ns in run_ns.items():
     if fam and ns > run_ns.get(dom_of.get(fam), 0.0):
         dom_of[fam] = k
 kernel_bytes = {k: (2 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"]) * 1024.0 / fc[k] for k in f if fc[k]}
+# a family's dominant kernel of the full run (names without a grid) -> its PMC entry: the plain name, or the name @ its largest grid
+pmc_of = {}
+for fam, k in list(dom_of.items()):
+    cands = [q for q in kernel_bytes if q == k or q.startswith(k + "@")]
+    cands = [q for q in cands if family_of(q) == fam] or cands
+    if cands:
+        pmc_of[fam] = max(cands, key=lambda q: int(q.split("@")[1]) if "@" in q else 0)
 if kernel_bytes:
     import subprocess
     sys.path.insert(0, ".")
     import mgr_amd  # noqa: F401
     from mgr_amd._build import source_hash
     dominant = max((k for k in run_ns if family_of(k)), key=lambda k: run_ns[k])
-    if dominant not in kernel_bytes:
+    if not any(q == dominant or q.startswith(dominant + "@") for q in kernel_bytes):
         sys.exit("summarize_profile: the PMC passes hold no dispatch of %s, the dominant kernel of the full run (they hold %s): "
                  "NOT writing profiles/pmc_traffic.json - take the passes on the schedule the product runs" % (dominant, sorted(kernel_bytes)))
     try:
@@ -99,13 +112,13 @@ if kernel_bytes:
     src_sha = open(sha_file).read().strip() if os.path.exists(sha_file) else source_hash()
     json.dump({"tag": tag, "src_sha": src_sha, "head_at_summary": head,
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 8 --warmup 3; per family: the family's dominant kernel of the full run",
-               "dominant_kernel": dominant, "family_kernel": {fam: k for fam, k in dom_of.items() if k in kernel_bytes},
+               "dominant_kernel": dominant, "family_kernel": dict(pmc_of),
                "pmc_dispatches": {k: fc[k] for k in kernel_bytes if family_of(k)},
-               "bytes_per_launch": {fam: kernel_bytes[k] for fam, k in dom_of.items() if k in kernel_bytes},
+               "bytes_per_launch": {fam: kernel_bytes[q] for fam, q in pmc_of.items()},
                "kernel_bytes_per_launch": {k: v for k, v in kernel_bytes.items() if family_of(k)}},
               open("profiles/pmc_traffic.json", "w"), indent=1)
-    out.append("\nDominant kernel of the full run: `%s` (%d PMC dispatches); per family: %s\n" % (
-        dominant, fc[dominant], ", ".join("%s = %s" % (fam, k) for fam, k in sorted(dom_of.items()))))
+    out.append("\nDominant kernel of the full run: `%s`; PMC entry per family (name @ workgroups where one kernel runs two kinds of launch): %s\n" % (
+        dominant, ", ".join("%s = %s (%d dispatches)" % (fam, q, fc[q]) for fam, q in sorted(pmc_of.items()))))
 s, sc = pmc("SQ_VALU_MFMA_BUSY_CYCLES")
 out.append("\n## SQ counters per kernel (sums over launches)\n")
 out.append("| kernel | launches | MFMA busy / (1024 SIMD x GUI_ACTIVE/8) | WAIT_INST_ANY/WAVE_CYCLES | WAIT_ANY/WAVE_CYCLES | ACTIVE/WAVE_CYCLES | LDS bank conflict cycles |\n|---|---|---|---|---|---|---|")
