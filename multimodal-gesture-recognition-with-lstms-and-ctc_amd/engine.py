@@ -6,6 +6,7 @@ directions of every Bidirectional layer and the modality encoders run concurrent
 Keras' ``train_on_batch`` / ``predict_on_batch`` do for the reference (multimodal_fusion/multimodal.py:264,
 multimodal_fusion/sequence_decoding.py:121); there is no CPU fallback.
 """
+import collections
 import ctypes as C
 import math
 
@@ -216,6 +217,8 @@ class Engine:
         self._seq_words = dev.pinned((16,), np.uint32)
         self._seq_words[...] = 0
         self._seq_next = 0
+        # (diagnostic, bounded) per fused step: (step id, kind, the words its two residency waits poll) - tools/startup_probe.py
+        self._gate_log = collections.deque(maxlen=16)
         # data parallel: [gate flag, sum over ranks of the local mean losses, -, -] of step s in slot s & 1, copied from behind the
         # all-reduced gradient buffer (apply_gradients); read by read_global_loss
         self.gloss_host = [dev.pinned((4,), np.float32) for _ in range(2)]
@@ -803,7 +806,6 @@ class Engine:
     _fusion_scan_form = _capi.SCAN_FORM_AUTO   # form of the fusion layer's scan launch
     _early_words = None      # seq_words dict of the generator in _early_gen
     _since_fresh = 0         # pipelined calls since the last one that started the next batch's pass itself (0 in such a call)
-    _gate_log = []           # (diagnostic) per fused step: (step id, kind, the words its two residency waits poll)
     _early_for = None        # the inputs the generator started last was announced for
     _early_gen = None        # _next_encoders_free generator of the batch after next, its first part already enqueued
     _beside_scans = False    # the fusion layer's GEMMs of the step being enqueued run beside encoder scans of the next batch

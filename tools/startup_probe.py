@@ -29,4 +29,4 @@ for region in range(2):
     print("   persist (launches, serialised) after each step:", ss, "waits", eng.resident_wait_stats())
     out = (ctypes.c_uint * 4)(); dev.call("mgr_resident_wait_stats", out)
     base = eng._seq_words.ctypes.data
-    print("   last expired wait: seq", out[2], "word index", ((out[3] - (base & 0xFFFFFFFF)) & 0xFFFFFFFF) // 4, "| gate log (step, kind, word indices):", [(a, b, tuple(None if w is None else (w - base) // 4 for w in ws)) for a, b, ws in eng._gate_log[-8:]], "| words now", list(eng._seq_words))
+    print("   last expired wait: seq", out[2], "word index", ((out[3] - (base & 0xFFFFFFFF)) & 0xFFFFFFFF) // 4, "| gate log (step, kind, word indices):", [(a, b, tuple(None if w is None else (w - base) // 4 for w in ws)) for a, b, ws in list(eng._gate_log)[-8:]], "| words now", list(eng._seq_words))
