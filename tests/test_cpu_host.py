@@ -483,3 +483,50 @@ def test_local_world_size_does_not_take_a_multi_node_world_for_the_node(monkeypa
     env = {k: v for k, v in os.environ.items() if k not in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")}
     env["MGR_NO_THREAD_CAP"] = "1"
     assert subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split() == ["None"]
+
+
+def test_binding_constants_and_structs_match_the_header():
+    """The ctypes binding restates enums and struct layouts of include/mgr.h by hand: the launch forms, MGR_SEQ_NONE, the ABI revision,
+    the profiling families, and the member lists of the three structs it fills field by field (the library reports their sizes at
+    load time - mgr_abi_struct_sizes - but only a GPU box loads it; this is the CPU-side half of the guard)."""
+    import re
+    from mgr_amd import _capi
+    hdr = open(os.path.join(ROOT, "include", "mgr.h")).read()
+    flat = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+
+    def enum(name):
+        m = re.search(r"\b%s\s*=\s*(0x[0-9A-Fa-f]+|\d+)" % name, flat)
+        assert m, name
+        return int(m.group(1), 0)
+
+    for c_name, py in (("MGR_SCAN_FORM_AUTO", _capi.SCAN_FORM_AUTO), ("MGR_SCAN_FORM_PLAIN", _capi.SCAN_FORM_PLAIN),
+                       ("MGR_SCAN_FORM_PAIR", _capi.SCAN_FORM_PAIR), ("MGR_SCAN_FORM_FUSED", _capi.SCAN_FORM_FUSED),
+                       ("MGR_SCAN_FORM_FUSED_ANY", _capi.SCAN_FORM_FUSED_ANY), ("MGR_BPTT_FORM_AUTO", _capi.BPTT_FORM_AUTO),
+                       ("MGR_BPTT_FORM_TRIMMED", _capi.BPTT_FORM_TRIMMED), ("MGR_BPTT_FORM_YIELDING", _capi.BPTT_FORM_YIELDING),
+                       ("MGR_BPTT_FORM_DIRECT", _capi.BPTT_FORM_DIRECT), ("MGR_BPTT_FORM_FUSED", _capi.BPTT_FORM_FUSED),
+                       ("MGR_BPTT_FORM_FUSED_DIRECT", _capi.BPTT_FORM_FUSED_DIRECT), ("MGR_BPTT_FORM_SINGLE_CU", _capi.BPTT_FORM_SINGLE_CU),
+                       ("MGR_SCAN_GAVE_UP", _capi.SCAN_GAVE_UP), ("MGR_SCAN_NONFINITE", _capi.SCAN_NONFINITE),
+                       ("MGR_K_SCAN_FWD", _capi.K_SCAN_FWD), ("MGR_K_SCAN_FWD_NARROW", _capi.K_SCAN_FWD_NARROW),
+                       ("MGR_K_ALLREDUCE", _capi.K_ALLREDUCE)):
+        assert enum(c_name) == py, c_name
+    assert enum("MGR_K_COUNT") == len(_capi.KERNEL_FAMILIES)
+    assert int(re.search(r"#define MGR_ABI_REVISION\s+(\d+)", hdr).group(1)) == _capi.ABI_REVISION
+    assert int(re.search(r"#define MGR_SEQ_NONE\s+(0x[0-9A-Fa-f]+)u", hdr).group(1), 16) == _capi.SEQ_NONE
+
+    def members(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), flat, re.S).group(1)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            first, *rest = [p.strip() for p in decl.split(",")]
+            names.append(re.search(r"(\w+)$", first.replace("*", " ")).group(1))
+            names += [re.search(r"(\w+)$", r.replace("*", " ")).group(1) for r in rest]
+        return names
+
+    assert members("mgr_scan_job") == [n for n, _ in _capi.ScanJob._fields_]
+    assert members("mgr_scan_bwd_job") == [n for n, _ in _capi.ScanBwdJob._fields_]
+    assert members("mgr_scan_launch_opts") == [n for n, _ in _capi.ScanLaunchOpts._fields_]
+    o = _capi.make_launch_opts(_capi.SCAN_FORM_FUSED, 0)
+    assert o.struct_size == __import__("ctypes").sizeof(_capi.ScanLaunchOpts) and o.form == 3 and not o.seq_out
