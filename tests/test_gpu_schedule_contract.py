@@ -312,3 +312,25 @@ def test_a_collective_shaped_guest_starts_beside_the_fused_layout(device):
     device.stream(0)
     for a in bufs + [ws, fws, out]:
         a.free()
+
+
+def test_stream_priority_is_a_property_of_the_context_stream(device):
+    """mgr_stream_set_priority recreates a stream of the context with a dispatch priority (Schedule.chain_stream_priority; measured:
+    no gain for config F, off by default).  Work enqueued on the recreated stream runs and orders as before; levels outside
+    -1 .. 1 and stream indices outside the context are refused."""
+    from mgr_amd import _capi
+    a = device.array(np.arange(1024, dtype=np.float32))
+    b = device.zeros((1024,))
+    for level in (1, -1, 0):
+        device.call("mgr_stream_set_priority", 3, level)
+        device.stream(3)
+        device.call("mgr_add2d", a, 1024, a, 1024, b, 1024, 1, 1024)
+        device.record(23)
+        device.stream(0)
+        device.wait_event(0, 23)
+        assert np.array_equal(b.download(), 2 * np.arange(1024, dtype=np.float32))
+    assert device.lib.mgr_stream_set_priority(device.ctx, 3, 2) != 0
+    assert device.lib.mgr_stream_set_priority(device.ctx, 99, 0) != 0
+    device.stream(0)
+    a.free()
+    b.free()
