@@ -230,10 +230,11 @@ typedef struct mgr_scan_launch_opts {
 int mgr_lstm_scan_fwd_multi_ex(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs, void* ws, size_t ws_bytes,
                                const mgr_scan_launch_opts* opts);
 /* ABI guard for bindings that fill mgr_scan_job / mgr_scan_bwd_job / mgr_scan_launch_opts field by field: the sizes the LIBRARY was
- * built with (round 5 appended mgr_scan_bwd_job.dzmax and turned mgr_scan_job's reserved word into yt_split - a caller built against
+ * built with (round 5 appended mgr_scan_bwd_job.dzmax and turned mgr_scan_job's reserved word into yt_split; revision 7 appended
+ * mgr_scan_bwd_job.dbsum and the dbsum argument of mgr_lstm_param_grads_dropout_ts - a caller built against
  * an older header must not pass its structs to this library).  out[0..2] = sizeof of the three structs, out[3] =
  * MGR_ABI_REVISION. */
-#define MGR_ABI_REVISION 6
+#define MGR_ABI_REVISION 7
 int mgr_abi_struct_sizes(unsigned out[4]);
 /* Tuning / test hooks.  key 0 (MGR_TUNE_SCAN_PATH): 0 auto, 1 force the L2-streaming fallback kernels,
  * 2 force one workgroup per batch group (no inter-CU exchange) where it fits, 3 force clusters with 4 tiles per
@@ -353,6 +354,10 @@ typedef struct mgr_scan_bwd_job {
    * the rows of dZ^T by.  The multi-CU kernel keeps it in four registers of the thread that owns a (sample, unit) for all T steps
    * (free); any other kernel family is followed by a reduction pass inside the call.  NULL: not wanted. */
   unsigned* dzmax;
+  /* optional: dbsum[b * 4H + col] = sum over t of dZ[b, t, col], added in step order - the bias gradient's per-sample partial sums
+   * (mgr_lstm_param_grads_dropout_ts takes them in place of its own pass over dZ).  Kept by the multi-CU kernels like dzmax, in four
+   * more registers; any other kernel family: the same reduction pass.  NULL: not wanted. */
+  float* dbsum;
 } mgr_scan_bwd_job;
 size_t mgr_lstm_scan_bwd_multi_ws_bytes(int njobs, const mgr_scan_bwd_job* jobs);
 int mgr_lstm_scan_bwd_multi(mgr_ctx* ctx, int njobs, const mgr_scan_bwd_job* jobs, void* ws, size_t ws_bytes);
@@ -394,8 +399,11 @@ int mgr_lstm_param_grads_dropout_t(mgr_ctx* ctx, const float* XT, int ldt, const
 size_t mgr_lstm_param_grads_dropout_ts_ws_bytes(int B, int T, int F, int H, int ldt);
 int mgr_lstm_param_grads_dropout_ts(mgr_ctx* ctx, const float* XS, int ldt, const float* mask4, float drop_rate,
                                     const float* Hs, int ldh, const float* dZ, float* dWp, float* dUp, float* dbp, int B,
-                                    int T, int F, int H, int reverse, void* ws, size_t ws_bytes, const unsigned* dzmax);
-/* (dzmax: the row maxima of dZ if the BPTT left them - mgr_scan_bwd_job.dzmax - or NULL: this call finds them with one more pass.) */
+                                    int T, int F, int H, int reverse, void* ws, size_t ws_bytes, const unsigned* dzmax,
+                                    const float* dbsum);
+/* (dzmax: the row maxima of dZ if the BPTT left them - mgr_scan_bwd_job.dzmax - or NULL: this call finds them with one more pass.
+ *  dbsum: the per-sample sums of dZ over time if the BPTT left them - mgr_scan_bwd_job.dbsum - then db = their sum over the samples in
+ *  sample order; or NULL: db from a pass over dZ, as in mgr_lstm_param_grads.) */
 /* dX[b,t,0:F] (stride lddx) (+)= sum_g mask4[g] (.) (dZ_g . W_g^T); accumulate=1 adds into dX. */
 int mgr_lstm_input_grad(mgr_ctx* ctx, const float* dZ, const float* Wp, const float* mask4, float* dX,
                         int lddx, int accumulate, int B, int T, int F, int H);

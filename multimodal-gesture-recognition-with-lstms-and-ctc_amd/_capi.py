@@ -94,7 +94,7 @@ SIGNATURES = {
     "mgr_lstm_param_grads_dropout_t_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
     "mgr_lstm_param_grads_dropout_t": (i32, [vp, vp, i32, vp, C.c_float, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, C.c_float]),
     "mgr_lstm_param_grads_dropout_ts_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
-    "mgr_lstm_param_grads_dropout_ts": (i32, [vp, vp, i32, vp, C.c_float, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "mgr_lstm_param_grads_dropout_ts": (i32, [vp, vp, i32, vp, C.c_float, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp, vp]),
     "mgr_lstm_input_grad": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32]),
     "mgr_dense_softmax_fwd": (i32, [vp, vp, i32, vp, C.c_float, u64, vp, vp, vp, i32, i32, i32, i32]),
     "mgr_dense_bwd_ws_bytes": (sz, [i32, i32, i32, i32]),
@@ -137,7 +137,7 @@ class ScanJob(C.Structure):
 class ScanBwdJob(C.Structure):
     """struct mgr_scan_bwd_job"""
     _fields_ = [("dY", vp), ("gates", vp), ("cs", vp), ("Up", vp), ("dZ", vp),
-                ("lddy", i32), ("B", i32), ("T", i32), ("H", i32), ("reverse", i32), ("dzmax", vp)]
+                ("lddy", i32), ("B", i32), ("T", i32), ("H", i32), ("reverse", i32), ("dzmax", vp), ("dbsum", vp)]
 
 
 class ScanLaunchOpts(C.Structure):
@@ -149,7 +149,7 @@ class ScanLaunchOpts(C.Structure):
 SCAN_FORM_AUTO, SCAN_FORM_PLAIN, SCAN_FORM_PAIR, SCAN_FORM_FUSED, SCAN_FORM_FUSED_ANY = range(5)
 BPTT_FORM_AUTO, BPTT_FORM_TRIMMED, BPTT_FORM_YIELDING, BPTT_FORM_DIRECT, BPTT_FORM_FUSED, BPTT_FORM_FUSED_DIRECT, BPTT_FORM_SINGLE_CU = range(7)
 SEQ_NONE = 0xFFFFFFFF
-ABI_REVISION = 6
+ABI_REVISION = 7
 
 
 def make_launch_opts(form=0, seq_out=0):
@@ -164,7 +164,7 @@ def make_launch_opts(form=0, seq_out=0):
 def make_scan_bwd_jobs(jobs):
     arr = (ScanBwdJob * len(jobs))()
     for a, j in zip(arr, jobs):
-        for k in ("dY", "gates", "cs", "Up", "dZ", "dzmax"):
+        for k in ("dY", "gates", "cs", "Up", "dZ", "dzmax", "dbsum"):
             v = j.get(k, 0)
             setattr(a, k, v.ptr if isinstance(v, DeviceArray) else (v or 0))
         for k in ("lddy", "B", "T", "H", "reverse"):

@@ -113,9 +113,9 @@ __host__ __device__ static inline float mgr_drop_scale(uint64_t seed, uint64_t i
 int mgr_transpose_bt_strided(mgr_ctx* c, const float* X, int ldx, float* XT, int ldt, long long xtb, int ldt_fill, int B, int T, int F);
 // the same into the split row format (gemm_split.hip): row (b, f) = ldt f16 hi values, then ldt f16 lo values of x 2^13
 int mgr_transpose_bt_split_strided(mgr_ctx* c, const float* X, int ldx, float* XS, int ldt, long long xsb, int ldt_fill, int B, int T, int F);
-// dU / db of one LSTM direction (gemm.hip); ws: mgr_lstm_param_grads_ws_bytes(B, T, F, H) bytes
+// dU / db of one LSTM direction (gemm.hip); ws: mgr_lstm_param_grads_ws_bytes(B, T, F, H) bytes; dbsum: [B][4H] sums of dZ over time or null
 int mgr_param_grads_du_db(mgr_ctx* c, const float* Hs, int ldh, const float* dZ, float* dUp, float* dbp, int B, int T, int F, int H, int reverse,
-                          void* ws);
+                          void* ws, const float* dbsum);
 
 // zmax[b * N + col] = largest |dZ[b, t, col]| over t as float bits (gemm_split.hip)
-int mgr_rowmax_bt(mgr_ctx* c, const float* dZ, int N, int T, int B, unsigned* zmax);
+int mgr_rowmax_bt(mgr_ctx* c, const float* dZ, int N, int T, int B, unsigned* zmax, float* zsum);   // (either output may be null)

@@ -27,15 +27,22 @@ namespace {
 
 constexpr float kNegInf = -__builtin_huge_valf();
 
+// The recursions run in BASE-2 log units (round 6): log2 y emissions, log2 alpha / beta, so that a log-sum-exp is v_exp_f32 / v_log_f32
+// on their own - no log2(e) / ln 2 multiplications, and none of logf's denormal-range and last-ulp fix-ups either: the argument of the
+// logarithm lies in [1, 3] (the largest term contributes exactly 1), where the raw instruction's 1 ulp is 1e-7 absolute on values that
+// are added to numbers of size O(10).  That was 30 of the 95 instructions of a step of the serial chain (12 for each logf).
+// All-(-inf) inputs (log 0): the maximum is floored at a huge finite negative number, x - floor stays -inf, 2^-inf = 0, log2 0 = -inf.
+constexpr float kLseFloor = -3.0e38f;
+constexpr double kLn2 = 0.693147180559945309417232121458;
+__device__ __forceinline__ float exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float log2_raw(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float lse2(float a, float b) {
-  float m = fmaxf(a, b);
-  if (m == kNegInf) return kNegInf;
-  return m + __logf(__expf(a - m) + __expf(b - m));
+  const float m = fmaxf(fmaxf(a, b), kLseFloor);
+  return m + log2_raw(exp2_raw(a - m) + exp2_raw(b - m));
 }
 __device__ __forceinline__ float lse3(float a, float b, float c) {
-  float m = fmaxf(fmaxf(a, b), c);
-  if (m == kNegInf) return kNegInf;
-  return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+  const float m = fmaxf(fmaxf(fmaxf(a, b), c), kLseFloor);
+  return m + log2_raw(exp2_raw(a - m) + exp2_raw(b - m) + exp2_raw(c - m));
 }
 
 // Cross-lane traffic of the recursions through DPP (one v_mov_b32_dpp, a few cycles) instead of __shfl_* (a ds_bpermute round trip
@@ -78,7 +85,7 @@ struct CtcSample {
   float* s_logp;
 };
 
-// ---- phase 0 (all 256 threads): labels into LDS; emissions log y(t,c) = log(P+eps) - log(sum_c (P+eps)), class-major, forward and
+// ---- phase 0 (all 256 threads): labels into LDS; emissions log2 y(t,c) = log2(P+eps) - log2(sum_c (P+eps)), class-major, forward and
 // reversed in time
 __device__ __forceinline__ void ctc_phase0(const CtcSample& cs_, int tid, const float* __restrict__ P, const int32_t* __restrict__ labels, int T,
                                            int C, int Lmax, int skip, float eps, size_t TS) {
@@ -95,9 +102,9 @@ __device__ __forceinline__ void ctc_phase0(const CtcSample& cs_, int tid, const 
     const float* row = P + ((size_t)b * T + skip + t) * C;
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += row[c] + eps;
-    float ls = logf(s);
+    float ls = log2f(s);
     for (int c = 0; c < C; ++c) {
-      const float v = logf(row[c] + eps) - ls;
+      const float v = log2f(row[c] + eps) - ls;   // (base-2 units, as everything the recursions touch)
       LYTb[(size_t)c * TS + t + 3] = v;
       LYRb[(size_t)c * TS + (Tp - 1 - t)] = v;
     }
@@ -237,7 +244,7 @@ __device__ __forceinline__ void ctc_phase1(const CtcSample& cs_, int role, int l
       }
       float lfin = lse2(fb, fl);
       if (lane == 0) {
-        loss[b] = (lfin == kNegInf) ? __builtin_huge_valf() : (float)(-((double)lfin + coff));
+        loss[b] = (lfin == kNegInf) ? __builtin_huge_valf() : (float)(-((double)lfin + coff) * kLn2);
         *s_logp = lfin;  // only its finiteness is used below
       }
     } else {
@@ -364,11 +371,11 @@ __device__ __forceinline__ void ctc_phase2(const CtcSample& cs_, int tid, float*
     for (int p = 0; p <= L; ++p) {
       float2 a = *reinterpret_cast<const float2*>(ar + 4 * p);
       float2 be = *reinterpret_cast<const float2*>(br + 4 * p);
-      float wb = __expf(a.x + be.x - vmax);
+      float wb = exp2_raw(a.x + be.x - vmax);
       occ[blank] += wb;
       den += wb;
       if (p < L) {
-        float wl = __expf(a.y + be.y - vmax);
+        float wl = exp2_raw(a.y + be.y - vmax);
         occ[s_lab[p]] += wl;
         den += wl;
       }

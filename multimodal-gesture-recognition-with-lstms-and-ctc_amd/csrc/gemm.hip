@@ -1600,7 +1600,8 @@ size_t mgr_lstm_param_grads_ws_bytes(int B, int T, int F, int H) {
 }
 
 static int param_grads_impl(mgr_ctx* c, const float* X, int ldx, const float* mask4, const float* Hs, int ldh, const float* dZ,
-                            float* dWp, float* dUp, float* dbp, int B, int T, int F, int H, int reverse, void* ws, bool with_dW) {
+                            float* dWp, float* dUp, float* dbp, int B, int T, int F, int H, int reverse, void* ws, bool with_dW,
+                            const float* dbsum = nullptr) {
   int N = 4 * H;
   int sgW = tn_groups(B, F, N), sgU = tn_groups(B, H, N);
   char* w = reinterpret_cast<char*>(ws);
@@ -1625,7 +1626,9 @@ static int param_grads_impl(mgr_ctx* c, const float* X, int ldx, const float* ma
     size_t n = (size_t)H * N;
     hipLaunchKernelGGL(k_reduce, dim3((int)((n + 255) / 256)), dim3(256), 0, s, slabU, dUp, n, sgU);
   }
-  {
+  if (dbsum) {   // the BPTT's per-sample sums over time: db = their sum over the samples, in sample order
+    hipLaunchKernelGGL(k_reduce_tall, dim3((N + 31) / 32), dim3(256), 0, s, dbsum, dbp, N, B);
+  } else {
     size_t rows = (size_t)B * T;
     int nwg = colsum_wgs(rows);
     int rpw = (int)((rows + nwg - 1) / nwg);
@@ -1778,8 +1781,8 @@ int mgr_lstm_input_grad(mgr_ctx* c, const float* dZ, const float* Wp, const floa
 // dU / db of one direction (the part of the parameter gradients that does not read the layer input): for gemm_split.hip.  ws: the
 // first mgr_lstm_param_grads_ws_bytes(B, T, F, H) bytes of the caller's workspace
 int mgr_param_grads_du_db(mgr_ctx* c, const float* Hs, int ldh, const float* dZ, float* dUp, float* dbp, int B, int T, int F, int H, int reverse,
-                          void* ws) {
-  return param_grads_impl(c, nullptr, 0, nullptr, Hs, ldh, dZ, nullptr, dUp, dbp, B, T, F, H, reverse, ws, false);
+                          void* ws, const float* dbsum) {
+  return param_grads_impl(c, nullptr, 0, nullptr, Hs, ldh, dZ, nullptr, dUp, dbp, B, T, F, H, reverse, ws, false, dbsum);
 }
 
 int mgr_transpose_bt_strided(mgr_ctx* c, const float* X, int ldx, float* XT, int ldt, long long xtb, int ldt_fill, int B, int T, int F) {

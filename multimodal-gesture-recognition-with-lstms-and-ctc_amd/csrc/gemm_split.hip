@@ -411,18 +411,26 @@ __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_proj_split(const 
 // position c ^ ((r >> 2) & 3) (ds_read_b128 of 32 consecutive rows at one chunk: conflict-free); 32 KiB per stage.
 constexpr int DW_BM = 128, DW_BN = 128, DW_TK = 32, DW_STAGE = 4 * 128 * 64;
 
-// zmax[b][col] = largest |dZ[b, t, col]| over t, as float bits
-__global__ __launch_bounds__(256) void k_rowmax_bt(const float* __restrict__ dZ, int N, int T, unsigned* __restrict__ zmax) {
-  __shared__ float part[4][64];
+// zmax[b][col] = largest |dZ[b, t, col]| over t, as float bits; zsum[b][col] = sum of dZ[b, t, col] over t (either may be null)
+__global__ __launch_bounds__(256) void k_rowmax_bt(const float* __restrict__ dZ, int N, int T, unsigned* __restrict__ zmax, float* __restrict__ zsum) {
+  __shared__ float part[2][4][64];
   const int b = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
-  float m = 0.f;
+  float m = 0.f, sm = 0.f;
   if (col < N) {
     const float* p = dZ + (size_t)b * T * N + col;
-    for (int t = w; t < T; t += 4) m = fmaxf(m, fabsf(p[(size_t)t * N]));
+    for (int t = w; t < T; t += 4) {
+      const float v = p[(size_t)t * N];
+      m = fmaxf(m, fabsf(v));
+      sm += v;
+    }
   }
-  part[w][threadIdx.x & 63] = m;
+  part[0][w][threadIdx.x & 63] = m;
+  part[1][w][threadIdx.x & 63] = sm;
   __syncthreads();
-  if (w == 0 && col < N) zmax[(size_t)b * N + col] = __float_as_uint(fmaxf(fmaxf(part[0][threadIdx.x], part[1][threadIdx.x]), fmaxf(part[2][threadIdx.x], part[3][threadIdx.x])));
+  if (w == 0 && col < N) {
+    if (zmax) zmax[(size_t)b * N + col] = __float_as_uint(fmaxf(fmaxf(part[0][0][threadIdx.x], part[0][1][threadIdx.x]), fmaxf(part[0][2][threadIdx.x], part[0][3][threadIdx.x])));
+    if (zsum) zsum[(size_t)b * N + col] = (part[1][0][threadIdx.x] + part[1][1][threadIdx.x]) + (part[1][2][threadIdx.x] + part[1][3][threadIdx.x]);
+  }
 }
 __device__ __forceinline__ float dw_zscale(unsigned zm_bits) {   // the power of two that puts the row's largest |dZ| in [2^14, 2^15)
   const float zm = __uint_as_float(zm_bits);
@@ -707,7 +715,7 @@ size_t mgr_lstm_param_grads_dropout_ts_ws_bytes(int B, int T, int F, int H, int 
 
 int mgr_lstm_param_grads_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const float* mask4, float drop_rate, const float* Hs, int ldh,
                                     const float* dZ, float* dWp, float* dUp, float* dbp, int B, int T, int F, int H, int reverse,
-                                    void* ws, size_t ws_bytes, const unsigned* dzmax) {
+                                    void* ws, size_t ws_bytes, const unsigned* dzmax, const float* dbsum) {
   MGR_REQUIRE(c && XS && mask4 && Hs && dZ && dWp && dUp && dbp, "null argument");
   MGR_REQUIRE(B > 0 && T > 0 && H > 0 && F >= 16 && F <= 2048 && ldh >= H, "bad shape (16 <= F <= 2048)");
   MGR_REQUIRE(ldt % 32 == 0 && ldt >= (T + DW_TK - 1) / DW_TK * DW_TK, "the split copy must be padded to whole stages of %d time steps (ldt %d, T %d)", DW_TK, ldt, T);
@@ -717,7 +725,7 @@ int mgr_lstm_param_grads_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const 
   (void)drop_rate;
   mgr_prof_begin(c, MGR_K_GEMM_TN);
   // dU / db first: they are short, and in the training step the long dW kernel then ends this direction's work (gemm.hip)
-  int r = mgr_param_grads_du_db(c, Hs, ldh, dZ, dUp, dbp, B, T, F, H, reverse, ws);
+  int r = mgr_param_grads_du_db(c, Hs, ldh, dZ, dUp, dbp, B, T, F, H, reverse, ws, dbsum);
   if (r) return r;
   const int Fp32 = fp32_of(F), N = 4 * H;
   char* w = reinterpret_cast<char*>(ws) + mgr_lstm_param_grads_ws_bytes(B, T, F, H);
@@ -742,7 +750,7 @@ int mgr_lstm_param_grads_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const 
   }
   MGR_HIP(hipMemsetAsync(words, 0, 2 * sizeof(unsigned), s));
   hipLaunchKernelGGL(k_lists32, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp32, lists, kcnt, kpos, words + 1);
-  if (!dzmax) hipLaunchKernelGGL(k_rowmax_bt, dim3((N + 63) / 64, B), dim3(256), 0, s, dZ, N, T, reinterpret_cast<unsigned*>(w));
+  if (!dzmax) hipLaunchKernelGGL(k_rowmax_bt, dim3((N + 63) / 64, B), dim3(256), 0, s, dZ, N, T, reinterpret_cast<unsigned*>(w), (float*)nullptr);
   hipLaunchKernelGGL(k_transpose_split_scaled, dim3((ldt + 63) / 64, (N + 63) / 64, B), dim3(256), 0, s, dZ, N, dZS, ldt, T, zmax);
   const int grid = 8 * ((B + 7) / 8) * 4 * ((Fp32 + DW_BM - 1) / DW_BM) * ((H + DW_BN - 1) / DW_BN);
   // tune key 12 (the tile switch of the projection): 1 = the 4-wave form, which fits on a CU beside a workgroup of a persistent scan
@@ -792,8 +800,8 @@ int mgr_transpose_bt_split(mgr_ctx* c, const float* X, int ldx, float* XS, int l
 
 }  // extern "C"
 
-int mgr_rowmax_bt(mgr_ctx* c, const float* dZ, int N, int T, int B, unsigned* zmax) {
-  hipLaunchKernelGGL(k_rowmax_bt, dim3((N + 63) / 64, B), dim3(256), 0, mgr_stream(c), dZ, N, T, zmax);
+int mgr_rowmax_bt(mgr_ctx* c, const float* dZ, int N, int T, int B, unsigned* zmax, float* zsum) {
+  hipLaunchKernelGGL(k_rowmax_bt, dim3((N + 63) / 64, B), dim3(256), 0, mgr_stream(c), dZ, N, T, zmax, zsum);
   MGR_LAUNCH_CHECK();
   return 0;
 }

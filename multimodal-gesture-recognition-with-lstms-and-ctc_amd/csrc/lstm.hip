@@ -490,8 +490,8 @@ int mgr_lstm_scan_bwd_multi_ex(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jo
     if (r == 1) {
       for (int i = 0; i < njobs; ++i) {   // (the row maxima of dZ: a reduction pass, as behind every kernel that does not keep them itself)
         const mgr_scan_bwd_job& j = jobs[i];
-        if (!j.dzmax) continue;
-        r = mgr_rowmax_bt(c, j.dZ, 4 * j.H, j.T, j.B, j.dzmax);
+        if (!j.dzmax && !j.dbsum) continue;
+        r = mgr_rowmax_bt(c, j.dZ, 4 * j.H, j.T, j.B, j.dzmax, j.dbsum);
         if (r) return r;
       }
       return mgr_prof_end(c, MGR_K_SCAN_BWD);
@@ -551,7 +551,7 @@ int mgr_lstm_scan_bwd_multi_ex(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jo
     if (!use_cluster[i]) continue;
     const mgr_scan_bwd_job& j = jobs[i];
     ClusterBwdJob& cj = L.job[L.njobs++];
-    cj.dY = j.dY; cj.gates = j.gates; cj.cs = j.cs; cj.Up = j.Up; cj.dZ = j.dZ; cj.dzmax = j.dzmax;
+    cj.dY = j.dY; cj.gates = j.gates; cj.cs = j.cs; cj.Up = j.Up; cj.dZ = j.dZ; cj.dzmax = j.dzmax; cj.dbsum = j.dbsum;
     cj.lddy = j.lddy; cj.B = j.B; cj.T = j.T; cj.H = j.H; cj.reverse = j.reverse;
     cj.G_ = (j.H + 15) / 16; cj.nbg = nbg[i];
     cj.cls_begin = cb[i]; cj.cls_nclusters = cn[i]; cj.cls_cluster0 = c0[i]; cj.cls_rot = cr[i];
@@ -604,10 +604,10 @@ int mgr_lstm_scan_bwd_multi_ex(mgr_ctx* c, int njobs, const mgr_scan_bwd_job* jo
     }
     if (r < 0) return r;
   }
-  for (int i = 0; i < njobs; ++i) {   // the row maxima of dZ where the kernel that ran did not leave them itself
+  for (int i = 0; i < njobs; ++i) {   // the row maxima / sums of dZ where the kernel that ran did not leave them itself
     const mgr_scan_bwd_job& j = jobs[i];
-    if (!j.dzmax || use_cluster[i]) continue;
-    r = mgr_rowmax_bt(c, j.dZ, 4 * j.H, j.T, j.B, j.dzmax);
+    if ((!j.dzmax && !j.dbsum) || use_cluster[i]) continue;
+    r = mgr_rowmax_bt(c, j.dZ, 4 * j.H, j.T, j.B, j.dzmax, j.dbsum);
     if (r) return r;
   }
   r = mgr_prof_end(c, MGR_K_SCAN_BWD);
@@ -621,7 +621,7 @@ int mgr_lstm_scan_bwd(mgr_ctx* c, const float* dY, int lddy, const float* gates,
   mgr_scan_bwd_job j;
   j.dY = dY; j.gates = gates; j.cs = cs; j.Up = Up; j.dZ = dZ;
   j.lddy = lddy; j.B = B; j.T = T; j.H = H; j.reverse = reverse;
-  j.dzmax = nullptr;
+  j.dzmax = nullptr; j.dbsum = nullptr;
   return mgr_lstm_scan_bwd_multi(c, 1, &j, ws, ws_bytes);
 }
 

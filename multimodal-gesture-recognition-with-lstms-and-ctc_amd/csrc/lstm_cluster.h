@@ -82,6 +82,7 @@ struct ClusterBwdJob {
   const float* Up;
   float* dZ;
   unsigned* dzmax;   // optional [B][4H]: largest |dZ| over t per (sample, gate column), float bits (mgr_scan_bwd_job)
+  float* dbsum;      // optional [B][4H]: sum of dZ over t per (sample, gate column), in step order (mgr_scan_bwd_job)
   float* xbuf;  // [nbg][2][IMG]
   int lddy, B, T, H, reverse;
   int G_, nbg;

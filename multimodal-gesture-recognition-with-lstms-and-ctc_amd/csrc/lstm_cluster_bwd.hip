@@ -203,6 +203,7 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   float dcc = 0.f;
   float4 zmx = make_float4(0.f, 0.f, 0.f, 0.f);   // largest |dz| of this thread's (sample, unit) per gate over all steps (jb.dzmax)
+  float4 zsm = make_float4(0.f, 0.f, 0.f, 0.f);   // and the sum of its dz per gate, in step order (jb.dbsum)
   f32x4 own_tile = {0.f, 0.f, 0.f, 0.f};  // the partial tile this workgroup computed for itself (held by wave ug % 4)
   bool failed = false;
   __syncthreads();
@@ -313,6 +314,7 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
       dz = mgr_cell_bwd_tc(dh, ug4, tc, cp, dcc);
       if (bvalid) *reinterpret_cast<float4*>(jb.dZ + ((size_t)b * T + t) * N + unit * 4) = dz;
       zmx = make_float4(fmaxf(zmx.x, fabsf(dz.x)), fmaxf(zmx.y, fabsf(dz.y)), fmaxf(zmx.z, fabsf(dz.z)), fmaxf(zmx.w, fabsf(dz.w)));
+      zsm = make_float4(zsm.x + dz.x, zsm.y + dz.y, zsm.z + dz.z, zsm.w + dz.w);
     }
     BSTAMP(2, dz.x);
     if (!has_prev) break;   // the first forward step has no predecessor: nothing to send (workgroup-uniform; it is the last iteration)
@@ -447,6 +449,7 @@ __device__ __forceinline__ void cluster_bwd_run(const ClusterBwdJob& jb, int bg,
 #endif
   if (jb.dzmax && computer && uvalid && bvalid)   // (fmaxf drops a NaN: a NaN gradient shows in dZ itself, not here)
     *reinterpret_cast<float4*>(jb.dzmax + (size_t)b * N + unit * 4) = zmx;
+  if (jb.dbsum && computer && uvalid && bvalid) *reinterpret_cast<float4*>(jb.dbsum + (size_t)b * N + unit * 4) = zsm;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the wave ends
 }
 
@@ -565,6 +568,7 @@ __device__ __forceinline__ void cluster_bwd_run16(const ClusterBwdJob& jb, int b
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the weight loads and the first ring slots (a wait hipcc can see)
   float dcc = 0.f;
   float4 zmx = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 zsm = make_float4(0.f, 0.f, 0.f, 0.f);
   bool failed = false;
   unsigned spins = 0;
   __syncthreads();
@@ -720,6 +724,7 @@ __device__ __forceinline__ void cluster_bwd_run16(const ClusterBwdJob& jb, int b
       dz = mgr_cell_bwd_tc(dy + dhr, ug4, tc, cp, dcc);
       if (bvalid) *reinterpret_cast<float4*>(jb.dZ + ((size_t)b * T + t) * N + unit * 4) = dz;
       zmx = make_float4(fmaxf(zmx.x, fabsf(dz.x)), fmaxf(zmx.y, fabsf(dz.y)), fmaxf(zmx.z, fabsf(dz.z)), fmaxf(zmx.w, fabsf(dz.w)));
+      zsm = make_float4(zsm.x + dz.x, zsm.y + dz.y, zsm.z + dz.z, zsm.w + dz.w);
     }
     BSTAMP(2, dz.x);
     if (!has_prev) break;   // the first forward step has no predecessor: nothing to send (workgroup-uniform; it is the last iteration)
@@ -813,6 +818,7 @@ __device__ __forceinline__ void cluster_bwd_run16(const ClusterBwdJob& jb, int b
 #endif
   if (jb.dzmax && uvalid && bvalid)   // (fmaxf drops a NaN: a NaN gradient shows in dZ itself, not here)
     *reinterpret_cast<float4*>(jb.dzmax + (size_t)b * N + unit * 4) = zmx;
+  if (jb.dbsum && uvalid && bvalid) *reinterpret_cast<float4*>(jb.dbsum + (size_t)b * N + unit * 4) = zsm;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the wave ends
 }
 

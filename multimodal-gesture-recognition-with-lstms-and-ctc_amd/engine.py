@@ -65,7 +65,7 @@ class _LstmDir:
         self.gWp = self.gUp = self.gbp = None
         self.mask = None       # device [4,B,fin] when input dropout is active
         self.Z = None
-        self.gates = self.cs = self.dZ = self.dzmax = None
+        self.gates = self.cs = self.dZ = self.dzmax = self.dbsum = None
         self.ws_scan = self.ws_pg = self.ws_sp = None
 
 
@@ -252,6 +252,7 @@ class Engine:
                     L.cs = dev.empty((B, T, H))
                     L.dZ = dev.empty((B, T, 4 * H))
                     L.dzmax = dev.zeros((B, 4 * H), np.uint32)   # row maxima of dZ^T, left by the BPTT (mgr_scan_bwd_job.dzmax)
+                    L.dbsum = dev.zeros((B, 4 * H))              # and its sums of dZ over time: db without a pass over dZ
                     L.ws_scan = dev.bytes(self.lib.mgr_lstm_scan_ws_bytes(B, T, H))
                     need = (self.lib.mgr_lstm_param_grads_dropout_ws_bytes(B, T, fin, H) if p > 0
                             else self.lib.mgr_lstm_param_grads_ws_bytes(B, T, fin, H))
@@ -1629,7 +1630,7 @@ class Engine:
             H = L.H
             dYv = dY.view(di * H, (1,)) if isinstance(dY, DeviceArray) else dY
             jobs.append(dict(dY=dYv, gates=L.gates, cs=L.cs, Up=L.Up, dZ=L.dZ, lddy=lddy, B=B, T=T, H=H,
-                             reverse=L.reverse, dzmax=L.dzmax))
+                             reverse=L.reverse, dzmax=L.dzmax, dbsum=L.dbsum))
         dev.stream(0)
         arr = _capi.make_scan_bwd_jobs(jobs)   # both directions in ONE call (one persistent launch of CU clusters)
         need = self.lib.mgr_lstm_scan_bwd_multi_ws_bytes(len(jobs), arr)
@@ -1667,7 +1668,7 @@ class Engine:
                 if mptr and XinT is not None and self._xt_split.get(XinT.ptr, False):
                     with self._narrow_tiles(beside_scans and not wide_ok):
                         dev.call("mgr_lstm_param_grads_dropout_ts", XinT, self.ldt, mptr, float(L.p), Hbuf.view(di * H, (1,)), ldh, L.dZ,
-                                 L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes, L.dzmax)
+                                 L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes, L.dzmax, L.dbsum)
                 elif mptr and XinT is not None and self.lib.mgr_lstm_param_grads_dropout_wants_transposed(
                         dev.ctx, C.c_float(float(L.p)), int(fin)):
                     need = self.lib.mgr_lstm_param_grads_dropout_t_ws_bytes(B, T, fin, H, self.ldt)

@@ -424,7 +424,8 @@ def test_bwd_multi_matches_oracle(device, B, T, H, path, f32_mfma):
         dYd = dev.array(np.ascontiguousarray(dy).astype(f32))
         dZ = dev.empty((B, T, 4 * H))
         zm = dev.array(np.full((B, 4 * H), 0xFFFFFFFF, np.uint32))     # dirty: the call must write every word
-        jobs.append(dict(dY=dYd, gates=G, cs=Cs, Up=Up, dZ=dZ, lddy=H, B=B, T=T, H=H, reverse=reverse, dzmax=zm))
+        zs = dev.array(np.full((B, 4 * H), np.nan, f32))
+        jobs.append(dict(dY=dYd, gates=G, cs=Cs, Up=Up, dZ=dZ, lddy=H, B=B, T=T, H=H, reverse=reverse, dzmax=zm, dbsum=zs))
         refs.append((dx_ref, dW_ref, dU_ref, db_ref))
         outs.append((dX, Y, dZ, Wp))
     dev.call("mgr_tune", 0, path)
@@ -439,6 +440,10 @@ def test_bwd_multi_matches_oracle(device, B, T, H, path, f32_mfma):
                 # mgr_scan_bwd_job.dzmax: the largest |dZ| over time per (sample, gate column), whatever kernel family ran
                 zm = jobs[reverse]["dzmax"].download().view(np.float32)
                 assert np.array_equal(zm, np.abs(dZ.download()).max(axis=1))
+                # mgr_scan_bwd_job.dbsum: the sums of dZ over time (the bias gradient per sample), f32 sums in the kernel's own order
+                dz64 = dZ.download().astype(np.float64)
+                zs = jobs[reverse]["dbsum"].download()
+                assert np.all(np.abs(zs - dz64.sum(axis=1)) <= 1e-6 * np.abs(dz64).sum(axis=1) + 1e-30)
                 gW, gU, gb = dev.empty((F, 4 * H)), dev.empty((H, 4 * H)), dev.empty((4 * H,))
                 ws2 = dev.bytes(dev.lib.mgr_lstm_param_grads_ws_bytes(B, T, F, H))
                 dev.call("mgr_lstm_param_grads", dX, F, 0, Y, H, dZ, gW, gU, gb, B, T, F, H, reverse, ws2, ws2.nbytes)
@@ -451,12 +456,13 @@ def test_bwd_multi_matches_oracle(device, B, T, H, path, f32_mfma):
         if f32_mfma == 0 and path == 0 and 16 < H <= 128:
             # narrow layers have three forms of the split-f16 step (mgr.h, tune key 16): the one trimmed along its dependent chain (what ran
             # above) and the one the engine asks for beside other persistent launches - same results bit for bit
-            lean = [(o[2].download(), j["dzmax"].download()) for o, j in zip(outs, jobs)]
+            lean = [(o[2].download(), np.concatenate([j["dzmax"].download(), j["dbsum"].download().view(np.uint32)])) for o, j in zip(outs, jobs)]
+            both = lambda j: np.concatenate([j["dzmax"].download(), j["dbsum"].download().view(np.uint32)])
             for form in (1, 2):      # 1: the form that yields to co-resident scans, 2: the direct gather (one barrier per step)
                 dev.call("mgr_tune", 16, form)
                 _capi.check(dev.lib.mgr_lstm_scan_bwd_multi(dev.ctx, 2, arr, ws.ptr, ws.nbytes))
                 for (dz0, zm0), o, j in zip(lean, outs, jobs):
-                    assert np.array_equal(o[2].download(), dz0) and np.array_equal(j["dzmax"].download(), zm0), form
+                    assert np.array_equal(o[2].download(), dz0) and np.array_equal(both(j), zm0), form
             dev.call("mgr_tune", 16, 0)
             # round 6: the form as an ARGUMENT of the launch (mgr_scan_launch_opts) - every named form, and the FUSED forms (8-wave
             # workgroups that run two unit groups of their cluster, a CU each; an odd group count leaves a half that only keeps the
@@ -472,7 +478,7 @@ def test_bwd_multi_matches_oracle(device, B, T, H, path, f32_mfma):
                 dev.call("mgr_persist_stats", ctypes.byref(n0), None)
                 assert seq.value == n0.value          # (the launch number the call reports is the context's newest)
                 for (dz0, zm0), o, j in zip(lean, outs, jobs):
-                    assert np.array_equal(o[2].download(), dz0) and np.array_equal(j["dzmax"].download(), zm0), form
+                    assert np.array_equal(o[2].download(), dz0) and np.array_equal(both(j), zm0), form
             # the SINGLE-CU form (lstm_cu_bwd.hip: one workgroup per (direction, 16-sample group), no inter-CU exchange): the same
             # arithmetic in another summation order - equal to the multi-CU forms to rounding, its row maxima exact for ITS dZ
             if H in (32, 64, 100):
@@ -486,6 +492,8 @@ def test_bwd_multi_matches_oracle(device, B, T, H, path, f32_mfma):
                     dz1 = o[2].download()
                     assert np.isfinite(dz1).all() and rel_err(dz1, dz0) < 2e-5, rel_err(dz1, dz0)
                     assert np.array_equal(j["dzmax"].download().view(np.float32), np.abs(dz1).max(axis=1))
+                    d64 = dz1.astype(np.float64)
+                    assert np.all(np.abs(j["dbsum"].download() - d64.sum(axis=1)) <= 1e-6 * np.abs(d64).sum(axis=1) + 1e-30)
     finally:
         dev.call("mgr_tune", 16, 0)
         dev.call("mgr_tune", 14, 0)

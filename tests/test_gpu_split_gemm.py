@@ -99,12 +99,19 @@ def test_weight_gradient_from_split_rows(device, B, T, F, H, p, reverse):
         gW, gU, gb = dev.empty((F, N)), dev.empty((H, N)), dev.empty((N,))
         gW.upload(np.full((F, N), np.nan, f32))
         dev.call("mgr_memset", ws, 0xFF, ws.nbytes)          # the workspace arrives dirty
-        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW, gU, gb, B, T, F, H, reverse, ws, ws.nbytes, 0)
+        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW, gU, gb, B, T, F, H, reverse, ws, ws.nbytes, 0, 0)
         # ... and with the row maxima handed in (what the BPTT leaves: mgr_scan_bwd_job.dzmax): the same bits
         zmx = dev.array(np.abs(dZ).max(axis=1).astype(f32).view(np.uint32))
         gW3 = dev.empty((F, N))
-        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW3, gU, gb, B, T, F, H, reverse, ws, ws.nbytes, zmx)
+        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW3, gU, gb, B, T, F, H, reverse, ws, ws.nbytes, zmx, 0)
         assert np.array_equal(gW3.download(), gW.download())
+        # ... and with the sums over time handed in (mgr_scan_bwd_job.dbsum): db is their sum over the samples, dW / dU the same bits
+        zsm = dev.array(dZ.astype(np.float64).sum(axis=1).astype(f32))
+        gU3, gb3 = dev.empty((H, N)), dev.empty((N,))
+        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW3, gU3, gb3, B, T, F, H, reverse, ws, ws.nbytes, zmx, zsm)
+        assert np.array_equal(gW3.download(), gW.download()) and np.array_equal(gU3.download(), gU.download())
+        dbref = dZ.astype(np.float64).sum(axis=(0, 1))
+        assert np.abs(gb3.download() - dbref).max() <= 2e-6 * np.abs(dZ).sum(axis=(0, 1)).max()
         got = gW.download()
         colscale = np.maximum(np.abs(ref).max(axis=0, keepdims=True), 1e-30)      # per column: the spread is per column
         assert np.all(np.isfinite(got)) and (np.abs(got - ref) / colscale).max() <= 3e-5, (spread, (np.abs(got - ref) / colscale).max())

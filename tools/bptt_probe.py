@@ -8,7 +8,7 @@ vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
 
 class BwdJob(C.Structure):
     _fields_ = [("dY", vp), ("gates", vp), ("cs", vp), ("Up", vp), ("dZ", vp), ("lddy", i32), ("B", i32), ("T", i32), ("H", i32),
-                ("reverse", i32), ("dzmax", vp)]
+                ("reverse", i32), ("dzmax", vp), ("dbsum", vp)]
 
 
 B, T = 64, int(os.environ.get("BPTT_PROBE_T", "1900"))
