@@ -256,6 +256,9 @@ int mgr_abi_struct_sizes(unsigned out[4]);
  * key 14: K-split scan step: 0 = recurrent product on the f16 matrix pipe with every f32 operand split into an f16 (hi, lo) pair and
  *        f32 accumulation (22+ significant bits per operand; lstm_cluster.hip cluster_run_k16), 1 = v_mfma_f32_16x16x4_f32.
  * key 15: 1 = the transposed-input projection / parameter-gradient GEMMs keep their f32 MFMA kernels whatever bound the caller states.
+ * key 20 / 21: KiB of LDS the CTC recurrence kernel / the CTC per-frame kernels ask for at least (0: what they use).  A placement hint
+ *         for callers that run mgr_ctc_loss_grad / mgr_head_fwd_bwd beside persistent scan launches of another stream: a workgroup that
+ *         asks for more LDS than a scan workgroup leaves on its CU lands on a CU without one (engine.py sets 96 / 64 for such steps).
  * key 19: 1 = mgr_lstm_scan_bwd_multi[_ex] with form AUTO takes MGR_BPTT_FORM_SINGLE_CU where it qualifies (A/B of whole runs).
  * key 18: 1 = mgr_ctc_loss_grad runs one sample per workgroup (rounds 1 - 5); 0 = two (from B = 2 on: the alpha / beta chains of a
  *         workgroup's two samples on its four SIMDs - 32 workgroups for config F's 64 samples, which the 48 CUs beside fused encoder scans

@@ -1,21 +1,22 @@
-// K6: CTC loss + gradient w.r.t. the Dense logits, one workgroup per sample.
+// K6: CTC loss + gradient w.r.t. the Dense logits: three kernels - emissions (a thread per frame), the alpha / beta recursions (two
+// waves per sample), gradient (a thread per frame).
 //
 // Restates K.ctc_batch_cost -> tf.nn.ctc_loss as called by ctc_lambda_func
 // (reference multimodal_fusion/losses.py:4-15): y = softmax(log(P[:,skip:]+eps)), blank = C-1,
 // log-space alpha/beta DP over l' = [blank,l1,blank,...,lL,blank].
 //
-// Mapping: wave 0 runs alpha forward in time, wave 1 runs beta backward in time, concurrently.  The
+// Recursions: one wave runs alpha forward in time, one runs beta backward in time, concurrently.  The
 // extended label sequence lives across the lanes of the wave as (blank,label) PAIRS: lane*PPL+j holds
 // states 2p (blank) and 2p+1 (label p), so the only cross-lane traffic per time step is one
-// shuffle-by-one of the neighbouring pair's label state; the three-way log-sum-exp is max-shifted fp32.
-// Emissions log y(t,.) are precomputed (phase 0, all 4 waves) and software-prefetched a chunk of time
-// steps ahead of the recursion, so the serial chain per step is shuffle -> lse -> add.
+// shift-by-one of the neighbouring pair's label state; the three-way log-sum-exp is max-shifted fp32.
+// Emissions log2 y(t,.) are precomputed (k_ctc_emissions) and software-prefetched a chunk of time
+// steps ahead of the recursion, so the serial chain per step is shift -> lse -> add.
 // Numerics: alpha and beta are RENORMALISED every 16 time steps (the wave-wide max is subtracted and summed
 // into an fp64 scalar), so the stored log-values stay O(10) instead of O(-5000) at T=1900, where an fp32 ulp is
 // 5e-4 and would put percent-level noise on the gradient.  The loss adds the fp64 offset back; the gradient
 // needs no offsets at all because sum_u alpha(t,u)beta(t,u) = p(l|x) at every t, so each frame's occupancies
 // are normalised by their own sum.
-// Phase 2 (all 4 waves) combines alpha+beta into per-class occupancies through an LDS row per thread and
+// The gradient (k_ctc_grad) combines alpha+beta into per-class occupancies through an LDS row per thread and
 // chains through softmax(log(P+eps)) and the network's own softmax to dLogits.
 // Vector-memory instructions of the serial chain (round 4; a wave that is alone with its chain pays 60-130 cycles of issue for
 // each): the emissions are stored CLASS-MAJOR, forward in time for alpha and reversed for beta, so that a lane fetches eight
@@ -85,20 +86,22 @@ struct CtcSample {
   float* s_logp;
 };
 
-// ---- phase 0 (all 256 threads): labels into LDS; emissions log2 y(t,c) = log2(P+eps) - log2(sum_c (P+eps)), class-major, forward and
-// reversed in time
-__device__ __forceinline__ void ctc_phase0(const CtcSample& cs_, int tid, const float* __restrict__ P, const int32_t* __restrict__ labels, int T,
-                                           int C, int Lmax, int skip, float eps, size_t TS) {
-  const int b = cs_.b, Tp = cs_.Tp, L = cs_.L;
-  float *LYTb = cs_.LYTb, *LYRb = cs_.LYRb;
-  int* s_lab = cs_.s_lab;
-  for (int i = tid; i < Lmax; i += 256) {
-    int v = (i < L) ? labels[(size_t)b * Lmax + i] : -1;
+// the sample's labels into the workgroup's LDS (clipped into the class range)
+__device__ __forceinline__ void ctc_labels(const CtcSample& cs_, int tid, int nthreads, const int32_t* __restrict__ labels, int C, int Lmax) {
+  for (int i = tid; i < Lmax; i += nthreads) {
+    int v = (i < cs_.L) ? labels[(size_t)cs_.b * Lmax + i] : -1;
     v = v < 0 ? 0 : (v >= C ? C - 1 : v);
-    s_lab[i] = v;
+    cs_.s_lab[i] = v;
   }
-  // ---- phase 0: emissions log y(t,c) = log(P+eps) - log(sum_c (P+eps)), class-major, forward and reversed in time ------
-  for (int t = tid; t < Tp; t += 256) {
+}
+// ---- phase 0: emissions log2 y(t,c) = log2(P+eps) - log2(sum_c (P+eps)), class-major, forward and reversed in time.  One frame per
+// thread: workgroup `blk` of the sample's ceil(To / 256) (workgroup 0 also writes the rows' zero tails)
+__device__ __forceinline__ void ctc_phase0(const CtcSample& cs_, int tid, int blk, const float* __restrict__ P, int T, int C, int skip, float eps,
+                                           size_t TS) {
+  const int b = cs_.b, Tp = cs_.Tp;
+  float *LYTb = cs_.LYTb, *LYRb = cs_.LYRb;
+  const int t = blk * 256 + tid;
+  if (t < Tp) {
     const float* row = P + ((size_t)b * T + skip + t) * C;
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += row[c] + eps;
@@ -109,6 +112,7 @@ __device__ __forceinline__ void ctc_phase0(const CtcSample& cs_, int tid, const 
       LYRb[(size_t)c * TS + (Tp - 1 - t)] = v;
     }
   }
+  if (blk != 0) return;
   // the two-chunks-ahead prefetch of the recursions reads up to 2 CH + 2 = 18 floats behind the last emission of a row (values it
   // never uses): they are zeros, not whatever the workspace held (forward rows: [Tp + 3, Tp + 24), reversed rows: [Tp, Tp + 21);
   // TS >= To + 24 holds both)
@@ -340,75 +344,102 @@ __device__ __forceinline__ void ctc_phase1(const CtcSample& cs_, int role, int l
   }
 }
 
-// ---- phase 2 (all 256 threads): gradient w.r.t. the Dense logits
-__device__ __forceinline__ void ctc_phase2(const CtcSample& cs_, int tid, float* smem, const float* __restrict__ P, int T, int C, int skip,
-                                           int blank, float eps, float gscale, int S2, float* __restrict__ dLogits) {
+// ---- phase 2 (one frame per thread): gradient w.r.t. the Dense logits
+__device__ __forceinline__ void ctc_phase2(const CtcSample& cs_, int tid, int blk, float* smem, const float* __restrict__ P, int T, int C, int skip,
+                                           int blank, float eps, float gscale, int S2, bool dead, float* __restrict__ dLogits) {
   const int b = cs_.b, Tp = cs_.Tp, L = cs_.L;
   float *ALb = cs_.ALb, *BEb = cs_.BEb;
   int* s_lab = cs_.s_lab;
-  float* s_logp = cs_.s_logp;
-  // ---- phase 2: gradient ------------------------------------------------------------------------------
-  const float logp = *s_logp;
   float* occ = smem + (size_t)tid * (C + 1);
-  for (int f = tid; f < T; f += 256) {
-    float* out = dLogits + ((size_t)b * T + f) * C;
-    int tt = f - skip;
-    if (tt < 0 || tt >= Tp || logp == kNegInf) {
-      for (int c = 0; c < C; ++c) out[c] = 0.f;
-      continue;
-    }
-    for (int c = 0; c < C; ++c) occ[c] = 0.f;
-    const float* ar = ALb + ab_off(tt, S2);
-    const float* br = BEb + ab_off(tt, S2);
-    float vmax = kNegInf;
-    for (int p = 0; p <= L; ++p) {
-      float2 a = *reinterpret_cast<const float2*>(ar + 4 * p);
-      float2 be = *reinterpret_cast<const float2*>(br + 4 * p);
-      vmax = fmaxf(vmax, a.x + be.x);
-      if (p < L) vmax = fmaxf(vmax, a.y + be.y);
-    }
-    float den = 0.f;
-    for (int p = 0; p <= L; ++p) {
-      float2 a = *reinterpret_cast<const float2*>(ar + 4 * p);
-      float2 be = *reinterpret_cast<const float2*>(br + 4 * p);
-      float wb = exp2_raw(a.x + be.x - vmax);
-      occ[blank] += wb;
-      den += wb;
-      if (p < L) {
-        float wl = exp2_raw(a.y + be.y - vmax);
-        occ[s_lab[p]] += wl;
-        den += wl;
-      }
-    }
-    const float iden = 1.f / den;  // sum_u alpha*beta = p(l|x) for every t: normalise by the frame's own sum
-    const float* row = P + ((size_t)b * T + f) * C;
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) s += row[c] + eps;
-    float inv = 1.f / s;
-    float dot = 0.f;
-    for (int c = 0; c < C; ++c) {
-      float u = row[c] + eps;
-      float gp = (u * inv - occ[c] * iden) / u;
-      occ[c] = gp;
-      dot += row[c] * gp;
-    }
-    for (int c = 0; c < C; ++c) out[c] = row[c] * (occ[c] - dot) * gscale;
+  const int f = blk * 256 + tid;
+  if (f >= T) return;
+  float* out = dLogits + ((size_t)b * T + f) * C;
+  const int tt = f - skip;
+  if (tt < 0 || tt >= Tp || dead) {   // (dead: p(l|x) = 0 - no alignment fits - or no frames at all: the loss is +inf, the gradient zero)
+    for (int c = 0; c < C; ++c) out[c] = 0.f;
+    return;
   }
+  for (int c = 0; c < C; ++c) occ[c] = 0.f;
+  const float* ar = ALb + ab_off(tt, S2);
+  const float* br = BEb + ab_off(tt, S2);
+  float vmax = kNegInf;
+  for (int p = 0; p <= L; ++p) {
+    float2 a = *reinterpret_cast<const float2*>(ar + 4 * p);
+    float2 be = *reinterpret_cast<const float2*>(br + 4 * p);
+    vmax = fmaxf(vmax, a.x + be.x);
+    if (p < L) vmax = fmaxf(vmax, a.y + be.y);
+  }
+  float den = 0.f;
+  for (int p = 0; p <= L; ++p) {
+    float2 a = *reinterpret_cast<const float2*>(ar + 4 * p);
+    float2 be = *reinterpret_cast<const float2*>(br + 4 * p);
+    float wb = exp2_raw(a.x + be.x - vmax);
+    occ[blank] += wb;
+    den += wb;
+    if (p < L) {
+      float wl = exp2_raw(a.y + be.y - vmax);
+      occ[s_lab[p]] += wl;
+      den += wl;
+    }
+  }
+  const float iden = 1.f / den;  // sum_u alpha*beta = p(l|x) for every t: normalise by the frame's own sum
+  const float* row = P + ((size_t)b * T + f) * C;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += row[c] + eps;
+  float inv = 1.f / s;
+  float dot = 0.f;
+  for (int c = 0; c < C; ++c) {
+    float u = row[c] + eps;
+    float gp = (u * inv - occ[c] * iden) / u;
+    occ[c] = gp;
+    dot += row[c] * gp;
+  }
+  for (int c = 0; c < C; ++c) out[c] = row[c] * (occ[c] - dot) * gscale;
 }
 
-// SPW = samples per workgroup.  1: wave 0 = alpha, wave 1 = beta of the workgroup's sample (waves 2, 3 idle in phase 1).  2 (round 6):
-// waves 0, 1 run the chains of sample 2 j, waves 2, 3 those of sample 2 j + 1 - one chain per SIMD.  In the training step the kernel runs
-// on the 48 CUs the fused encoder scans leave: 64 one-sample workgroups there put two on 16 CUs, whose alpha (beta) waves then SHARE a
-// SIMD, and every chain of the launch waits for those (0.97 ms in the step for 0.55 alone); 32 two-sample workgroups have a CU each.
-// Phases 0 and 2 run the workgroup's samples one after the other (microseconds against the chains' half millisecond).
+// One sample's slices of the workspace and its clipped lengths.  s_lab: the sample's label row in the workgroup's LDS (or null).
+__device__ __forceinline__ CtcSample ctc_sample(int b, int B, const int32_t* __restrict__ input_len, const int32_t* __restrict__ label_len, int To,
+                                                int C, int Lmax, float* LY, float* AL, float* BE, int* s_lab) {
+  CtcSample s_;
+  s_.b = b < B ? b : -1;
+  const int bc = b < B ? b : B - 1;
+  const int S2 = 2 * (Lmax + 1);
+  const size_t TS = ctc_ts(To);
+  int Tp = input_len[bc];
+  s_.Tp = Tp < 0 ? 0 : (Tp > To ? To : Tp);
+  int L = label_len[bc];
+  s_.L = L < 0 ? 0 : (L > Lmax ? Lmax : L);
+  s_.LYTb = LY + (size_t)bc * 2 * C * TS;           // [C][TS]: y(t, c) at c * TS + t + 3
+  s_.LYRb = s_.LYTb + (size_t)C * TS;               // [C][TS]: y(Tp - 1 - r, c) at c * TS + r
+  s_.ALb = AL + (size_t)bc * (To + 1) * S2;
+  s_.BEb = BE + (size_t)bc * (To + 1) * S2;
+  s_.s_lab = s_lab;
+  s_.s_logp = nullptr;
+  return s_;
+}
+
+// Three kernels (round 6; one kernel with three phases before): the emissions and the gradient are one independent piece of work per
+// FRAME - 121,600 of them at config F's shape - and ran on the 256 threads of the workgroup that owns the sample's two chains, one sample
+// after the other: 0.09 + 0.20 ms of the kernel's 0.56, for microseconds of work once every frame has a thread of its own.
+//
+// k_ctc_emissions: grid (ceil(To / 256), B) - phase 0.
+__global__ __launch_bounds__(256) void k_ctc_emissions(const float* __restrict__ P, const int32_t* __restrict__ input_len,
+                                                       const int32_t* __restrict__ label_len, int B, int T, int C, int Lmax, int skip, float eps,
+                                                       float* __restrict__ LY) {
+  const CtcSample s_ = ctc_sample((int)blockIdx.y, B, input_len, label_len, T - skip, C, Lmax, LY, nullptr, nullptr, nullptr);
+  ctc_phase0(s_, threadIdx.x, (int)blockIdx.x, P, T, C, skip, eps, ctc_ts(T - skip));
+}
+
+// k_ctc_chains - phase 1.  SPW = samples per workgroup.  1: wave 0 = alpha, wave 1 = beta of the workgroup's sample (128 threads).  2: waves
+// 0, 1 run the chains of sample 2 j, waves 2, 3 those of sample 2 j + 1 - one chain per SIMD.  In the training step the kernel runs on
+// the 48 CUs the fused encoder scans leave: 64 one-sample workgroups there put two on 16 CUs, whose alpha (beta) waves then SHARE a SIMD,
+// and every chain of the launch waits for those (0.97 ms in the step for 0.55 alone); 32 two-sample workgroups have a CU each.
 template <int PPL, int SPW>
-__global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const int32_t* __restrict__ labels,
-                                             const int32_t* __restrict__ input_len,
-                                             const int32_t* __restrict__ label_len, int B, int T, int C, int Lmax,
-                                             int skip, int blank, float eps, float gscale, float* __restrict__ loss,
-                                             float* __restrict__ dLogits, float* __restrict__ LY,
-                                             float* __restrict__ AL, float* __restrict__ BE) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [256][C+1] occupancy rows, then SPW label rows, then SPW words
+__global__ __launch_bounds__(128 * SPW) void k_ctc_chains(const int32_t* __restrict__ labels, const int32_t* __restrict__ input_len,
+                                                          const int32_t* __restrict__ label_len, int B, int T, int C, int Lmax, int skip, int blank,
+                                                          float* __restrict__ loss, float* __restrict__ LY, float* __restrict__ AL,
+                                                          float* __restrict__ BE) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // SPW label rows, then SPW words
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -416,49 +447,35 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ P, const 
   const int S2 = 2 * (Lmax + 1);
   const size_t TS = ctc_ts(To);
   auto sample = [&](int si) {
-    CtcSample s_;
-    const int b = (int)blockIdx.x * SPW + si;
-    s_.b = b < B ? b : -1;
-    const int bc = b < B ? b : B - 1;
-    int Tp = input_len[bc];
-    s_.Tp = Tp < 0 ? 0 : (Tp > To ? To : Tp);
-    int L = label_len[bc];
-    s_.L = L < 0 ? 0 : (L > Lmax ? Lmax : L);
-    s_.LYTb = LY + (size_t)bc * 2 * C * TS;           // [C][TS]: y(t, c) at c * TS + t + 3
-    s_.LYRb = s_.LYTb + (size_t)C * TS;               // [C][TS]: y(Tp - 1 - r, c) at c * TS + r
-    s_.ALb = AL + (size_t)bc * (To + 1) * S2;
-    s_.BEb = BE + (size_t)bc * (To + 1) * S2;
-    s_.s_lab = reinterpret_cast<int*>(smem + 256 * (C + 1)) + si * (Lmax + 1);
-    s_.s_logp = reinterpret_cast<float*>(reinterpret_cast<int*>(smem + 256 * (C + 1)) + SPW * (Lmax + 1)) + si;
+    CtcSample s_ = ctc_sample((int)blockIdx.x * SPW + si, B, input_len, label_len, To, C, Lmax, LY, AL, BE,
+                              reinterpret_cast<int*>(smem) + si * (Lmax + 1));
+    s_.s_logp = reinterpret_cast<float*>(reinterpret_cast<int*>(smem) + SPW * (Lmax + 1)) + si;
     return s_;
   };
-#pragma unroll
-  for (int si = 0; si < SPW; ++si) {
-    const CtcSample s_ = sample(si);
-    if (s_.b >= 0) ctc_phase0(s_, tid, P, labels, T, C, Lmax, skip, eps, TS);
+  {
+    const CtcSample s_ = sample(wave >> 1);
+    if (s_.b >= 0) ctc_labels(s_, tid & 127, 128, labels, C, Lmax);
   }
   __syncthreads();
   {
-    const int si = SPW == 2 ? wave >> 1 : 0, role = SPW == 2 ? (wave & 1) : wave;
-    const CtcSample s_ = sample(si);
-    if (s_.b >= 0) ctc_phase1<PPL>(s_, role, lane, blank, Lmax, S2, TS, loss);
+    const CtcSample s_ = sample(wave >> 1);
+    if (s_.b >= 0) ctc_phase1<PPL>(s_, wave & 1, lane, blank, Lmax, S2, TS, loss);
+    if (s_.b >= 0 && s_.Tp == 0 && (tid & 127) == 0) loss[s_.b] = __builtin_huge_valf();
   }
-#pragma unroll
-  for (int si = 0; si < SPW; ++si) {
-    const CtcSample s_ = sample(si);
-    if (s_.b >= 0 && s_.Tp == 0 && tid == 0) {
-      loss[s_.b] = __builtin_huge_valf();
-      *s_.s_logp = kNegInf;
-    }
-  }
+}
+
+// k_ctc_grad: grid (ceil(T / 256), B) - phase 2.
+__global__ __launch_bounds__(256) void k_ctc_grad(const float* __restrict__ P, const int32_t* __restrict__ labels,
+                                                  const int32_t* __restrict__ input_len, const int32_t* __restrict__ label_len, int B, int T, int C,
+                                                  int Lmax, int skip, int blank, float eps, float gscale, const float* __restrict__ loss,
+                                                  float* __restrict__ dLogits, float* __restrict__ AL, float* __restrict__ BE) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [256][C+1] occupancy rows, then the label row
+  const CtcSample s_ = ctc_sample((int)blockIdx.y, B, input_len, label_len, T - skip, C, Lmax, nullptr, AL, BE,
+                                  reinterpret_cast<int*>(smem + 256 * (C + 1)));
+  ctc_labels(s_, threadIdx.x, 256, labels, C, Lmax);
   __syncthreads();
-  if (dLogits == nullptr) return;
-#pragma unroll
-  for (int si = 0; si < SPW; ++si) {
-    const CtcSample s_ = sample(si);
-    if (s_.b >= 0) ctc_phase2(s_, tid, smem, P, T, C, skip, blank, eps, gscale, S2, dLogits);
-    if (SPW == 2) __syncthreads();   // (the occupancy rows of the next sample reuse the same LDS)
-  }
+  const bool dead = loss[s_.b] == __builtin_huge_valf();
+  ctc_phase2(s_, threadIdx.x, (int)blockIdx.x, smem, P, T, C, skip, blank, eps, gscale, 2 * (Lmax + 1), dead, dLogits);
 }
 
 }  // namespace
@@ -488,19 +505,43 @@ int mgr_ctc_loss_grad(mgr_ctx* c, const float* P, const int32_t* labels, const i
   float* BE = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ly + ab);
   // two samples per workgroup (one chain per SIMD) from B = 2 on; tune key 18 = 1: one sample per workgroup (rounds 1 - 5)
   const int spw = (B >= 2 && c->tune[18] == 0) ? 2 : 1;
-  size_t lds = (size_t)256 * (C + 1) * sizeof(float) + (size_t)spw * (Lmax + 1) * sizeof(int) + 16;
-  MGR_REQUIRE(lds <= 160 * 1024, "C=%d too large for the LDS occupancy tile", C);
+  size_t lds_grad = (size_t)256 * (C + 1) * sizeof(float) + (size_t)(Lmax + 1) * sizeof(int);
+  size_t lds_chains = (size_t)spw * (Lmax + 1) * sizeof(int) + 16, lds_emis = 0;
+  MGR_REQUIRE(lds_grad <= 160 * 1024, "C=%d too large for the LDS occupancy tile", C);
+  // tune keys 20 / 21 = KiB of LDS the recurrence / the per-frame kernels ask for at least.  Placement: a workgroup that asks for more
+  // than a persistent scan workgroup leaves on its CU can only land on a CU without one (the engine sets them for the steps of its
+  // fused schedule, where this call runs beside 208 whole-CU scan workgroups: 96 KiB = the 32 recurrence workgroups on a CU each)
+  if (c->tune[20] > 0 && lds_chains < (size_t)c->tune[20] * 1024) lds_chains = (size_t)c->tune[20] * 1024;
+  if (c->tune[21] > 0) {
+    if (lds_grad < (size_t)c->tune[21] * 1024) lds_grad = (size_t)c->tune[21] * 1024;
+    lds_emis = (size_t)c->tune[21] * 1024;
+  }
+  if (!(c->attr_done & 128u)) {
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_emissions), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_grad), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_chains<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_chains<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_chains<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_chains<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_chains<3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_chains<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_chains<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ctc_chains<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    c->attr_done |= 128u;
+  }
   int npairs = Lmax + 1;
   int ppl = (npairs + 63) / 64;
+  hipStream_t s = mgr_stream(c);
   mgr_prof_begin(c, MGR_K_CTC);
-#define MGR_CTC_LAUNCH(N)                                                                                                            \
-  do {                                                                                                                               \
-    if (spw == 2)                                                                                                                    \
-      hipLaunchKernelGGL((k_ctc<N, 2>), dim3((B + 1) / 2), dim3(256), lds, mgr_stream(c), P, labels, input_len, label_len, B, T, C,  \
-                         Lmax, skip, blank, eps, gscale, loss, dLogits, LY, AL, BE);                                                 \
-    else                                                                                                                             \
-      hipLaunchKernelGGL((k_ctc<N, 1>), dim3(B), dim3(256), lds, mgr_stream(c), P, labels, input_len, label_len, B, T, C, Lmax,      \
-                         skip, blank, eps, gscale, loss, dLogits, LY, AL, BE);                                                       \
+  hipLaunchKernelGGL(k_ctc_emissions, dim3((unsigned)((To + 255) / 256), B), dim3(256), lds_emis, s, P, input_len, label_len, B, T, C, Lmax, skip, eps, LY);
+#define MGR_CTC_LAUNCH(N)                                                                                                              \
+  do {                                                                                                                                 \
+    if (spw == 2)                                                                                                                      \
+      hipLaunchKernelGGL((k_ctc_chains<N, 2>), dim3((B + 1) / 2), dim3(256), lds_chains, s, labels, input_len, label_len, B, T, C, Lmax, \
+                         skip, blank, loss, LY, AL, BE);                                                                               \
+    else                                                                                                                               \
+      hipLaunchKernelGGL((k_ctc_chains<N, 1>), dim3(B), dim3(128), lds_chains, s, labels, input_len, label_len, B, T, C, Lmax, skip,   \
+                         blank, loss, LY, AL, BE);                                                                                     \
   } while (0)
   switch (ppl) {
     case 1: MGR_CTC_LAUNCH(1); break;
@@ -509,6 +550,9 @@ int mgr_ctc_loss_grad(mgr_ctx* c, const float* P, const int32_t* labels, const i
     default: MGR_CTC_LAUNCH(4); break;
   }
 #undef MGR_CTC_LAUNCH
+  if (dLogits)
+    hipLaunchKernelGGL(k_ctc_grad, dim3((unsigned)((T + 255) / 256), B), dim3(256), lds_grad, s, P, labels, input_len, label_len, B, T, C, Lmax, skip,
+                       blank, eps, gscale, loss, dLogits, AL, BE);
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_CTC);
   return 0;

@@ -811,23 +811,32 @@ class Engine:
     _early_gen = None        # _next_encoders_free generator of the batch after next, its first part already enqueued
     _beside_scans = False    # the fusion layer's GEMMs of the step being enqueued run beside encoder scans of the next batch
 
-    def _narrow_tiles(self, on):
-        """Context manager: the pre-split products enqueued inside take their 4-wave forms (tune key 12 = 1, mgr.h)."""
+    def _tuned(self, on, keys, keep_set=False):
+        """Context manager: the library calls enqueued inside run with the tune keys `keys` ({key: value}, mgr.h); a caller's own
+        settings - bench.py --tune ... - come back afterwards (keep_set: and are not overridden where they are non-zero)."""
         eng = self
 
         class _Ctx:
             def __enter__(self_):
+                self_.old = {}
                 if on:
-                    v = C.c_int()
-                    eng.dev.call("mgr_tune_get", 12, C.byref(v))
-                    self_.old = v.value      # (a caller's own setting - bench.py --tune 12=... - comes back afterwards)
-                    eng.dev.call("mgr_tune", 12, 1)
+                    for k, val in keys.items():
+                        v = C.c_int()
+                        eng.dev.call("mgr_tune_get", k, C.byref(v))
+                        if keep_set and v.value != 0:
+                            continue
+                        self_.old[k] = v.value
+                        eng.dev.call("mgr_tune", k, val)
 
             def __exit__(self_, *exc):
-                if on:
-                    eng.dev.call("mgr_tune", 12, self_.old)
+                for k, val in self_.old.items():
+                    eng.dev.call("mgr_tune", k, val)
                 return False
         return _Ctx()
+
+    def _narrow_tiles(self, on):
+        """Context manager: the pre-split products enqueued inside take their 4-wave forms (tune key 12 = 1, mgr.h)."""
+        return self._tuned(on, {12: 1})
 
     def _new_seq_word(self):
         """Address of a zeroed page-locked word: a launch number on its way from the launch (mgr_scan_launch_opts.seq_out) to the
@@ -1452,10 +1461,14 @@ class Engine:
         else:
             dA, ldda = 0, D
         # the whole head in one call (mgr.h): Dropout / Dense / softmax, CTC loss + gradient, the mean loss, Dense backward
-        dev.call("mgr_head_fwd_bwd", feat, ldf, hm, p_head, C.c_uint64(hseed), self._wview("dense/W"), self._wview("dense/b"),
-                 self.labels_d, self.ilen_d, self.llen_d, B, T, D, Cn, self.Lmax, int(sp.ctc["skip"]), Cn - 1, float(sp.ctc["eps"]),
-                 1.0 / B, self.P, self.loss_b, self.loss_mean, self.dLogits, self._gview("dense/W"), self._gview("dense/b"),
-                 dA, ldda, self.ws_head, self.ws_head.nbytes)
+        # (a step of the fused schedule: the head runs beside the next batch's deepest encoder scan - 208 whole CUs.  The CTC kernels ask
+        #  for more LDS than a scan workgroup leaves on its CU - tune keys 20 / 21, mgr.h - so that the 32 recurrence workgroups get one of
+        #  the 48 other CUs each, and neither they nor the per-frame kernels share SIMDs with the scan, which is on the step's critical path)
+        with self._tuned(self._gate_words[0] is not None or self._gate_words[1] is not None, {20: 96, 21: 64}, keep_set=True):
+            dev.call("mgr_head_fwd_bwd", feat, ldf, hm, p_head, C.c_uint64(hseed), self._wview("dense/W"), self._wview("dense/b"),
+                     self.labels_d, self.ilen_d, self.llen_d, B, T, D, Cn, self.Lmax, int(sp.ctc["skip"]), Cn - 1, float(sp.ctc["eps"]),
+                     1.0 / B, self.P, self.loss_b, self.loss_mean, self.dLogits, self._gview("dense/W"), self._gview("dense/b"),
+                     dA, ldda, self.ws_head, self.ws_head.nbytes)
         if self.comm is not None:
             dev.call("mgr_mean", self.loss_b, B, self.loss_slot)   # travels with the gradient all-reduce (apply_gradients)
         dev.record(self.EV_LAB[self._lab_slot])
