@@ -77,13 +77,12 @@ __host__ __device__ inline size_t ctc_ts(int To) { return ((size_t)To + 24 + 3) 
 // alpha / beta rows, two time steps per block: element (t, state 2p + e) at  (t >> 1) * 2 S2 + 4 p + 2 (t & 1) + e
 __device__ __forceinline__ size_t ab_off(int t, int S2) { return (size_t)(t >> 1) * (2 * S2) + 2 * (t & 1); }
 
-// One sample's three phases as functions (round 6): the kernel runs ONE or TWO samples per workgroup.
-// Per-sample state of a workgroup: which sample, its clipped lengths, its slices of the workspace, its labels in LDS.
+// One sample's three phases as functions (the recurrence kernel runs ONE or TWO samples per workgroup).
+// Per-sample state: which sample, its clipped lengths, its slices of the workspace, its labels in the workgroup's LDS.
 struct CtcSample {
   int b, Tp, L;
   float *LYTb, *LYRb, *ALb, *BEb;
   int* s_lab;
-  float* s_logp;
 };
 
 // the sample's labels into the workgroup's LDS (clipped into the class range)
@@ -131,7 +130,6 @@ __device__ __forceinline__ void ctc_phase1(const CtcSample& cs_, int role, int l
   const int b = cs_.b, Tp = cs_.Tp, L = cs_.L;
   float *LYTb = cs_.LYTb, *LYRb = cs_.LYRb, *ALb = cs_.ALb, *BEb = cs_.BEb;
   int* s_lab = cs_.s_lab;
-  float* s_logp = cs_.s_logp;
   if (role < 2 && Tp > 0) {
     int lab[PPL];
     bool vl[PPL], vb[PPL], cs[PPL];
@@ -248,8 +246,8 @@ __device__ __forceinline__ void ctc_phase1(const CtcSample& cs_, int role, int l
       }
       float lfin = lse2(fb, fl);
       if (lane == 0) {
+        // (+inf: no alignment fits - what k_ctc_grad reads as "no gradient")
         loss[b] = (lfin == kNegInf) ? __builtin_huge_valf() : (float)(-((double)lfin + coff) * kLn2);
-        *s_logp = lfin;  // only its finiteness is used below
       }
     } else {
       float bb[PPL], bl[PPL];
@@ -414,7 +412,6 @@ __device__ __forceinline__ CtcSample ctc_sample(int b, int B, const int32_t* __r
   s_.ALb = AL + (size_t)bc * (To + 1) * S2;
   s_.BEb = BE + (size_t)bc * (To + 1) * S2;
   s_.s_lab = s_lab;
-  s_.s_logp = nullptr;
   return s_;
 }
 
@@ -425,8 +422,8 @@ __device__ __forceinline__ CtcSample ctc_sample(int b, int B, const int32_t* __r
 // k_ctc_emissions: grid (ceil(To / 256), B) - phase 0.
 __global__ __launch_bounds__(256) void k_ctc_emissions(const float* __restrict__ P, const int32_t* __restrict__ input_len,
                                                        const int32_t* __restrict__ label_len, int B, int T, int C, int Lmax, int skip, float eps,
-                                                       float* __restrict__ LY) {
-  const CtcSample s_ = ctc_sample((int)blockIdx.y, B, input_len, label_len, T - skip, C, Lmax, LY, nullptr, nullptr, nullptr);
+                                                       float* __restrict__ LY, float* __restrict__ AL, float* __restrict__ BE) {
+  const CtcSample s_ = ctc_sample((int)blockIdx.y, B, input_len, label_len, T - skip, C, Lmax, LY, AL, BE, nullptr);
   ctc_phase0(s_, threadIdx.x, (int)blockIdx.x, P, T, C, skip, eps, ctc_ts(T - skip));
 }
 
@@ -439,7 +436,7 @@ __global__ __launch_bounds__(128 * SPW) void k_ctc_chains(const int32_t* __restr
                                                           const int32_t* __restrict__ label_len, int B, int T, int C, int Lmax, int skip, int blank,
                                                           float* __restrict__ loss, float* __restrict__ LY, float* __restrict__ AL,
                                                           float* __restrict__ BE) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // SPW label rows, then SPW words
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // SPW label rows
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -447,10 +444,8 @@ __global__ __launch_bounds__(128 * SPW) void k_ctc_chains(const int32_t* __restr
   const int S2 = 2 * (Lmax + 1);
   const size_t TS = ctc_ts(To);
   auto sample = [&](int si) {
-    CtcSample s_ = ctc_sample((int)blockIdx.x * SPW + si, B, input_len, label_len, To, C, Lmax, LY, AL, BE,
-                              reinterpret_cast<int*>(smem) + si * (Lmax + 1));
-    s_.s_logp = reinterpret_cast<float*>(reinterpret_cast<int*>(smem) + SPW * (Lmax + 1)) + si;
-    return s_;
+    return ctc_sample((int)blockIdx.x * SPW + si, B, input_len, label_len, To, C, Lmax, LY, AL, BE,
+                      reinterpret_cast<int*>(smem) + si * (Lmax + 1));
   };
   {
     const CtcSample s_ = sample(wave >> 1);
@@ -468,9 +463,10 @@ __global__ __launch_bounds__(128 * SPW) void k_ctc_chains(const int32_t* __restr
 __global__ __launch_bounds__(256) void k_ctc_grad(const float* __restrict__ P, const int32_t* __restrict__ labels,
                                                   const int32_t* __restrict__ input_len, const int32_t* __restrict__ label_len, int B, int T, int C,
                                                   int Lmax, int skip, int blank, float eps, float gscale, const float* __restrict__ loss,
-                                                  float* __restrict__ dLogits, float* __restrict__ AL, float* __restrict__ BE) {
+                                                  float* __restrict__ dLogits, float* __restrict__ LY, float* __restrict__ AL,
+                                                  float* __restrict__ BE) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [256][C+1] occupancy rows, then the label row
-  const CtcSample s_ = ctc_sample((int)blockIdx.y, B, input_len, label_len, T - skip, C, Lmax, nullptr, AL, BE,
+  const CtcSample s_ = ctc_sample((int)blockIdx.y, B, input_len, label_len, T - skip, C, Lmax, LY, AL, BE,
                                   reinterpret_cast<int*>(smem + 256 * (C + 1)));
   ctc_labels(s_, threadIdx.x, 256, labels, C, Lmax);
   __syncthreads();
@@ -533,7 +529,7 @@ int mgr_ctc_loss_grad(mgr_ctx* c, const float* P, const int32_t* labels, const i
   int ppl = (npairs + 63) / 64;
   hipStream_t s = mgr_stream(c);
   mgr_prof_begin(c, MGR_K_CTC);
-  hipLaunchKernelGGL(k_ctc_emissions, dim3((unsigned)((To + 255) / 256), B), dim3(256), lds_emis, s, P, input_len, label_len, B, T, C, Lmax, skip, eps, LY);
+  hipLaunchKernelGGL(k_ctc_emissions, dim3((unsigned)((To + 255) / 256), B), dim3(256), lds_emis, s, P, input_len, label_len, B, T, C, Lmax, skip, eps, LY, AL, BE);
 #define MGR_CTC_LAUNCH(N)                                                                                                              \
   do {                                                                                                                                 \
     if (spw == 2)                                                                                                                      \
@@ -552,7 +548,7 @@ int mgr_ctc_loss_grad(mgr_ctx* c, const float* P, const int32_t* labels, const i
 #undef MGR_CTC_LAUNCH
   if (dLogits)
     hipLaunchKernelGGL(k_ctc_grad, dim3((unsigned)((T + 255) / 256), B), dim3(256), lds_grad, s, P, labels, input_len, label_len, B, T, C, Lmax, skip,
-                       blank, eps, gscale, loss, dLogits, AL, BE);
+                       blank, eps, gscale, loss, dLogits, LY, AL, BE);
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_CTC);
   return 0;
