@@ -231,7 +231,7 @@ int mgr_lstm_scan_fwd_multi_ex(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs
                                const mgr_scan_launch_opts* opts);
 /* ABI guard for bindings that fill mgr_scan_job / mgr_scan_bwd_job / mgr_scan_launch_opts field by field: the sizes the LIBRARY was
  * built with (round 5 appended mgr_scan_bwd_job.dzmax and turned mgr_scan_job's reserved word into yt_split; revision 7 appended
- * mgr_scan_bwd_job.dbsum and the dbsum argument of mgr_lstm_param_grads_dropout_ts - a caller built against
+ * mgr_scan_bwd_job.dbsum and the dbsum / proj_ws arguments of mgr_lstm_param_grads_dropout_ts - a caller built against
  * an older header must not pass its structs to this library).  out[0..2] = sizeof of the three structs, out[3] =
  * MGR_ABI_REVISION. */
 #define MGR_ABI_REVISION 7
@@ -403,10 +403,12 @@ size_t mgr_lstm_param_grads_dropout_ts_ws_bytes(int B, int T, int F, int H, int 
 int mgr_lstm_param_grads_dropout_ts(mgr_ctx* ctx, const float* XS, int ldt, const float* mask4, float drop_rate,
                                     const float* Hs, int ldh, const float* dZ, float* dWp, float* dUp, float* dbp, int B,
                                     int T, int F, int H, int reverse, void* ws, size_t ws_bytes, const unsigned* dzmax,
-                                    const float* dbsum);
+                                    const float* dbsum, const void* proj_ws);
 /* (dzmax: the row maxima of dZ if the BPTT left them - mgr_scan_bwd_job.dzmax - or NULL: this call finds them with one more pass.
  *  dbsum: the per-sample sums of dZ over time if the BPTT left them - mgr_scan_bwd_job.dbsum - then db = their sum over the samples in
- *  sample order; or NULL: db from a pass over dZ, as in mgr_lstm_param_grads.) */
+ *  sample order; or NULL: db from a pass over dZ, as in mgr_lstm_param_grads.
+ *  proj_ws: the workspace of the mgr_lstm_input_proj_dropout_ts call that projected with the SAME mask4 (same B, F, H), untouched since -
+ *  its kept lists are used instead of being built again; or NULL.) */
 /* dX[b,t,0:F] (stride lddx) (+)= sum_g mask4[g] (.) (dZ_g . W_g^T); accumulate=1 adds into dX. */
 int mgr_lstm_input_grad(mgr_ctx* ctx, const float* dZ, const float* Wp, const float* mask4, float* dX,
                         int lddx, int accumulate, int B, int T, int F, int H);

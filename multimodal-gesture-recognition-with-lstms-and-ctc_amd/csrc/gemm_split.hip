@@ -632,9 +632,12 @@ static int fp32_of(int F) { return (F + PS_SK - 1) / PS_SK * PS_SK; }
 
 extern "C" {
 
+// workspace of the projection: kept lists [4B][Fp32] | counts [4B] | words | weight planes | list positions [4B][F] (the last for
+// mgr_lstm_param_grads_dropout_ts, which may take its lists from the projection of the same mask instead of building them again)
+static size_t proj_ts_planes_bytes(int F, int H) { return mgr_align_up((size_t)4 * (F + 1) * 2 * hp_of(H) * sizeof(_Float16), 256); }
 size_t mgr_lstm_input_proj_dropout_ts_ws_bytes(int B, int F, int H) {
   return mgr_align_up((size_t)4 * B * fp32_of(F) * sizeof(int), 256) + mgr_align_up((size_t)4 * B * sizeof(int), 256) + 256 +
-         mgr_align_up((size_t)4 * (F + 1) * 2 * hp_of(H) * sizeof(_Float16), 256);
+         proj_ts_planes_bytes(F, H) + mgr_align_up((size_t)4 * B * F * sizeof(int), 256);
 }
 
 int mgr_lstm_input_proj_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const float* mask4, float drop_rate, const float* Wp,
@@ -655,6 +658,8 @@ int mgr_lstm_input_proj_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const f
   unsigned* words = reinterpret_cast<unsigned*>(w);   // [0] largest |W|, [1] the mask factor
   w += 256;
   _Float16* WSp = reinterpret_cast<_Float16*>(w);
+  w += proj_ts_planes_bytes(F, H);
+  int* kpos = reinterpret_cast<int*>(w);
   hipStream_t s = mgr_stream(c);
   if (!(c->attr_done & 16u)) {
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_split<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PsCfg<2>::LDS));
@@ -675,7 +680,7 @@ int mgr_lstm_input_proj_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const f
     }
   }
   MGR_HIP(hipMemsetAsync(words + (cached ? 1 : 0), 0, (cached ? 1 : 2) * sizeof(unsigned), s));
-  hipLaunchKernelGGL(k_lists32, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp32, lists, kcnt, (int*)nullptr, words + 1);
+  hipLaunchKernelGGL(k_lists32, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp32, lists, kcnt, kpos, words + 1);
   if (!cached) {
     const size_t n4 = (size_t)F * H;
     hipLaunchKernelGGL(k_wmax, dim3((int)((n4 + 255) / 256 < 256 ? (n4 + 255) / 256 : 256)), dim3(256), 0, s, Wp, n4, words);
@@ -715,7 +720,7 @@ size_t mgr_lstm_param_grads_dropout_ts_ws_bytes(int B, int T, int F, int H, int 
 
 int mgr_lstm_param_grads_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const float* mask4, float drop_rate, const float* Hs, int ldh,
                                     const float* dZ, float* dWp, float* dUp, float* dbp, int B, int T, int F, int H, int reverse,
-                                    void* ws, size_t ws_bytes, const unsigned* dzmax, const float* dbsum) {
+                                    void* ws, size_t ws_bytes, const unsigned* dzmax, const float* dbsum, const void* proj_ws) {
   MGR_REQUIRE(c && XS && mask4 && Hs && dZ && dWp && dUp && dbp, "null argument");
   MGR_REQUIRE(B > 0 && T > 0 && H > 0 && F >= 16 && F <= 2048 && ldh >= H, "bad shape (16 <= F <= 2048)");
   MGR_REQUIRE(ldt % 32 == 0 && ldt >= (T + DW_TK - 1) / DW_TK * DW_TK, "the split copy must be padded to whole stages of %d time steps (ldt %d, T %d)", DW_TK, ldt, T);
@@ -748,8 +753,21 @@ int mgr_lstm_param_grads_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const 
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dw_split<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * DW_STAGE));
     c->attr_done |= 32u;
   }
-  MGR_HIP(hipMemsetAsync(words, 0, 2 * sizeof(unsigned), s));
-  hipLaunchKernelGGL(k_lists32, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp32, lists, kcnt, kpos, words + 1);
+  if (proj_ws) {
+    // the lists, counts, list positions and the mask factor the projection of the SAME mask left in its workspace (the layout of
+    // mgr_lstm_input_proj_dropout_ts above): nothing to build
+    char* pw = reinterpret_cast<char*>(const_cast<void*>(proj_ws));
+    lists = reinterpret_cast<int*>(pw);
+    pw += mgr_align_up((size_t)4 * B * Fp32 * sizeof(int), 256);
+    kcnt = reinterpret_cast<int*>(pw);
+    pw += mgr_align_up((size_t)4 * B * sizeof(int), 256);
+    words = reinterpret_cast<unsigned*>(pw);
+    pw += 256 + proj_ts_planes_bytes(F, H);
+    kpos = reinterpret_cast<int*>(pw);
+  } else {
+    MGR_HIP(hipMemsetAsync(words, 0, 2 * sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_lists32, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp32, lists, kcnt, kpos, words + 1);
+  }
   if (!dzmax) hipLaunchKernelGGL(k_rowmax_bt, dim3((N + 63) / 64, B), dim3(256), 0, s, dZ, N, T, reinterpret_cast<unsigned*>(w), (float*)nullptr);
   hipLaunchKernelGGL(k_transpose_split_scaled, dim3((ldt + 63) / 64, (N + 63) / 64, B), dim3(256), 0, s, dZ, N, dZS, ldt, T, zmax);
   const int grid = 8 * ((B + 7) / 8) * 4 * ((Fp32 + DW_BM - 1) / DW_BM) * ((H + DW_BN - 1) / DW_BN);

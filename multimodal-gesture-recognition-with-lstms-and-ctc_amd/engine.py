@@ -67,6 +67,7 @@ class _LstmDir:
         self.Z = None
         self.gates = self.cs = self.dZ = self.dzmax = self.dbsum = None
         self.ws_scan = self.ws_pg = self.ws_sp = None
+        self.lists_mask = 0     # the mask whose kept lists the projection of this step left in ws_sp (0: none)
 
 
 class Schedule:
@@ -584,6 +585,7 @@ class Engine:
                 p = float(Ls[d].p) if masked else 0.0
                 if split:
                     self.dev.call("mgr_lstm_input_proj_dropout_ts", XT, self.ldt, m, p, Wp, bp, Z, B, T, fin, H, ws, ws.nbytes)
+                    Ls[d].lists_mask = m if masked else 0     # (the kept lists of this mask now sit in ws: the dW product of the step reuses them)
                 elif XT is not None:
                     self.dev.call("mgr_lstm_input_proj_dropout_t", XT, self.ldt, m, p, Wp, bp, Z, B, T, fin, H, ws, ws.nbytes, self.XT_BOUND)
                 else:
@@ -1679,9 +1681,12 @@ class Engine:
                 if two:
                     dev.stream(self.PG_STREAM if di == 1 else 0)
                 if mptr and XinT is not None and self._xt_split.get(XinT.ptr, False):
+                    # (the projection of this step left the kept lists of this very mask in its workspace: not built again)
+                    pws = L.ws_sp if (L.ws_sp is not None and L.lists_mask == mptr) else 0
+                    L.lists_mask = 0
                     with self._narrow_tiles(beside_scans and not wide_ok):
                         dev.call("mgr_lstm_param_grads_dropout_ts", XinT, self.ldt, mptr, float(L.p), Hbuf.view(di * H, (1,)), ldh, L.dZ,
-                                 L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes, L.dzmax, L.dbsum)
+                                 L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes, L.dzmax, L.dbsum, pws)
                 elif mptr and XinT is not None and self.lib.mgr_lstm_param_grads_dropout_wants_transposed(
                         dev.ctx, C.c_float(float(L.p)), int(fin)):
                     need = self.lib.mgr_lstm_param_grads_dropout_t_ws_bytes(B, T, fin, H, self.ldt)

@@ -99,19 +99,30 @@ def test_weight_gradient_from_split_rows(device, B, T, F, H, p, reverse):
         gW, gU, gb = dev.empty((F, N)), dev.empty((H, N)), dev.empty((N,))
         gW.upload(np.full((F, N), np.nan, f32))
         dev.call("mgr_memset", ws, 0xFF, ws.nbytes)          # the workspace arrives dirty
-        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW, gU, gb, B, T, F, H, reverse, ws, ws.nbytes, 0, 0)
+        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW, gU, gb, B, T, F, H, reverse, ws, ws.nbytes, 0, 0, 0)
         # ... and with the row maxima handed in (what the BPTT leaves: mgr_scan_bwd_job.dzmax): the same bits
         zmx = dev.array(np.abs(dZ).max(axis=1).astype(f32).view(np.uint32))
         gW3 = dev.empty((F, N))
-        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW3, gU, gb, B, T, F, H, reverse, ws, ws.nbytes, zmx, 0)
+        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW3, gU, gb, B, T, F, H, reverse, ws, ws.nbytes, zmx, 0, 0)
         assert np.array_equal(gW3.download(), gW.download())
         # ... and with the sums over time handed in (mgr_scan_bwd_job.dbsum): db is their sum over the samples, dW / dU the same bits
         zsm = dev.array(dZ.astype(np.float64).sum(axis=1).astype(f32))
         gU3, gb3 = dev.empty((H, N)), dev.empty((N,))
-        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW3, gU3, gb3, B, T, F, H, reverse, ws, ws.nbytes, zmx, zsm)
+        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW3, gU3, gb3, B, T, F, H, reverse, ws, ws.nbytes, zmx, zsm, 0)
         assert np.array_equal(gW3.download(), gW.download()) and np.array_equal(gU3.download(), gU.download())
         dbref = dZ.astype(np.float64).sum(axis=(0, 1))
         assert np.abs(gb3.download() - dbref).max() <= 2e-6 * np.abs(dZ).sum(axis=(0, 1)).max()
+        # ... and with the kept lists of the PROJECTION of the same mask (proj_ws: the workspace mgr_lstm_input_proj_dropout_ts left
+        # behind) instead of lists of its own: the same bits - with a dirty own workspace, so that nothing stale can be what it reads
+        if p < 0.99:
+            Wp_, bp_, Z_ = dev.array(rng.standard_normal((F, N)).astype(f32)), dev.zeros((N,)), dev.empty((B, T, N))
+            pws = dev.bytes(dev.lib.mgr_lstm_input_proj_dropout_ts_ws_bytes(B, F, H))
+            dev.call("mgr_memset", pws, 0xFF, pws.nbytes)
+            dev.call("mgr_lstm_input_proj_dropout_ts", XS, ldt, dM, p, Wp_, bp_, Z_, B, T, F, H, pws, pws.nbytes)
+            dev.call("mgr_memset", ws, 0xFF, ws.nbytes)
+            gW4 = dev.empty((F, N))
+            dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p, dH, H, ddZ, gW4, gU3, gb3, B, T, F, H, reverse, ws, ws.nbytes, zmx, zsm, pws)
+            assert np.array_equal(gW4.download(), gW.download())
         got = gW.download()
         colscale = np.maximum(np.abs(ref).max(axis=0, keepdims=True), 1e-30)      # per column: the spread is per column
         assert np.all(np.isfinite(got)) and (np.abs(got - ref) / colscale).max() <= 3e-5, (spread, (np.abs(got - ref) / colscale).max())
