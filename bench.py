@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--chain-priority", type=int, default=0, help="Schedule.chain_stream_priority: 1 = stream 0 high, -1 = the encoder stream low")
     ap.add_argument("--pg-two-streams", action="store_true", help="Schedule.param_grads_two_streams: the two directions' dW / dU / db chains on two streams")
     ap.add_argument("--first-pass-inline", action="store_true", help="Schedule.first_pass_on_encoder_stream off: a step without a prefetched pass runs it in line on stream 0 (round 5)")
+    ap.add_argument("--du-f32", action="store_true", help="Schedule.du_split off: dU by the f32 split-K product (rounds 1 - 5)")
     ap.add_argument("--bptt-single-cu", action="store_true", help="Schedule.bptt_single_cu: the fusion layer's BPTT on one CU per (direction, 16-sample group), no inter-CU exchange")
     ap.add_argument("--bptt-fused", action="store_true", help="Schedule.bptt_fused: the fusion layer's BPTT as 32 eight-wave workgroups, a CU each")
     ap.add_argument("--bptt-direct", action="store_true", help="beside fused encoder scans the fusion layer's BPTT takes the direct-gather form (one barrier per step)")
@@ -218,7 +219,7 @@ def main():
     eng = Engine(spec, B, T, Lmax, device=dev, seed=1000 + rank, comm=comm, world=world,
                  schedule=Schedule(transposed_inputs=not args.no_transposed, split_rows=not args.no_split_rows,
                                    deepest_scan_after_fusion_proj=not args.scan_with_fproj, depth1_proj_ahead=not args.no_d1_ahead,
-                                   bptt_yields_beside_scans=not args.bptt_lean, fused_encoder_scans=not args.no_fused_scans, fused_wide_tiles=not args.no_fused_wide, bptt_direct_when_alone=args.bptt_direct, fusion_scan_fused=not args.no_fusion_scan_fused, bptt_fused=args.bptt_fused, chain_stream_priority=args.chain_priority, param_grads_two_streams=args.pg_two_streams, first_pass_on_encoder_stream=not args.first_pass_inline, bptt_single_cu=args.bptt_single_cu))
+                                   bptt_yields_beside_scans=not args.bptt_lean, fused_encoder_scans=not args.no_fused_scans, fused_wide_tiles=not args.no_fused_wide, bptt_direct_when_alone=args.bptt_direct, fusion_scan_fused=not args.no_fusion_scan_fused, bptt_fused=args.bptt_fused, chain_stream_priority=args.chain_priority, param_grads_two_streams=args.pg_two_streams, first_pass_on_encoder_stream=not args.first_pass_inline, bptt_single_cu=args.bptt_single_cu, du_split=not args.du_f32))
     eng.set_weights(synthetic_weights(spec, 20131900 + 3))
     xs, labels, il, ll = synthetic_arrays(spec, B, T, Lmax, 20131900 + 3 + 17 * rank)
     eng._upload_inputs(xs, None, True)

@@ -157,6 +157,8 @@ int mgr_lstm_input_proj_dropout_ts(mgr_ctx* ctx, const float* XS, int ldt, const
                                    size_t ws_bytes);
 /* XS[b][f] = the split row (above) of X[b][0..T)[f], zero for t in [T, ldt); ldt % 8 == 0. */
 int mgr_transpose_bt_split(mgr_ctx* ctx, const float* X, int ldx, float* XS, int ldt, int B, int T, int F);
+/* the same with entry t of a row = X[b, t + tshift, f] (tshift in {-1, 0, 1}; zero where that step does not exist) */
+int mgr_transpose_bt_split_shift(mgr_ctx* ctx, const float* X, int ldx, float* XS, int ldt, int B, int T, int F, int tshift);
 /* Frozen weights: frozen != 0 promises that the contents of Wp (a packed input-weight matrix passed to mgr_lstm_input_proj_dropout_ts) do
  * not change until the next call of this function for the same pointer; the (hi, lo) weight planes and the largest |W| that
  * mgr_lstm_input_proj_dropout_ts leaves in its workspace are then reused by later calls with the same (Wp, workspace, F, H) instead of
@@ -231,7 +233,7 @@ int mgr_lstm_scan_fwd_multi_ex(mgr_ctx* ctx, int njobs, const mgr_scan_job* jobs
                                const mgr_scan_launch_opts* opts);
 /* ABI guard for bindings that fill mgr_scan_job / mgr_scan_bwd_job / mgr_scan_launch_opts field by field: the sizes the LIBRARY was
  * built with (round 5 appended mgr_scan_bwd_job.dzmax and turned mgr_scan_job's reserved word into yt_split; revision 7 appended
- * mgr_scan_bwd_job.dbsum and the dbsum / proj_ws arguments of mgr_lstm_param_grads_dropout_ts - a caller built against
+ * mgr_scan_bwd_job.dbsum and the dbsum / proj_ws / HsT arguments of mgr_lstm_param_grads_dropout_ts - a caller built against
  * an older header must not pass its structs to this library).  out[0..2] = sizeof of the three structs, out[3] =
  * MGR_ABI_REVISION. */
 #define MGR_ABI_REVISION 7
@@ -403,12 +405,15 @@ size_t mgr_lstm_param_grads_dropout_ts_ws_bytes(int B, int T, int F, int H, int 
 int mgr_lstm_param_grads_dropout_ts(mgr_ctx* ctx, const float* XS, int ldt, const float* mask4, float drop_rate,
                                     const float* Hs, int ldh, const float* dZ, float* dWp, float* dUp, float* dbp, int B,
                                     int T, int F, int H, int reverse, void* ws, size_t ws_bytes, const unsigned* dzmax,
-                                    const float* dbsum, const void* proj_ws);
+                                    const float* dbsum, const void* proj_ws, const float* HsT);
 /* (dzmax: the row maxima of dZ if the BPTT left them - mgr_scan_bwd_job.dzmax - or NULL: this call finds them with one more pass.
  *  dbsum: the per-sample sums of dZ over time if the BPTT left them - mgr_scan_bwd_job.dbsum - then db = their sum over the samples in
  *  sample order; or NULL: db from a pass over dZ, as in mgr_lstm_param_grads.
  *  proj_ws: the workspace of the mgr_lstm_input_proj_dropout_ts call that projected with the SAME mask4 (same B, F, H), untouched since -
- *  its kept lists are used instead of being built again; or NULL.) */
+ *  its kept lists are used instead of being built again; or NULL.
+ *  HsT: the rows h_prev in the split row format - mgr_transpose_bt_split_shift of this direction's outputs Hs with tshift = -1 (forward) /
+ *  +1 (reverse), [B][H][ldt] - then dU is formed like dW, on the f16 matrix pipe against the same dZ^T rows (16 <= H); or NULL: the f32
+ *  product of mgr_lstm_param_grads.) */
 /* dX[b,t,0:F] (stride lddx) (+)= sum_g mask4[g] (.) (dZ_g . W_g^T); accumulate=1 adds into dX. */
 int mgr_lstm_input_grad(mgr_ctx* ctx, const float* dZ, const float* Wp, const float* mask4, float* dX,
                         int lddx, int accumulate, int B, int T, int F, int H);

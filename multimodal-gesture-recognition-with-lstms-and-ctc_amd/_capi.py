@@ -53,6 +53,7 @@ SIGNATURES = {
     "mgr_lstm_input_proj_dropout_ts_ws_bytes": (sz, [i32, i32, i32]),
     "mgr_lstm_input_proj_dropout_ts": (i32, [vp, vp, i32, vp, C.c_float, vp, vp, vp, i32, i32, i32, i32, vp, sz]),
     "mgr_transpose_bt_split": (i32, [vp, vp, i32, vp, i32, i32, i32, i32]),
+    "mgr_transpose_bt_split_shift": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32]),
     "mgr_weight_planes_cache": (i32, [vp, vp, i32]),
     "mgr_lstm_input_proj_pair": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
     "mgr_lstm_scan_ws_bytes": (sz, [i32, i32, i32]),
@@ -94,7 +95,7 @@ SIGNATURES = {
     "mgr_lstm_param_grads_dropout_t_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
     "mgr_lstm_param_grads_dropout_t": (i32, [vp, vp, i32, vp, C.c_float, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, C.c_float]),
     "mgr_lstm_param_grads_dropout_ts_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
-    "mgr_lstm_param_grads_dropout_ts": (i32, [vp, vp, i32, vp, C.c_float, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp, vp, vp]),
+    "mgr_lstm_param_grads_dropout_ts": (i32, [vp, vp, i32, vp, C.c_float, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp, vp, vp, vp]),
     "mgr_lstm_input_grad": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32]),
     "mgr_dense_softmax_fwd": (i32, [vp, vp, i32, vp, C.c_float, u64, vp, vp, vp, i32, i32, i32, i32]),
     "mgr_dense_bwd_ws_bytes": (sz, [i32, i32, i32, i32]),

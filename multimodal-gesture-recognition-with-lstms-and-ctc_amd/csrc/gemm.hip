@@ -1618,7 +1618,7 @@ static int param_grads_impl(mgr_ctx* c, const float* X, int ldx, const float* ma
     size_t n = (size_t)F * N;
     hipLaunchKernelGGL(k_reduce, dim3((int)((n + 255) / 256)), dim3(256), 0, s, slabW, dWp, n, sgW);
   }
-  {
+  if (dUp) {   // (null: the caller forms dU itself - gemm_split.hip, from the split transposed copy of h_prev)
     // h_prev: forward direction uses h[t-1], reverse direction uses h[t+1]
     int vecA = (ldh % 4 == 0) && (H % 4 == 0) && aligned16(Hs);
     dim3 grid((N + BN - 1) / BN, (H + BM - 1) / BM, sgU);

@@ -68,7 +68,10 @@ __global__ __launch_bounds__(64) void k_lists32(const float* __restrict__ mask4,
       n += __popcll(bal);
     }
   } else {   // no mask: every feature kept, factor 1
-    for (int f = lane; f < F; f += 64) out[f] = f | (f << 16);
+    for (int f = lane; f < F; f += 64) {
+      out[f] = f | (f << 16);
+      if (kpos) kpos[(size_t)gb * F + f] = f;
+    }
     n = F;
     seen = __float_as_uint(1.f);
   }
@@ -137,9 +140,11 @@ __global__ __launch_bounds__(256) void k_wplanes(const float* __restrict__ Wp, _
   }
 }
 
-// XS[b][f] = split row of X[b][0..T)[f] (zero for t >= T): the generic producer of the split row format
+// XS[b][f] = split row of X[b][0..T)[f] (zero for t >= T): the generic producer of the split row format.  tshift: entry t of a row is
+// X[b][t + tshift][f], zero where that step does not exist (tshift = -1 / +1: the rows h_{t-1} / h_{t+1} the recurrent weight gradient of a
+// forward / reverse direction multiplies dz_t with)
 __global__ __launch_bounds__(256) void k_transpose_split(const float* __restrict__ X, int ldx, float* __restrict__ XS, int ldt, int T, int F,
-                                                         long long xsb /* batch stride of XS in floats; 0: F * ldt */, int fill) {
+                                                         long long xsb /* batch stride of XS in floats; 0: F * ldt */, int fill, int tshift) {
   __shared__ float tile[64][65];
   const int b = blockIdx.z, t0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -147,8 +152,8 @@ __global__ __launch_bounds__(256) void k_transpose_split(const float* __restrict
   float* XSb = XS + (size_t)b * (xsb ? (size_t)xsb : (size_t)F * ldt);
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const int t = t0 + ty + 4 * i, f = f0 + tx;
-    tile[ty + 4 * i][tx] = (t < T && f < F) ? Xb[(size_t)t * ldx + f] : 0.f;
+    const int t = t0 + ty + 4 * i, f = f0 + tx, ts = t + tshift;
+    tile[ty + 4 * i][tx] = (t < T && ts >= 0 && ts < T && f < F) ? Xb[(size_t)ts * ldx + f] : 0.f;
   }
   __syncthreads();
 #pragma unroll
@@ -707,11 +712,15 @@ int mgr_lstm_input_proj_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const f
   return 0;
 }
 
-static size_t dw_ts_extra(int B, int F, int H, int ldt) {
+// lists | counts | words | list positions | partial tiles of a dW-shaped product with F input rows
+static size_t dw_ts_lists_and_tiles(int B, int F, int H) {
   const size_t Fp32 = (size_t)fp32_of(F);
   return mgr_align_up((size_t)4 * B * Fp32 * sizeof(int), 256) + mgr_align_up((size_t)4 * B * sizeof(int), 256) + 256 +
-         mgr_align_up((size_t)4 * B * F * sizeof(int), 256) + mgr_align_up((size_t)4 * B * Fp32 * H * sizeof(float), 256) +
-         mgr_align_up((size_t)B * 4 * H * ldt * sizeof(float), 256) + mgr_align_up((size_t)B * 4 * H * sizeof(unsigned), 256);
+         mgr_align_up((size_t)4 * B * F * sizeof(int), 256) + mgr_align_up((size_t)4 * B * Fp32 * H * sizeof(float), 256);
+}
+static size_t dw_ts_extra(int B, int F, int H, int ldt) {
+  return dw_ts_lists_and_tiles(B, F, H) + mgr_align_up((size_t)B * 4 * H * ldt * sizeof(float), 256) +
+         mgr_align_up((size_t)B * 4 * H * sizeof(unsigned), 256) + dw_ts_lists_and_tiles(B, H, H);   // (the last: dU from HsT, F = H rows)
 }
 
 size_t mgr_lstm_param_grads_dropout_ts_ws_bytes(int B, int T, int F, int H, int ldt) {
@@ -720,7 +729,8 @@ size_t mgr_lstm_param_grads_dropout_ts_ws_bytes(int B, int T, int F, int H, int 
 
 int mgr_lstm_param_grads_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const float* mask4, float drop_rate, const float* Hs, int ldh,
                                     const float* dZ, float* dWp, float* dUp, float* dbp, int B, int T, int F, int H, int reverse,
-                                    void* ws, size_t ws_bytes, const unsigned* dzmax, const float* dbsum, const void* proj_ws) {
+                                    void* ws, size_t ws_bytes, const unsigned* dzmax, const float* dbsum, const void* proj_ws,
+                                    const float* HsT) {
   MGR_REQUIRE(c && XS && mask4 && Hs && dZ && dWp && dUp && dbp, "null argument");
   MGR_REQUIRE(B > 0 && T > 0 && H > 0 && F >= 16 && F <= 2048 && ldh >= H, "bad shape (16 <= F <= 2048)");
   MGR_REQUIRE(ldt % 32 == 0 && ldt >= (T + DW_TK - 1) / DW_TK * DW_TK, "the split copy must be padded to whole stages of %d time steps (ldt %d, T %d)", DW_TK, ldt, T);
@@ -730,7 +740,8 @@ int mgr_lstm_param_grads_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const 
   (void)drop_rate;
   mgr_prof_begin(c, MGR_K_GEMM_TN);
   // dU / db first: they are short, and in the training step the long dW kernel then ends this direction's work (gemm.hip)
-  int r = mgr_param_grads_du_db(c, Hs, ldh, dZ, dUp, dbp, B, T, F, H, reverse, ws, dbsum);
+  MGR_REQUIRE(!HsT || (H >= 16 && aligned16(HsT) && (size_t)H * ldt * 4 < (1ull << 32)), "HsT: 16 <= H, 16-byte aligned");
+  int r = mgr_param_grads_du_db(c, Hs, ldh, dZ, HsT ? nullptr : dUp, dbp, B, T, F, H, reverse, ws, dbsum);
   if (r) return r;
   const int Fp32 = fp32_of(F), N = 4 * H;
   char* w = reinterpret_cast<char*>(ws) + mgr_lstm_param_grads_ws_bytes(B, T, F, H);
@@ -747,6 +758,18 @@ int mgr_lstm_param_grads_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const 
   float* dZS = reinterpret_cast<float*>(w);
   w += mgr_align_up((size_t)B * N * ldt * sizeof(float), 256);
   const unsigned* zmax = dzmax ? dzmax : reinterpret_cast<unsigned*>(w);   // (the BPTT's own row maxima, or found here)
+  w += mgr_align_up((size_t)B * N * sizeof(unsigned), 256);
+  // dU from HsT: the same product with the H rows h_prev in place of the kept input features (every row kept, factor 1)
+  const int Hp32 = fp32_of(H);
+  int* lists2 = reinterpret_cast<int*>(w);
+  w += mgr_align_up((size_t)4 * B * Hp32 * sizeof(int), 256);
+  int* kcnt2 = reinterpret_cast<int*>(w);
+  w += mgr_align_up((size_t)4 * B * sizeof(int), 256);
+  unsigned* words2 = reinterpret_cast<unsigned*>(w);
+  w += 256;
+  int* kpos2 = reinterpret_cast<int*>(w);
+  w += mgr_align_up((size_t)4 * B * H * sizeof(int), 256);
+  float* P2 = reinterpret_cast<float*>(w);
   hipStream_t s = mgr_stream(c);
   if (!(c->attr_done & 32u)) {
     MGR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dw_split<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * DW_STAGE));
@@ -768,8 +791,21 @@ int mgr_lstm_param_grads_dropout_ts(mgr_ctx* c, const float* XS, int ldt, const 
     MGR_HIP(hipMemsetAsync(words, 0, 2 * sizeof(unsigned), s));
     hipLaunchKernelGGL(k_lists32, dim3(4 * B), dim3(64), 0, s, mask4, F, Fp32, lists, kcnt, kpos, words + 1);
   }
-  if (!dzmax) hipLaunchKernelGGL(k_rowmax_bt, dim3((N + 63) / 64, B), dim3(256), 0, s, dZ, N, T, reinterpret_cast<unsigned*>(w), (float*)nullptr);
+  if (!dzmax) hipLaunchKernelGGL(k_rowmax_bt, dim3((N + 63) / 64, B), dim3(256), 0, s, dZ, N, T, const_cast<unsigned*>(zmax), (float*)nullptr);
   hipLaunchKernelGGL(k_transpose_split_scaled, dim3((ldt + 63) / 64, (N + 63) / 64, B), dim3(256), 0, s, dZ, N, dZS, ldt, T, zmax);
+  if (HsT) {
+    const int grid2 = 8 * ((B + 7) / 8) * 4 * ((Hp32 + DW_BM - 1) / DW_BM) * ((H + DW_BN - 1) / DW_BN);
+    MGR_HIP(hipMemsetAsync(words2, 0, 2 * sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_lists32, dim3(4 * B), dim3(64), 0, s, (const float*)nullptr, H, Hp32, lists2, kcnt2, kpos2, words2 + 1);
+    if (c->tune[12] == 1)
+      hipLaunchKernelGGL(k_dw_split<4>, dim3(grid2), dim3(256), 3 * DW_STAGE, s, reinterpret_cast<const char*>(HsT), ldt, lists2, kcnt2, words2 + 1,
+                         reinterpret_cast<const char*>(dZS), zmax, P2, B, T, Hp32, H, H);
+    else
+      hipLaunchKernelGGL(k_dw_split<8>, dim3(grid2), dim3(512), 4 * DW_STAGE, s, reinterpret_cast<const char*>(HsT), ldt, lists2, kcnt2, words2 + 1,
+                         reinterpret_cast<const char*>(dZS), zmax, P2, B, T, Hp32, H, H);
+    const size_t n2 = (size_t)4 * H * H;
+    hipLaunchKernelGGL(k_dw_gather32, dim3((int)((n2 + 255) / 256 < 4096 ? (n2 + 255) / 256 : 4096)), dim3(256), 0, s, P2, kpos2, dUp, B, H, Hp32, H);
+  }
   const int grid = 8 * ((B + 7) / 8) * 4 * ((Fp32 + DW_BM - 1) / DW_BM) * ((H + DW_BN - 1) / DW_BN);
   // tune key 12 (the tile switch of the projection): 1 = the 4-wave form, which fits on a CU beside a workgroup of a persistent scan
   if (c->tune[12] == 1)
@@ -810,7 +846,17 @@ int mgr_transpose_bt_split(mgr_ctx* c, const float* X, int ldx, float* XS, int l
   MGR_REQUIRE(c && X && XS, "null argument");
   MGR_REQUIRE(B > 0 && T > 0 && F > 0 && ldx >= F && ldt >= T && ldt % 8 == 0, "bad shape");
   mgr_prof_begin(c, MGR_K_MISC);
-  hipLaunchKernelGGL(k_transpose_split, dim3((ldt + 63) / 64, (F + 63) / 64, B), dim3(256), 0, mgr_stream(c), X, ldx, XS, ldt, T, F, 0LL, ldt);
+  hipLaunchKernelGGL(k_transpose_split, dim3((ldt + 63) / 64, (F + 63) / 64, B), dim3(256), 0, mgr_stream(c), X, ldx, XS, ldt, T, F, 0LL, ldt, 0);
+  MGR_LAUNCH_CHECK();
+  mgr_prof_end(c, MGR_K_MISC);
+  return 0;
+}
+
+int mgr_transpose_bt_split_shift(mgr_ctx* c, const float* X, int ldx, float* XS, int ldt, int B, int T, int F, int tshift) {
+  MGR_REQUIRE(c && X && XS, "null argument");
+  MGR_REQUIRE(B > 0 && T > 0 && F > 0 && ldx >= F && ldt >= T && ldt % 8 == 0 && tshift >= -1 && tshift <= 1, "bad shape");
+  mgr_prof_begin(c, MGR_K_MISC);
+  hipLaunchKernelGGL(k_transpose_split, dim3((ldt + 63) / 64, (F + 63) / 64, B), dim3(256), 0, mgr_stream(c), X, ldx, XS, ldt, T, F, 0LL, ldt, tshift);
   MGR_LAUNCH_CHECK();
   mgr_prof_end(c, MGR_K_MISC);
   return 0;
@@ -825,7 +871,7 @@ int mgr_rowmax_bt(mgr_ctx* c, const float* dZ, int N, int T, int B, unsigned* zm
 }
 
 int mgr_transpose_bt_split_strided(mgr_ctx* c, const float* X, int ldx, float* XS, int ldt, long long xsb, int ldt_fill, int B, int T, int F) {
-  hipLaunchKernelGGL(k_transpose_split, dim3((ldt_fill + 63) / 64, (F + 63) / 64, B), dim3(256), 0, mgr_stream(c), X, ldx, XS, ldt, T, F, xsb, ldt_fill);
+  hipLaunchKernelGGL(k_transpose_split, dim3((ldt_fill + 63) / 64, (F + 63) / 64, B), dim3(256), 0, mgr_stream(c), X, ldx, XS, ldt, T, F, xsb, ldt_fill, 0);
   MGR_LAUNCH_CHECK();
   return 0;
 }

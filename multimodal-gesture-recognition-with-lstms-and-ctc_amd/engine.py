@@ -68,6 +68,8 @@ class _LstmDir:
         self.gates = self.cs = self.dZ = self.dzmax = self.dbsum = None
         self.ws_scan = self.ws_pg = self.ws_sp = None
         self.lists_mask = 0     # the mask whose kept lists the projection of this step left in ws_sp (0: none)
+        self.HsT = None         # [B][H][ldt] split rows of h_prev (the recurrent weight gradient as a product along time; first use)
+        self.hst_ready = False  # ... already written for the step in flight (Engine._prep_hst)
 
 
 class Schedule:
@@ -125,6 +127,9 @@ class Schedule:
     bptt_single_cu      (round 6; measured, not the default) narrow trainable layers (H in {32, 64, 100}) run their BPTT on ONE CU per
                         (direction, 16-sample group) without an inter-CU exchange (MGR_BPTT_FORM_SINGLE_CU, lstm_cu_bwd.hip) - in every
                         schedule (its results equal the multi-CU forms' to rounding, not bit for bit)
+    du_split            (round 6) the recurrent weight gradient dU of a layer whose dW runs on pre-split rows is formed the same way - the
+                        split rows of h_prev along time (one transposing pass over the layer's outputs) against the dZ^T rows the dW
+                        product reads anyway - instead of by the f32 split-K product and its slab reduction
     split_rows          (round 5) the transposed copies are written in the split row format (f16 hi / lo pairs) and the wide products
                         run as loader / matrix pipelines on pre-split operands (gemm_split.hip); False: f32 rows, converted by
                         every product that reads them (round 4's kernels)
@@ -139,8 +144,9 @@ class Schedule:
                  deepest_scan_after_fusion_proj=True, depth1_proj_ahead=True, bptt_yields_beside_scans=True,
                  fused_encoder_scans=True, fused_wide_tiles=True, bptt_direct_when_alone=False, fusion_scan_fused=True,
                  bptt_fused=False, chain_stream_priority=0, param_grads_two_streams=False, first_pass_on_encoder_stream=True,
-                 bptt_single_cu=False):
+                 bptt_single_cu=False, du_split=True):
         self.bptt_single_cu = bool(bptt_single_cu)
+        self.du_split = bool(du_split)
         self.first_pass_on_encoder_stream = bool(first_pass_on_encoder_stream)
         self.param_grads_two_streams = bool(param_grads_two_streams)
         self.chain_stream_priority = int(chain_stream_priority)
@@ -1684,9 +1690,14 @@ class Engine:
                     # (the projection of this step left the kept lists of this very mask in its workspace: not built again)
                     pws = L.ws_sp if (L.ws_sp is not None and L.lists_mask == mptr) else 0
                     L.lists_mask = 0
+                    # dU like dW: from the split rows of h_prev along time against the same dZ^T rows (Schedule.du_split)
+                    hst = 0
+                    if self.schedule.du_split and H >= 16:
+                        self._prep_hst(L, Hbuf.view(di * H, (1,)), ldh)
+                        hst, L.hst_ready = L.HsT, False
                     with self._narrow_tiles(beside_scans and not wide_ok):
                         dev.call("mgr_lstm_param_grads_dropout_ts", XinT, self.ldt, mptr, float(L.p), Hbuf.view(di * H, (1,)), ldh, L.dZ,
-                                 L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes, L.dzmax, L.dbsum, pws)
+                                 L.gWp, L.gUp, L.gbp, B, T, fin, H, L.reverse, L.ws_pg, L.ws_pg.nbytes, L.dzmax, L.dbsum, pws, hst)
                 elif mptr and XinT is not None and self.lib.mgr_lstm_param_grads_dropout_wants_transposed(
                         dev.ctx, C.c_float(float(L.p)), int(fin)):
                     need = self.lib.mgr_lstm_param_grads_dropout_t_ws_bytes(B, T, fin, H, self.ldt)
@@ -1711,6 +1722,16 @@ class Engine:
                 mptr = self._masks.get((L.prefix, L.d), 0)
                 dev.call("mgr_lstm_input_grad", L.dZ, L.Wp, mptr, dX, lddx, 1 if di == 1 else 0, B, T, fin, L.H)
         return param_grads if defer_param_grads else None
+
+    def _prep_hst(self, L, Hdir, ldh):
+        """The split transposed copy of h_prev of direction L (rows h_{t-1} forward, h_{t+1} reverse) from its outputs Hdir, on the
+        current stream, unless this step's copy exists already."""
+        if L.hst_ready:
+            return
+        if L.HsT is None:
+            L.HsT = self.dev.zeros((self.B, L.H, self.ldt))
+        self.dev.call("mgr_transpose_bt_split_shift", Hdir, ldh, L.HsT, self.ldt, self.B, self.T, L.H, 1 if L.reverse else -1)
+        L.hst_ready = True
 
     def _stream_backward(self, s, col):
         sp, dev, B, T = self.spec, self.dev, self.B, self.T

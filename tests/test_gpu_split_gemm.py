@@ -99,16 +99,16 @@ def test_weight_gradient_from_split_rows(device, B, T, F, H, p, reverse):
         gW, gU, gb = dev.empty((F, N)), dev.empty((H, N)), dev.empty((N,))
         gW.upload(np.full((F, N), np.nan, f32))
         dev.call("mgr_memset", ws, 0xFF, ws.nbytes)          # the workspace arrives dirty
-        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW, gU, gb, B, T, F, H, reverse, ws, ws.nbytes, 0, 0, 0)
+        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW, gU, gb, B, T, F, H, reverse, ws, ws.nbytes, 0, 0, 0, 0)
         # ... and with the row maxima handed in (what the BPTT leaves: mgr_scan_bwd_job.dzmax): the same bits
         zmx = dev.array(np.abs(dZ).max(axis=1).astype(f32).view(np.uint32))
         gW3 = dev.empty((F, N))
-        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW3, gU, gb, B, T, F, H, reverse, ws, ws.nbytes, zmx, 0, 0)
+        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW3, gU, gb, B, T, F, H, reverse, ws, ws.nbytes, zmx, 0, 0, 0)
         assert np.array_equal(gW3.download(), gW.download())
         # ... and with the sums over time handed in (mgr_scan_bwd_job.dbsum): db is their sum over the samples, dW / dU the same bits
         zsm = dev.array(dZ.astype(np.float64).sum(axis=1).astype(f32))
         gU3, gb3 = dev.empty((H, N)), dev.empty((N,))
-        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW3, gU3, gb3, B, T, F, H, reverse, ws, ws.nbytes, zmx, zsm, 0)
+        dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW3, gU3, gb3, B, T, F, H, reverse, ws, ws.nbytes, zmx, zsm, 0, 0)
         assert np.array_equal(gW3.download(), gW.download()) and np.array_equal(gU3.download(), gU.download())
         dbref = dZ.astype(np.float64).sum(axis=(0, 1))
         assert np.abs(gb3.download() - dbref).max() <= 2e-6 * np.abs(dZ).sum(axis=(0, 1)).max()
@@ -121,8 +121,29 @@ def test_weight_gradient_from_split_rows(device, B, T, F, H, p, reverse):
             dev.call("mgr_lstm_input_proj_dropout_ts", XS, ldt, dM, p, Wp_, bp_, Z_, B, T, F, H, pws, pws.nbytes)
             dev.call("mgr_memset", ws, 0xFF, ws.nbytes)
             gW4 = dev.empty((F, N))
-            dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p, dH, H, ddZ, gW4, gU3, gb3, B, T, F, H, reverse, ws, ws.nbytes, zmx, zsm, pws)
+            dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p, dH, H, ddZ, gW4, gU3, gb3, B, T, F, H, reverse, ws, ws.nbytes, zmx, zsm, pws, 0)
             assert np.array_equal(gW4.download(), gW.download())
+        # ... and dU formed like dW (HsT: the split rows of h_prev along time, mgr_transpose_bt_split_shift): against fp64, with the bound of
+        # dW (per column: the spread of the gate gradients is per column); dW itself the same bits
+        if H >= 16:
+            HsT = dev.zeros((B, H, ldt))
+            dev.call("mgr_transpose_bt_split_shift", dH, H, HsT, ldt, B, T, H, 1 if reverse else -1)
+            hp = np.zeros_like(Hs, dtype=np.float64)
+            if reverse:
+                hp[:, :-1] = Hs[:, 1:]
+            else:
+                hp[:, 1:] = Hs[:, :-1]
+            refU = np.einsum("btk,btn->kn", hp, dZ.astype(np.float64))
+            gW5, gU5 = dev.empty((F, N)), dev.empty((H, N))
+            gU5.upload(np.full((H, N), np.nan, f32))
+            dev.call("mgr_memset", ws, 0xFF, ws.nbytes)
+            dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, p if p < 0.99 else 0.5, dH, H, ddZ, gW5, gU5, gb3, B, T, F, H, reverse, ws, ws.nbytes, zmx, zsm, 0, HsT)
+            assert np.array_equal(gW5.download(), gW.download())
+            gotU = gU5.download()
+            cs = np.maximum(np.abs(refU).max(axis=0, keepdims=True), 1e-30)
+            assert np.all(np.isfinite(gotU)) and (np.abs(gotU - refU) / cs).max() <= 3e-5, (spread, (np.abs(gotU - refU) / cs).max())
+            refU32 = gU.download()      # (the f32 split-K product: how far the two forms are apart, in the same measure)
+            assert (np.abs(gotU - refU32) / cs).max() <= 6e-5
         got = gW.download()
         colscale = np.maximum(np.abs(ref).max(axis=0, keepdims=True), 1e-30)      # per column: the spread is per column
         assert np.all(np.isfinite(got)) and (np.abs(got - ref) / colscale).max() <= 3e-5, (spread, (np.abs(got - ref) / colscale).max())

@@ -26,7 +26,7 @@ for (B, T, F, H) in ((16, 96, 1600, 100), (64, 1900, 1600, 100)):
         for rep in range(40):
             gW, gU, gb = dev.empty((F, N)), dev.empty((H, N)), dev.empty((N,))
             dev.call("mgr_memset", ws, 0xFF if rep % 2 else 0x00, ws.nbytes)
-            dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, 0.5, dH, H, ddZ, gW, gU, gb, B, T, F, H, 0, ws, ws.nbytes, zmx if rep % 3 else 0, 0, 0)
+            dev.call("mgr_lstm_param_grads_dropout_ts", XS, ldt, dM, 0.5, dH, H, ddZ, gW, gU, gb, B, T, F, H, 0, ws, ws.nbytes, zmx if rep % 3 else 0, 0, 0, 0)
             g = gW.download()
             if ref is None:
                 ref = g
