@@ -588,9 +588,11 @@ __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_gemm_nn_sparse(co
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           const int row = r0 + wr * 64 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-          if (row < T)
-            *reinterpret_cast<float4*>(Z + ((size_t)b * T + row) * N + unit * 4) =
-                make_float4(acc[0][mt][reg] + bias.x, acc[1][mt][reg] + bias.y, acc[2][mt][reg] + bias.z, acc[3][mt][reg] + bias.w);
+          if (row < T) {
+            typedef float nt_f4 __attribute__((ext_vector_type(4)));
+            const nt_f4 v = {acc[0][mt][reg] + bias.x, acc[1][mt][reg] + bias.y, acc[2][mt][reg] + bias.z, acc[3][mt][reg] + bias.w};
+            __builtin_nontemporal_store(v, reinterpret_cast<nt_f4*>(Z + ((size_t)b * T + row) * N + unit * 4));
+          }
         }
     }
   }
