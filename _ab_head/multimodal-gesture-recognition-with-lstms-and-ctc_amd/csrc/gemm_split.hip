@@ -397,13 +397,10 @@ __global__ __launch_bounds__(128 * WC, WC == 2 ? 2 : 1) void k_proj_split(const 
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int row = r0 + wr * 64 + mb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-        if (row < T) {
-          // (non-temporal: Z is read once, by a scan, milliseconds later - it need not displace what concurrent products keep in L2)
-          typedef float nt_f4 __attribute__((ext_vector_type(4)));
-          const nt_f4 v = {fmaf(acc[0][mb][reg], inv, bias.x), fmaf(acc[1][mb][reg], inv, bias.y), fmaf(acc[2][mb][reg], inv, bias.z),
-                           fmaf(acc[3][mb][reg], inv, bias.w)};
-          __builtin_nontemporal_store(v, reinterpret_cast<nt_f4*>(Z + ((size_t)b * T + row) * N + unit * 4));
-        }
+        if (row < T)
+          *reinterpret_cast<float4*>(Z + ((size_t)b * T + row) * N + unit * 4) =
+              make_float4(fmaf(acc[0][mb][reg], inv, bias.x), fmaf(acc[1][mb][reg], inv, bias.y), fmaf(acc[2][mb][reg], inv, bias.z),
+                          fmaf(acc[3][mb][reg], inv, bias.w));
       }
   }
 }
